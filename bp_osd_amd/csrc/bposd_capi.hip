@@ -1,0 +1,664 @@
+// bposd_capi.hip -- host side of libbposd_mi355x.so: the C-ABI declared in
+// include/bposd_mi355x.h, Tanner-graph table construction, kernel dispatch, workspace
+// and HIP-event timing.  gfx950 only; there is no CPU fallback anywhere in this file:
+// without a HIP device every entry point fails with BPOSD_ERR_NO_DEVICE.
+//
+// Reference interface replaced: the `bposd_decoder` / `BpOsdDecoder` object of the
+// third-party `ldpc` package as used at /root/reference/README.md:178-202 and
+// /root/reference/src/bposd/css_decode_sim.py:444-463,174-202.
+#include "../../include/bposd_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bp_kernel.hip.h"
+#include "osd_kernel.hip.h"
+
+using namespace bposd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct bposd_handle {
+    bposd_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int num_cu = 0;
+    size_t lds_per_cu = 160 * 1024;
+    int m = 0, n = 0, E = 0;
+    int dc_max = 0, dv_max = 0;
+    bool regular = false;
+    int max_iter = 0;
+    int rank = 0, kprime = 0, ncand = 0;
+    bool probs_uniform = true;
+    int bp_variant = 0;
+    // host copies
+    std::vector<int> rp, ci;
+    std::vector<double> probs;
+    // device tables
+    int *d_rp = nullptr, *d_ci = nullptr;
+    int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr, *d_var_row = nullptr;
+    double* d_llr0 = nullptr;
+    int tab_dc = 0, tab_dv = 0;  // layout the tables were built for
+    // workspace (grow-only)
+    DevBuf llr_ws, osd_list, io_synd, io_osdw, io_osd0, io_bp, io_conv, io_iters, io_llr;
+    int* d_counters = nullptr;              // 4 ints
+    unsigned long long* d_iter_total = nullptr;
+    int* h_counters = nullptr;              // pinned: 4 ints
+    unsigned long long* h_iter_total = nullptr;  // pinned
+    bool have_timing = false;
+    bool ran_osd = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(bposd_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(h, BPOSD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+int ensure(bposd_handle* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.bytes && b.p) return 0;
+    if (b.p) {
+        HIP_TRY(h, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = std::max<size_t>(bytes, 256);
+    HIP_TRY(h, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return 0;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+// GF(2) rank of the pcm by packed elimination (ctor-time, host).  a1: upstream's ctor
+// eliminates H once to learn rank and k' = n - rank.
+int gf2_rank_host(int m, int n, const std::vector<int>& rp, const std::vector<int>& ci) {
+    const int W = (n + 63) / 64;
+    std::vector<uint64_t> a((size_t)m * W, 0);
+    for (int r = 0; r < m; ++r)
+        for (int e = rp[r]; e < rp[r + 1]; ++e) a[(size_t)r * W + (ci[e] >> 6)] |= 1ull << (ci[e] & 63);
+    int rank = 0;
+    for (int j = 0; j < n && rank < m; ++j) {
+        const int w = j >> 6;
+        const uint64_t bit = 1ull << (j & 63);
+        int p = -1;
+        for (int r = rank; r < m; ++r)
+            if (a[(size_t)r * W + w] & bit) { p = r; break; }
+        if (p < 0) continue;
+        if (p != rank)
+            for (int x = 0; x < W; ++x) std::swap(a[(size_t)p * W + x], a[(size_t)rank * W + x]);
+        for (int r = rank + 1; r < m; ++r)
+            if (a[(size_t)r * W + w] & bit)
+                for (int x = w; x < W; ++x) a[(size_t)r * W + x] ^= a[(size_t)rank * W + x];
+        ++rank;
+    }
+    return rank;
+}
+
+struct DegPair { int dc, dv; };
+const DegPair kPairs[] = {{4, 2}, {6, 3}, {8, 4}, {12, 6}, {16, 8}};
+
+bool pick_pair(int dc, int dv, DegPair* out) {
+    for (const auto& p : kPairs)
+        if (p.dc >= dc && p.dv >= dv) { *out = p; return true; }
+    return false;
+}
+
+size_t bp_lds_bytes(int DC, int m) {
+    const int dwords = (m + 31) / 32;
+    return (size_t)DC * m * 8 + (size_t)((dwords + 1) & ~1) * 4 + 64;
+}
+
+int upload_priors(bposd_handle* h) {
+    // a3: prior LLR = log((1 - p) / p), evaluated on the host in fp64 (same libm call the
+    // CPU path makes) so that device arithmetic is add / compare / multiply only.
+    std::vector<double> l0(h->n);
+    for (int i = 0; i < h->n; ++i) l0[i] = std::log((1 - h->probs[i]) / h->probs[i]);
+    HIP_TRY(h, hipMemcpy(h->d_llr0, l0.data(), sizeof(double) * h->n, hipMemcpyHostToDevice));
+    h->probs_uniform = true;
+    for (int i = 1; i < h->n; ++i)
+        if (h->probs[i] != h->probs[0]) { h->probs_uniform = false; break; }
+    return 0;
+}
+
+int build_tables(bposd_handle* h, int DC, int DV) {
+    const int m = h->m, n = h->n;
+    std::vector<int> chk_deg(m), var_deg(n, 0);
+    std::vector<int> var_pos((size_t)DV * n, 0), var_row((size_t)DV * n, 0);
+    for (int c = 0; c < m; ++c) {
+        chk_deg[c] = h->rp[c + 1] - h->rp[c];
+        for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
+            const int k = e - h->rp[c];
+            const int i = h->ci[e];
+            const int d = var_deg[i]++;  // rows visited ascending => ascending row within a column
+            var_pos[(size_t)d * n + i] = k * m + c;
+            var_row[(size_t)d * n + i] = c;
+        }
+    }
+    auto up = [&](int** dst, const std::vector<int>& v) -> int {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        HIP_TRY(h, hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1)));
+        HIP_TRY(h, hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc;
+    if ((rc = up(&h->d_chk_deg, chk_deg))) return rc;
+    if ((rc = up(&h->d_var_deg, var_deg))) return rc;
+    if ((rc = up(&h->d_var_pos, var_pos))) return rc;
+    if ((rc = up(&h->d_var_row, var_row))) return rc;
+    h->tab_dc = DC;
+    h->tab_dv = DV;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ BP launch
+template <int DC, int DV, int CPT, int VPT, int MAXNT, int MINW, bool REG>
+int launch_bp_t(bposd_handle* h, const BpParams& P, int NT) {
+    const size_t lds = bp_lds_bytes(DC, h->m);
+    int wg_per_cu = (int)std::min<size_t>(h->lds_per_cu / lds, (size_t)(2048 / NT));
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
+    long long grid = std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu);
+    if (grid < 1) grid = 1;
+    if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
+        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 1>;
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, P);
+    } else {
+        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 0>;
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, P);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int round64(int x) { return std::max(64, (x + 63) / 64 * 64); }
+
+// shape id: 1 -> (CPT 1, VPT 2, <=1024 threads), 2 -> (2, 4, <=512), 4 -> (4, 8, <=256)
+int shape_threads(const bposd_handle* h, int shape) {
+    const int cpt = shape, vpt = 2 * shape;
+    return round64(std::max((h->m + cpt - 1) / cpt, (h->n + vpt - 1) / vpt));
+}
+
+int pick_shape(const bposd_handle* h) {
+    const int caps[3][2] = {{1, 1024}, {2, 512}, {4, 256}};
+    if (h->bp_variant) {
+        for (auto& c : caps)
+            if (c[0] == h->bp_variant && shape_threads(h, c[0]) <= c[1]) return c[0];
+    }
+    // auto: small codes keep one check per thread; otherwise the widest shape that fits
+    if (shape_threads(h, 1) <= 256) return 1;
+    if (h->regular && h->dc_max == 6 && h->dv_max == 3) {
+        if (shape_threads(h, 2) <= 512) return 2;
+    }
+    if (shape_threads(h, 1) <= 1024) return 1;
+    if (shape_threads(h, 2) <= 512) return 2;
+    return 0;
+}
+
+template <int DC, int DV, bool REG>
+int launch_bp_shape(bposd_handle* h, const BpParams& P, int shape, int NT) {
+    // occupancy targets: LDS admits 3 workgroups per CU for H1922 (46 KB each); the regular
+    // (6,3) kernels are register-capped for that (2 x 1024, 3 x 512 or 3 x 256 threads per CU)
+    if (shape == 1) return launch_bp_t<DC, DV, 1, 2, 1024, (REG ? 8 : 4), REG>(h, P, NT);
+    if (shape == 2) return launch_bp_t<DC, DV, 2, 4, 512, (REG ? 6 : 2), REG>(h, P, NT);
+    if constexpr (REG) {
+        if (shape == 4) return launch_bp_t<DC, DV, 4, 8, 256, 3, REG>(h, P, NT);
+    }
+    return fail(h, BPOSD_ERR_UNSUPPORTED, "no BP kernel shape %d for this code", shape);
+}
+
+int launch_bp(bposd_handle* h, BpParams& P) {
+    int shape = pick_shape(h);
+    if (!shape) return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the LDS-resident BP kernel (m=%d n=%d)", h->m, h->n);
+    if (shape == 4 && !(h->regular && h->dc_max == 6 && h->dv_max == 3)) shape = 2;
+    const int NT = shape_threads(h, shape);
+    P.dc_rt = h->tab_dc;
+    if (h->regular && h->dc_max == 6 && h->dv_max == 3) return launch_bp_shape<6, 3, true>(h, P, shape, NT);
+    switch (h->tab_dc) {
+        case 4: return launch_bp_shape<4, 2, false>(h, P, shape, NT);
+        case 6: return launch_bp_shape<6, 3, false>(h, P, shape, NT);
+        case 8: return launch_bp_shape<8, 4, false>(h, P, shape, NT);
+        case 12: return launch_bp_shape<12, 6, false>(h, P, shape, NT);
+        case 16: return launch_bp_shape<16, 8, false>(h, P, shape, NT);
+    }
+    return fail(h, BPOSD_ERR_UNSUPPORTED, "no BP kernel for check degree %d / bit degree %d", h->dc_max, h->dv_max);
+}
+
+// ----------------------------------------------------------------------------- OSD launch
+template <int W>
+int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
+    const int NT = std::min(1024, round64(h->m));
+    const size_t lds = osd_lds_bytes(h->n, P.nsort, W);
+    long long grid = std::min<long long>(B, h->num_cu);
+    if (grid < 1) grid = 1;
+    auto k = osd_kernel<W>;
+    HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, P);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int osd_words(int n) {
+    const int need = (n + 1 + 63) / 64;
+    for (int w : {1, 2, 4, 8, 16, 32})
+        if (w >= need) return w;
+    return 0;
+}
+
+int launch_osd(bposd_handle* h, const OsdParams& P, long long B) {
+    switch (osd_words(h->n)) {
+        case 1: return launch_osd_t<1>(h, P, B);
+        case 2: return launch_osd_t<2>(h, P, B);
+        case 4: return launch_osd_t<4>(h, P, B);
+        case 8: return launch_osd_t<8>(h, P, B);
+        case 16: return launch_osd_t<16>(h, P, B);
+        case 32: return launch_osd_t<32>(h, P, B);
+    }
+    return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the register-resident OSD kernel (n=%d)", h->n);
+}
+
+int num_candidates(const bposd_handle* h) {
+    const int w = h->cfg.osd_order;
+    if (h->cfg.osd_method <= BPOSD_OSD_0 || w == 0) return 0;
+    if (h->cfg.osd_method == BPOSD_OSD_E) return (1 << w) - 1;
+    return h->kprime + w * (w - 1) / 2;
+}
+
+}  // namespace
+
+// ================================================================================ C-ABI
+extern "C" {
+
+int bposd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* bposd_version(void) { return "bposd_mi355x 0.1 (gfx950)"; }
+
+const char* bposd_last_error(bposd_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void bposd_destroy(bposd_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (DevBuf* b : {&h->llr_ws, &h->osd_list, &h->io_synd, &h->io_osdw, &h->io_osd0, &h->io_bp,
+                      &h->io_conv, &h->io_iters, &h->io_llr})
+        release(*b);
+    for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
+                    (void*)h->d_var_pos, (void*)h->d_var_row, (void*)h->d_llr0, (void*)h->d_counters,
+                    (void*)h->d_iter_total})
+        if (p) (void)hipFree(p);
+    if (h->h_counters) (void)hipHostFree(h->h_counters);
+    if (h->h_iter_total) (void)hipHostFree(h->h_iter_total);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* indices, int32_t m,
+                 int32_t n, const double* channel_probs, bposd_handle** out) {
+    if (out) *out = nullptr;
+    if (!cfg || !indptr || !indices || !channel_probs || !out)
+        return fail(nullptr, BPOSD_ERR_INVALID, "null argument");
+    if (m <= 0 || n <= 0) return fail(nullptr, BPOSD_ERR_INVALID, "empty parity-check matrix (%d x %d)", m, n);
+    if (cfg->bp_method != BPOSD_BP_PRODUCT_SUM && cfg->bp_method != BPOSD_BP_MIN_SUM)
+        return fail(nullptr, BPOSD_ERR_INVALID, "bp_method must be 0 (product-sum) or 1 (min-sum)");
+    if (cfg->osd_method < BPOSD_OSD_OFF || cfg->osd_method > BPOSD_OSD_CS)
+        return fail(nullptr, BPOSD_ERR_INVALID, "osd_method out of range");
+    if (cfg->max_iter < 0 || cfg->osd_order < 0) return fail(nullptr, BPOSD_ERR_INVALID, "negative max_iter / osd_order");
+    if (cfg->sort_tie_policy < 0 || cfg->sort_tie_policy > 1 || cfg->weight_fn < 0 || cfg->weight_fn > 1)
+        return fail(nullptr, BPOSD_ERR_INVALID, "sort_tie_policy / weight_fn out of range");
+    for (int k = 0; k < 4; ++k)
+        if (cfg->reserved[k] != 0) return fail(nullptr, BPOSD_ERR_INVALID, "reserved config fields must be 0");
+    if (indptr[0] != 0) return fail(nullptr, BPOSD_ERR_INVALID, "csr_indptr[0] must be 0");
+    for (int c = 0; c < m; ++c) {
+        if (indptr[c + 1] < indptr[c]) return fail(nullptr, BPOSD_ERR_INVALID, "csr_indptr not monotone");
+        for (int e = indptr[c]; e < indptr[c + 1]; ++e) {
+            if (indices[e] < 0 || indices[e] >= n) return fail(nullptr, BPOSD_ERR_INVALID, "column index out of range");
+            if (e > indptr[c] && indices[e] <= indices[e - 1])
+                return fail(nullptr, BPOSD_ERR_INVALID, "column indices must be strictly ascending within a row");
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (!(channel_probs[i] >= 0.0 && channel_probs[i] <= 1.0))
+            return fail(nullptr, BPOSD_ERR_INVALID, "channel_probs[%d] = %g is not a probability", i, channel_probs[i]);
+
+    int ndev = bposd_device_count();
+    if (ndev <= 0) return fail(nullptr, BPOSD_ERR_NO_DEVICE, "no HIP device visible: the MI355X decoder has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, BPOSD_ERR_INVALID, "device %d out of range (%d visible)", cfg->device, ndev);
+
+    bposd_handle* h = new bposd_handle();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    h->m = m;
+    h->n = n;
+    h->E = indptr[m];
+    h->rp.assign(indptr, indptr + m + 1);
+    h->ci.assign(indices, indices + h->E);
+    h->probs.assign(channel_probs, channel_probs + n);
+    h->max_iter = cfg->max_iter > 0 ? cfg->max_iter : n;  // A.1: 0 => block length
+
+#define CREATE_TRY(expr)                                                                        \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            fail(nullptr, BPOSD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));        \
+            bposd_destroy(h);                                                                   \
+            return BPOSD_ERR_HIP;                                                               \
+        }                                                                                       \
+    } while (0)
+#define CREATE_RC(expr)                                                                         \
+    do {                                                                                        \
+        int _rc = (expr);                                                                       \
+        if (_rc) {                                                                              \
+            g_create_error = h->err;                                                            \
+            bposd_destroy(h);                                                                   \
+            return _rc;                                                                         \
+        }                                                                                       \
+    } while (0)
+
+    CREATE_TRY(hipSetDevice(h->device));
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
+    h->num_cu = prop.multiProcessorCount;
+    if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto& e : h->ev) CREATE_TRY(hipEventCreate(&e));
+
+    // degrees
+    std::vector<int> vdeg(n, 0);
+    int dc_min = 1 << 30, dv_min = 1 << 30;
+    for (int c = 0; c < m; ++c) {
+        const int d = indptr[c + 1] - indptr[c];
+        h->dc_max = std::max(h->dc_max, d);
+        dc_min = std::min(dc_min, d);
+        for (int e = indptr[c]; e < indptr[c + 1]; ++e) vdeg[indices[e]]++;
+    }
+    for (int i = 0; i < n; ++i) {
+        h->dv_max = std::max(h->dv_max, vdeg[i]);
+        dv_min = std::min(dv_min, vdeg[i]);
+    }
+    h->regular = (dc_min == h->dc_max) && (dv_min == h->dv_max);
+
+    DegPair pair;
+    if (h->regular && h->dc_max == 6 && h->dv_max == 3) pair = {6, 3};
+    else if (!pick_pair(h->dc_max, h->dv_max, &pair)) {
+        fail(nullptr, BPOSD_ERR_UNSUPPORTED, "check degree %d / bit degree %d exceed the built kernels (16 / 8)",
+             h->dc_max, h->dv_max);
+        bposd_destroy(h);
+        return BPOSD_ERR_UNSUPPORTED;
+    }
+    if (bp_lds_bytes(pair.dc, m) > h->lds_per_cu || !pick_shape(h)) {
+        fail(nullptr, BPOSD_ERR_UNSUPPORTED,
+             "code too large for the LDS-resident BP kernel (m=%d n=%d needs %zu B of LDS): large-code path not built yet",
+             m, n, bp_lds_bytes(pair.dc, m));
+        bposd_destroy(h);
+        return BPOSD_ERR_UNSUPPORTED;
+    }
+
+    h->rank = gf2_rank_host(m, n, h->rp, h->ci);
+    h->kprime = n - h->rank;
+    if (cfg->osd_method != BPOSD_OSD_OFF) {
+        if (m > 1024 || osd_words(n) == 0) {
+            fail(nullptr, BPOSD_ERR_UNSUPPORTED,
+                 "code too large for the register-resident OSD kernel (m=%d > 1024 or n=%d > 2047): large-code path not built yet",
+                 m, n);
+            bposd_destroy(h);
+            return BPOSD_ERR_UNSUPPORTED;
+        }
+        if (cfg->osd_method >= BPOSD_OSD_E && cfg->osd_order > h->kprime) {
+            fail(nullptr, BPOSD_ERR_INVALID, "osd_order %d exceeds the number of non-pivot columns n - rank = %d",
+                 cfg->osd_order, h->kprime);
+            bposd_destroy(h);
+            return BPOSD_ERR_INVALID;
+        }
+        if (cfg->osd_method == BPOSD_OSD_E && cfg->osd_order > 20) {
+            fail(nullptr, BPOSD_ERR_UNSUPPORTED, "osd_e order %d > 20 not supported", cfg->osd_order);
+            bposd_destroy(h);
+            return BPOSD_ERR_UNSUPPORTED;
+        }
+        if (cfg->osd_method == BPOSD_OSD_CS && cfg->osd_order > 64) {
+            fail(nullptr, BPOSD_ERR_UNSUPPORTED, "osd_cs order %d > 64 not supported", cfg->osd_order);
+            bposd_destroy(h);
+            return BPOSD_ERR_UNSUPPORTED;
+        }
+    }
+    h->ncand = num_candidates(h);
+
+    auto upi = [&](int** dst, const std::vector<int>& v) -> hipError_t {
+        hipError_t e = hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice);
+    };
+    CREATE_TRY(upi(&h->d_rp, h->rp));
+    CREATE_TRY(upi(&h->d_ci, h->ci));
+    CREATE_TRY(hipMalloc((void**)&h->d_llr0, sizeof(double) * n));
+    CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(int) * 4));
+    CREATE_TRY(hipMalloc((void**)&h->d_iter_total, sizeof(unsigned long long)));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_counters, sizeof(int) * 4));
+    CREATE_TRY(hipHostMalloc((void**)&h->h_iter_total, sizeof(unsigned long long)));
+    CREATE_RC(build_tables(h, pair.dc, pair.dv));
+    CREATE_RC(upload_priors(h));
+    if (h->cfg.osd_method >= BPOSD_OSD_E && h->cfg.osd_order > 0 && h->cfg.weight_fn == 0 && !h->probs_uniform) {
+        fail(nullptr, BPOSD_ERR_UNSUPPORTED,
+             "OSD-W with non-uniform channel_probs needs the fp64 log-weight sweep, which is not built yet "
+             "(use weight_fn=1 / Hamming weight, osd0, or uniform probabilities)");
+        bposd_destroy(h);
+        return BPOSD_ERR_UNSUPPORTED;
+    }
+    *out = h;
+    return BPOSD_OK;
+#undef CREATE_TRY
+#undef CREATE_RC
+}
+
+int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
+    if (!h || !channel_probs) return fail(h, BPOSD_ERR_INVALID, "null argument");
+    for (int i = 0; i < h->n; ++i)
+        if (!(channel_probs[i] >= 0.0 && channel_probs[i] <= 1.0))
+            return fail(h, BPOSD_ERR_INVALID, "channel_probs[%d] = %g is not a probability", i, channel_probs[i]);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<double> keep = h->probs;
+    h->probs.assign(channel_probs, channel_probs + h->n);
+    int rc = upload_priors(h);
+    if (rc) return rc;
+    if (h->cfg.osd_method >= BPOSD_OSD_E && h->cfg.osd_order > 0 && h->cfg.weight_fn == 0 && !h->probs_uniform) {
+        h->probs = keep;
+        (void)upload_priors(h);
+        return fail(h, BPOSD_ERR_UNSUPPORTED,
+                    "OSD-W with non-uniform channel_probs needs the fp64 log-weight sweep, which is not built yet");
+    }
+    return BPOSD_OK;
+}
+
+int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4)
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0, 1, 2 or 4");
+    h->bp_variant = variant;
+    return BPOSD_OK;
+}
+
+int bposd_info(bposd_handle* h, int32_t* rank, int32_t* ncand, int32_t* max_iter, int32_t* nnz) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (rank) *rank = h->rank;
+    if (ncand) *ncand = h->ncand;
+    if (max_iter) *max_iter = h->max_iter;
+    if (nnz) *nnz = h->E;
+    return BPOSD_OK;
+}
+
+int bposd_synchronize(bposd_handle* h) {
+    if (!h) return BPOSD_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return BPOSD_OK;
+}
+
+int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B, uint8_t* d_osdw,
+                              uint8_t* d_osd0, uint8_t* d_bp, uint8_t* d_conv, int32_t* d_iters,
+                              double* d_llr) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
+    if (B == 0) return BPOSD_OK;
+    if (!d_synd || !d_osdw) return fail(h, BPOSD_ERR_INVALID, "syndromes and osdw buffers are required");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF;
+    int rc;
+    if (osd_on) {
+        if ((rc = ensure(h, h->llr_ws, sizeof(double) * (size_t)B * h->n))) return rc;
+        if ((rc = ensure(h, h->osd_list, sizeof(int) * (size_t)B))) return rc;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(int) * 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_iter_total, 0, sizeof(unsigned long long), h->stream));
+
+    BpParams P{};
+    P.m = h->m;
+    P.n = h->n;
+    P.B = B;
+    P.max_iter = h->max_iter;
+    P.ms_scaling = h->cfg.ms_scaling_factor;
+    P.osd_enabled = osd_on ? 1 : 0;
+    P.synd = d_synd;
+    P.llr0 = h->d_llr0;
+    P.chk_deg = h->d_chk_deg;
+    P.var_deg = h->d_var_deg;
+    P.var_pos = h->d_var_pos;
+    P.var_row = h->d_var_row;
+    P.out_bp = d_bp;
+    P.out_osd0 = d_osd0;
+    P.out_osdw = d_osdw;
+    P.out_conv = d_conv;
+    P.out_iters = d_iters;
+    P.out_llr = d_llr;
+    P.llr_ws = (double*)h->llr_ws.p;
+    P.osd_list = (int*)h->osd_list.p;
+    P.counters = h->d_counters;
+    P.iter_total = h->d_iter_total;
+
+    HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    if ((rc = launch_bp(h, P))) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+    h->ran_osd = false;
+    if (osd_on) {
+        OsdParams Q{};
+        Q.m = h->m;
+        Q.n = h->n;
+        Q.rank = h->rank;
+        Q.osd_method = h->cfg.osd_order == 0 ? BPOSD_OSD_0 : h->cfg.osd_method;
+        Q.osd_order = h->cfg.osd_order;
+        Q.tie_policy = h->cfg.sort_tie_policy;
+        int ns = 2;
+        while (ns < h->n) ns <<= 1;
+        Q.nsort = ns;
+        Q.synd = d_synd;
+        Q.rp = h->d_rp;
+        Q.ci = h->d_ci;
+        Q.llr_ws = (const double*)h->llr_ws.p;
+        Q.osd_list = (const int*)h->osd_list.p;
+        Q.counters = h->d_counters;
+        Q.out_osd0 = d_osd0;
+        Q.out_osdw = d_osdw;
+        if ((rc = launch_osd(h, Q, B))) return rc;
+        h->ran_osd = true;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_iter_total, h->d_iter_total, sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, h->stream));
+    h->have_timing = true;
+    return BPOSD_OK;
+}
+
+int bposd_decode_batch(bposd_handle* h, const uint8_t* synd, int64_t B, uint8_t* osdw, uint8_t* osd0,
+                       uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
+    if (B == 0) return BPOSD_OK;
+    if (!synd || !osdw) return fail(h, BPOSD_ERR_INVALID, "syndromes and osdw buffers are required");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bn = (size_t)B * h->n, bm = (size_t)B * h->m;
+    int rc;
+    if ((rc = ensure(h, h->io_synd, bm))) return rc;
+    if ((rc = ensure(h, h->io_osdw, bn))) return rc;
+    if (osd0 && (rc = ensure(h, h->io_osd0, bn))) return rc;
+    if (bp && (rc = ensure(h, h->io_bp, bn))) return rc;
+    if (conv && (rc = ensure(h, h->io_conv, (size_t)B))) return rc;
+    if (iters && (rc = ensure(h, h->io_iters, sizeof(int) * (size_t)B))) return rc;
+    if (llr && (rc = ensure(h, h->io_llr, sizeof(double) * bn))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->io_synd.p, synd, bm, hipMemcpyHostToDevice, h->stream));
+    rc = bposd_decode_batch_device(h, (const uint8_t*)h->io_synd.p, B, (uint8_t*)h->io_osdw.p,
+                                   osd0 ? (uint8_t*)h->io_osd0.p : nullptr, bp ? (uint8_t*)h->io_bp.p : nullptr,
+                                   conv ? (uint8_t*)h->io_conv.p : nullptr, iters ? (int32_t*)h->io_iters.p : nullptr,
+                                   llr ? (double*)h->io_llr.p : nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(osdw, h->io_osdw.p, bn, hipMemcpyDeviceToHost, h->stream));
+    if (osd0) HIP_TRY(h, hipMemcpyAsync(osd0, h->io_osd0.p, bn, hipMemcpyDeviceToHost, h->stream));
+    if (bp) HIP_TRY(h, hipMemcpyAsync(bp, h->io_bp.p, bn, hipMemcpyDeviceToHost, h->stream));
+    if (conv) HIP_TRY(h, hipMemcpyAsync(conv, h->io_conv.p, (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->io_iters.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
+    if (llr) HIP_TRY(h, hipMemcpyAsync(llr, h->io_llr.p, sizeof(double) * bn, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return BPOSD_OK;
+}
+
+int bposd_last_timing(bposd_handle* h, double* bp_ms, double* osd_ms, int64_t* bp_iterations,
+                      int64_t* osd_invocations) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (!h->have_timing) return fail(h, BPOSD_ERR_INVALID, "no decode call has been made on this handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    if (bp_ms) *bp_ms = a;
+    if (osd_ms) *osd_ms = h->ran_osd ? b : 0.0;
+    if (bp_iterations) *bp_iterations = (int64_t)*h->h_iter_total;
+    if (osd_invocations) *osd_invocations = h->h_counters[1];
+    return BPOSD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+"""Host-side mirror of the reference's decoder object, on top of the MI355X C-ABI.
+
+The reference does not implement its decoder: it re-exports ``ldpc.bposd_decoder``
+(/root/reference/src/bposd/__init__.py:1) and its Monte-Carlo harness instantiates
+``ldpc.BpOsdDecoder`` (/root/reference/src/bposd/css_decode_sim.py:6,444-463).  The two
+classes below keep those names, ctor kwargs, methods and result attributes
+(README.md:178-202; css_decode_sim.py:174-258,294-339) so that user code switches by
+changing one import line, while every decode runs in the HIP kernels
+behind ``libbposd_mi355x.so``.  There is no CPU path in this module.
+
+Build-native extension beyond the reference surface: :meth:`BpOsdDecoder.decode_batch`
+(B syndromes per call -- the unit the GPU path is designed around) and
+:meth:`BpOsdDecoder.decode_batch_device` (device pointers, asynchronous).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+__all__ = ["BpOsdDecoder", "bposd_decoder"]
+
+_BP_METHODS = {
+    "product_sum": 0, "prod_sum": 0, "ps": 0, "0": 0,
+    "minimum_sum": 1, "min_sum": 1, "ms": 1, "1": 1,
+}
+_BP_NAMES = {0: "product_sum", 1: "minimum_sum"}
+_OSD_METHODS = {
+    "osd_off": 0, "off": 0,
+    "osd_0": 1, "osd0": 1, "0": 1, "osd_zero": 1,
+    "osd_e": 2, "osde": 2, "e": 2, "exhaustive": 2,
+    "osd_cs": 3, "osdcs": 3, "cs": 3, "combination_sweep": 3,
+}
+_OSD_NAMES = {0: "osd_off", 1: "osd_0", 2: "osd_e", 3: "osd_cs"}
+
+
+def _parse(table, value, what):
+    key = str(value).strip().lower()
+    if key not in table:
+        raise ValueError(f"{what}='{value}' is invalid. Valid options: {sorted(set(table))}")
+    return table[key]
+
+
+class BpOsdDecoder:
+    """MI355X BP+OSD decoder with the call surface of ``ldpc.BpOsdDecoder``.
+
+    Parameters follow the reference call sites (css_decode_sim.py:444-463, README.md:178-187):
+
+    pcm : scipy.sparse matrix or ndarray, shape (m, n)
+    error_rate : float, optional -- bit error probability broadcast to all n bits
+    error_channel / channel_probs : sequence of n floats, optional -- overrides error_rate
+    max_iter : int -- 0 means the block length n
+    bp_method : "product_sum" | "minimum_sum" (aliases "ps", "ms", 0, 1)
+    ms_scaling_factor : float -- 0 selects the variable factor 1 - 2^-iteration
+    osd_method : "osd_0" | "osd_e" | "osd_cs" (aliases "osd0", "exhaustive", "combination_sweep")
+    osd_order : int
+    device : int -- HIP device ordinal (build-native; default 0)
+    """
+
+    def __init__(self, pcm, error_rate=None, error_channel=None, max_iter=0, bp_method="minimum_sum",
+                 ms_scaling_factor=1.0, schedule="parallel", omp_thread_count=1, osd_method="osd_0",
+                 osd_order=0, input_vector_type="syndrome", channel_probs=None, device=0,
+                 sort_tie_policy=0, weight_fn=0, **kwargs):
+        if kwargs:
+            raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
+        if str(schedule).lower() != "parallel":
+            raise ValueError("only the parallel (flooding) BP schedule is implemented on MI355X")
+        ivt = str(input_vector_type).lower()
+        if ivt not in ("syndrome", "auto", "-1", "0"):
+            raise ValueError("input_vector_type must be 'syndrome' (received-vector decoding is not on this path)")
+
+        if sp.issparse(pcm):
+            h = sp.csr_matrix(pcm)
+        else:
+            arr = np.asarray(pcm)
+            if arr.ndim != 2:
+                raise ValueError("The parity check matrix must be a 2-D array or scipy.sparse matrix")
+            h = sp.csr_matrix(arr)
+        h = h.astype(np.int64)
+        h.data %= 2
+        h.eliminate_zeros()
+        h.sum_duplicates()
+        h.sort_indices()
+        self.m, self.n = h.shape
+        if self.m == 0 or self.n == 0:
+            raise ValueError("The parity check matrix is empty")
+        self._indptr = np.ascontiguousarray(h.indptr, dtype=np.int32)
+        self._indices = np.ascontiguousarray(h.indices, dtype=np.int32)
+
+        probs = error_channel if error_channel is not None else channel_probs
+        if probs is not None and len(probs) == 1 and probs[0] is None:  # channel_probs=[None] (README.md:181)
+            probs = None
+        if probs is not None:
+            probs = np.ascontiguousarray(probs, dtype=np.float64)
+            if probs.shape != (self.n,):
+                raise ValueError(f"The error channel vector must have length {self.n}, not {probs.shape}")
+        else:
+            if error_rate is None:
+                raise ValueError("Please specify the error channel: either `error_rate` (float) or "
+                                 "`channel_probs` / `error_channel` (list of floats of length n)")
+            probs = np.full(self.n, float(error_rate), dtype=np.float64)
+        if np.any(~((probs >= 0) & (probs <= 1))):
+            raise ValueError("channel probabilities must lie in [0, 1]")
+        self._probs = probs
+
+        self._bp_method = bp_method if isinstance(bp_method, (int, np.integer)) and bp_method in (0, 1) \
+            else _parse(_BP_METHODS, bp_method, "bp_method")
+        self._osd_method = _parse(_OSD_METHODS, osd_method, "osd_method")
+        max_iter = int(max_iter)
+        osd_order = int(osd_order)
+        if osd_order < 0:  # legacy "-1 = default"
+            osd_order = 0
+        if max_iter < 0:
+            raise ValueError("max_iter must be >= 0")
+        self._ms = float(ms_scaling_factor)
+        self._osd_order = osd_order
+
+        lib = _lib.load()
+        self._lib = lib
+        cfg = _lib.BposdConfig()
+        cfg.device = int(device)
+        cfg.bp_method = int(self._bp_method)
+        cfg.ms_scaling_factor = self._ms
+        cfg.max_iter = max_iter
+        cfg.osd_method = int(self._osd_method)
+        cfg.osd_order = osd_order
+        cfg.sort_tie_policy = int(sort_tie_policy)
+        cfg.weight_fn = int(weight_fn)
+        self._h = C.c_void_p()
+        rc = lib.bposd_create(C.byref(cfg), self._indptr.ctypes.data, self._indices.ctypes.data,
+                              self.m, self.n, self._probs.ctypes.data, C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            _lib.check(lib, None, rc)
+        rank, ncand, mi, nnz = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        lib.bposd_info(self._h, C.byref(rank), C.byref(ncand), C.byref(mi), C.byref(nnz))
+        self.rank, self.num_candidates, self._max_iter, self.nnz = rank.value, ncand.value, mi.value, nnz.value
+
+        zi = np.zeros(self.n, dtype=int)
+        self._osdw, self._osd0, self._bp = zi, zi.copy(), zi.copy()
+        self._converge = False
+        self._iter = 0
+        self._llr = np.zeros(self.n, dtype=np.float64)
+        # batch results of the last decode_batch call
+        self.batch_converge = None
+        self.batch_iter = None
+        self.batch_osd0 = None
+        self.batch_bp = None
+        self.batch_llr = None
+
+    # ------------------------------------------------------------------ lifetime
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self._lib.bposd_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------ decode
+    def decode_batch(self, syndromes, want_osd0=True, want_bp=True, want_llr=False):
+        """Decode B syndromes (array [B, m], any integer dtype).  Returns the OSD-W (or BP, when BP
+        converged) corrections as uint8 [B, n]; per-row ``batch_converge``, ``batch_iter`` and, if
+        requested, ``batch_osd0`` / ``batch_bp`` / ``batch_llr`` are left on the object."""
+        s = np.asarray(syndromes)
+        if s.ndim != 2 or s.shape[1] != self.m:
+            raise ValueError(f"The syndromes must have shape (B, {self.m}). Not {s.shape}.")
+        s8 = np.ascontiguousarray(s.astype(np.int64) & 1, dtype=np.uint8) if s.dtype != np.uint8 \
+            else np.ascontiguousarray(s & 1)
+        B = s8.shape[0]
+        osdw = np.empty((B, self.n), np.uint8)
+        osd0 = np.empty((B, self.n), np.uint8) if want_osd0 else None
+        bp = np.empty((B, self.n), np.uint8) if want_bp else None
+        conv = np.empty(B, np.uint8)
+        iters = np.empty(B, np.int32)
+        llr = np.empty((B, self.n), np.float64) if want_llr else None
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        rc = self._lib.bposd_decode_batch(self._h, s8.ctypes.data, B, ptr(osdw), ptr(osd0), ptr(bp),
+                                          ptr(conv), ptr(iters), ptr(llr))
+        _lib.check(self._lib, self._h, rc)
+        self.batch_converge = conv.astype(bool)
+        self.batch_iter = iters
+        self.batch_osd0, self.batch_bp, self.batch_llr = osd0, bp, llr
+        return osdw
+
+    def decode(self, syndrome):
+        """Decode one syndrome; returns the correction with the syndrome's dtype
+        (README.md:197; css_decode_sim.py:174-202).  Result attributes are updated."""
+        s = np.asarray(syndrome)
+        if s.ndim != 1 or len(s) != self.m:
+            raise ValueError(f"The syndrome must have length {self.m}. Not {len(s) if s.ndim else 0}.")
+        osdw = self.decode_batch(s[None, :], want_osd0=True, want_bp=True, want_llr=True)
+        self._osdw = osdw[0].astype(int)
+        self._osd0 = self.batch_osd0[0].astype(int)
+        self._bp = self.batch_bp[0].astype(int)
+        self._converge = bool(self.batch_converge[0])
+        self._iter = int(self.batch_iter[0])
+        self._llr = self.batch_llr[0].copy()
+        dtype = s.dtype if np.issubdtype(s.dtype, np.number) else int
+        return osdw[0].astype(dtype)
+
+    def decode_batch_device(self, d_syndromes, B, d_osdw, d_osd0=None, d_bp=None, d_converged=None,
+                            d_iters=None, d_llr=None):
+        """Asynchronous decode on device pointers (ints, e.g. ``tensor.data_ptr()``) that live on this
+        decoder's device; call :meth:`synchronize` before reading the outputs."""
+        rc = self._lib.bposd_decode_batch_device(self._h, d_syndromes, int(B), d_osdw, d_osd0, d_bp,
+                                                 d_converged, d_iters, d_llr)
+        _lib.check(self._lib, self._h, rc)
+
+    def synchronize(self):
+        _lib.check(self._lib, self._h, self._lib.bposd_synchronize(self._h))
+
+    def last_timing(self):
+        """dict(bp_ms, osd_ms, bp_iterations, osd_invocations) of the last decode call (HIP events)."""
+        a, b = C.c_double(), C.c_double()
+        it, no = C.c_int64(), C.c_int64()
+        rc = self._lib.bposd_last_timing(self._h, C.byref(a), C.byref(b), C.byref(it), C.byref(no))
+        _lib.check(self._lib, self._h, rc)
+        return {"bp_ms": a.value, "osd_ms": b.value, "bp_iterations": it.value, "osd_invocations": no.value}
+
+    def set_bp_variant(self, variant: int):
+        _lib.check(self._lib, self._h, self._lib.bposd_set_bp_variant(self._h, int(variant)))
+
+    # ------------------------------------------------------------------ mutators / attributes
+    def update_channel_probs(self, channel_probs):
+        """css_decode_sim.py:229,248."""
+        p = np.ascontiguousarray(channel_probs, dtype=np.float64)
+        if p.shape != (self.n,):
+            raise ValueError(f"The error channel vector must have length {self.n}, not {p.shape}")
+        rc = self._lib.bposd_update_channel_probs(self._h, p.ctypes.data)
+        _lib.check(self._lib, self._h, rc)
+        self._probs = p.copy()
+
+    @property
+    def osdw_decoding(self):
+        return self._osdw
+
+    @property
+    def osd0_decoding(self):
+        return self._osd0
+
+    @property
+    def bp_decoding(self):
+        return self._bp
+
+    @property
+    def decoding(self):
+        return self._osdw
+
+    @property
+    def converge(self):
+        return self._converge
+
+    @property
+    def iter(self):
+        return self._iter
+
+    @property
+    def log_prob_ratios(self):
+        return self._llr
+
+    @property
+    def channel_probs(self):
+        return self._probs.copy()
+
+    error_channel = channel_probs
+
+    @property
+    def max_iter(self):
+        return self._max_iter
+
+    @property
+    def bp_method(self):
+        return _BP_NAMES[self._bp_method]
+
+    @property
+    def osd_method(self):
+        return _OSD_NAMES[self._osd_method]
+
+    @property
+    def osd_order(self):
+        return self._osd_order
+
+    @property
+    def ms_scaling_factor(self):
+        return self._ms
+
+    @property
+    def check_count(self):
+        return self.m
+
+    @property
+    def bit_count(self):
+        return self.n
+
+
+class bposd_decoder(BpOsdDecoder):
+    """Legacy-name constructor, kwargs as at /root/reference/README.md:178-187
+    (``from ldpc import bposd_decoder``, re-exported by /root/reference/src/bposd/__init__.py:1)."""
+
+    def __init__(self, parity_check_matrix, error_rate=None, max_iter=0, bp_method=0, ms_scaling_factor=1.0,
+                 channel_probs=[None], input_vector_type=-1, osd_order=-1, osd_method=0, **kwargs):
+        if isinstance(osd_method, (int, np.integer)):
+            osd_method = {0: "osd_0", 1: "osd_e", 2: "osd_cs"}.get(int(osd_method), osd_method)
+        if isinstance(input_vector_type, (int, np.integer)):
+            if int(input_vector_type) not in (-1, 0):
+                raise ValueError("only syndrome input is supported on this path")
+            input_vector_type = "syndrome"
+        super().__init__(parity_check_matrix, error_rate=error_rate, max_iter=max_iter, bp_method=bp_method,
+                         ms_scaling_factor=ms_scaling_factor, channel_probs=channel_probs,
+                         osd_method=osd_method, osd_order=osd_order, input_vector_type=input_vector_type,
+                         **kwargs)

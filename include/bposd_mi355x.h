@@ -1,0 +1,135 @@
+/*
+ * bposd_mi355x.h -- C-ABI of libbposd_mi355x.so, the MI355X (gfx950) BP+OSD decoder.
+ *
+ * This is the drop-in boundary for the reference's decode path.  The reference has
+ * no C/FFI plugin interface of its own: its "operator API" is the Python class
+ * `bposd_decoder` / `BpOsdDecoder` that it imports from the third-party `ldpc`
+ * package (/root/reference/src/bposd/__init__.py:1,
+ * /root/reference/src/bposd/css_decode_sim.py:6).  Each entry point below names the
+ * reference interface it replaces; bp_osd_amd/decoder.py binds them with ctypes and
+ * re-creates that Python class on top (INTEGRATION.md shows the one-line switch).
+ *
+ * Plain C: opaque handle, plain pointers and sizes, no C++ or torch types.
+ * Return value 0 = OK, negative = error (message via bposd_last_error).  The library
+ * never aborts the process.  One handle <-> one device <-> one caller thread at a
+ * time; different handles may be driven from different threads.
+ */
+#ifndef BPOSD_MI355X_H
+#define BPOSD_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bposd_handle bposd_handle;
+
+/* Values of bposd_config fields. */
+enum { BPOSD_BP_PRODUCT_SUM = 0, BPOSD_BP_MIN_SUM = 1 };
+enum { BPOSD_OSD_OFF = 0, BPOSD_OSD_0 = 1, BPOSD_OSD_E = 2, BPOSD_OSD_CS = 3 };
+
+/* Error codes. */
+enum {
+    BPOSD_OK = 0,
+    BPOSD_ERR_INVALID = -1,     /* bad argument / shape / option          -> ValueError   */
+    BPOSD_ERR_UNSUPPORTED = -2, /* valid request this build cannot run    -> ValueError   */
+    BPOSD_ERR_HIP = -3,         /* HIP runtime failure                    -> RuntimeError */
+    BPOSD_ERR_NO_DEVICE = -4    /* no gfx950 device visible               -> RuntimeError */
+};
+
+/*
+ * Constructor options.  Replaces the kwargs of
+ *   bposd_decoder(pcm, error_rate, max_iter, bp_method, ms_scaling_factor,
+ *                 channel_probs, osd_method, osd_order)      /root/reference/README.md:178-187
+ *   BpOsdDecoder(pcm, channel_probs=..., max_iter=..., bp_method=...,
+ *                ms_scaling_factor=..., osd_method=..., osd_order=...)
+ *                                         /root/reference/src/bposd/css_decode_sim.py:444-463
+ */
+typedef struct {
+    int32_t device;            /* HIP device ordinal (>= 0)                                  */
+    int32_t bp_method;         /* BPOSD_BP_*                                                 */
+    double ms_scaling_factor;  /* 0 => variable scaling 1 - 2^-it (README.md:184)            */
+    int32_t max_iter;          /* 0 => block length n                                        */
+    int32_t osd_method;        /* BPOSD_OSD_*                                                */
+    int32_t osd_order;         /* osd_e: patterns on the first w non-pivots; osd_cs: pair span */
+    int32_t sort_tie_policy;   /* 0 = stable ascending index among equal LLRs, 1 = descending */
+    int32_t weight_fn;         /* 0 = sum log(1/p_i) (ldpc v2), 1 = Hamming weight (ldpc v1)  */
+    int32_t reserved[4];       /* must be 0                                                  */
+} bposd_config;
+
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int bposd_device_count(void);
+
+/* Library version string, e.g. "bposd_mi355x 0.1 (gfx950)". */
+const char *bposd_version(void);
+
+/*
+ * Create a decoder.  pcm is CSR (indptr[m+1], indices[E], column indices strictly
+ * ascending within a row); channel_probs[n] are the per-bit error probabilities
+ * (`channel_probs`, or `error_rate` broadcast: README.md:180-181).  The library
+ * copies everything; the caller keeps ownership of its arrays.
+ * Replaces: the ctor call sites README.md:178-187, css_decode_sim.py:444-463.
+ */
+int bposd_create(const bposd_config *cfg, const int32_t *csr_indptr, const int32_t *csr_indices,
+                 int32_t m, int32_t n, const double *channel_probs, bposd_handle **out);
+
+/* Replaces `.update_channel_probs(p)` -- css_decode_sim.py:229,248. */
+int bposd_update_channel_probs(bposd_handle *h, const double *channel_probs);
+
+/*
+ * Decode B syndromes held in HOST memory (row-major uint8[B*m], values 0/1) and write
+ * the results to HOST buffers.  Synchronous.  osdw is required; osd0, bp, converged,
+ * iters, llr may be NULL.
+ *   osdw[B*n]  -> `.osdw_decoding`  (README.md:202; css_decode_sim.py:257-258)
+ *   osd0[B*n]  -> `.osd0_decoding`  (css_decode_sim.py:294-295)
+ *   bp[B*n]    -> `.bp_decoding`    (css_decode_sim.py:338-339)
+ *   converged[B] -> `.converge`     (css_decode_sim.py:331-336)
+ *   iters[B]   -> `.iter`;  llr[B*n] -> `.log_prob_ratios` (final BP LLRs, fp64)
+ * Replaces: `.decode(syndrome)` -- README.md:197; css_decode_sim.py:174-202 (B = 1),
+ * and is the batched form the MI355X path is built around.
+ */
+int bposd_decode_batch(bposd_handle *h, const uint8_t *syndromes, int64_t B, uint8_t *osdw,
+                       uint8_t *osd0, uint8_t *bp, uint8_t *converged, int32_t *iters, double *llr);
+
+/*
+ * Same, but every pointer is a DEVICE pointer on the handle's device (inputs already
+ * resident in HBM).  Asynchronous on the handle's stream: call bposd_synchronize()
+ * before reading the outputs.
+ */
+int bposd_decode_batch_device(bposd_handle *h, const uint8_t *d_syndromes, int64_t B,
+                              uint8_t *d_osdw, uint8_t *d_osd0, uint8_t *d_bp,
+                              uint8_t *d_converged, int32_t *d_iters, double *d_llr);
+
+/* Wait for all work queued on the handle's stream. */
+int bposd_synchronize(bposd_handle *h);
+
+/*
+ * Timing and work counters of the LAST decode call, measured with HIP events on the
+ * stream the kernels were launched on (waits for that call to finish):
+ *   bp_ms, osd_ms    kernel durations
+ *   bp_iterations    sum over syndromes of BP iterations executed
+ *   osd_invocations  syndromes that went through OSD (BP did not converge)
+ * Any pointer may be NULL.
+ */
+int bposd_last_timing(bposd_handle *h, double *bp_ms, double *osd_ms, int64_t *bp_iterations,
+                      int64_t *osd_invocations);
+
+/* Decoder facts: rank of the pcm over GF(2), number of OSD-W candidates per decode,
+ * effective max_iter, nonzeros E.  Any pointer may be NULL. */
+int bposd_info(bposd_handle *h, int32_t *rank, int32_t *num_candidates, int32_t *max_iter,
+               int32_t *nnz);
+
+/* Tuning knob (not part of the reference surface): BP workgroup shape variant
+ * 0 = auto, 1 = 1 check/thread, 2 = 2 checks/thread, 4 = 4 checks/thread. */
+int bposd_set_bp_variant(bposd_handle *h, int32_t variant);
+
+/* Message for the last error on this handle (h == NULL: last create() failure). */
+const char *bposd_last_error(bposd_handle *h);
+
+void bposd_destroy(bposd_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPOSD_MI355X_H */

@@ -1,0 +1,67 @@
+/*
+ * oracle/bposd_oracle.h -- CPU restatement of the reference's BP+OSD decode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under bp_osd_amd/ may include, link or call
+ * this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY STATUS: "parity unpinned" in the strict sense of the build contract.
+ * The reference repository (/root/reference) contains no decoder arithmetic: the
+ * path `bposd_decoder(...).decode(syndrome)` is implemented by the un-vendored,
+ * un-pinned third-party dependency `ldpc>=2.0.0` (/root/reference/setup.py:30,
+ * imported at /root/reference/src/bposd/__init__.py:1 and
+ * /root/reference/src/bposd/css_decode_sim.py:6).  That package is absent from this
+ * pipeline, and the reference's own tests never call decode().  This file restates
+ * the published algorithm of ldpc v2 (BpDecoder parallel schedule, OsdDecoder,
+ * soft_decision_col_sort, RowReduce) as described in SURVEY.md Appendix A, and is
+ * pinned by the only reference-authored datum for the path -- the worked example
+ * at /root/reference/README.md:178-216 -- plus mathematical invariants
+ * (tests/test_oracle.py).
+ */
+#ifndef BPOSD_ORACLE_H
+#define BPOSD_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_decoder oracle_decoder;
+
+/* bp_method: 0 product-sum, 1 min-sum.  osd_method: 0 off, 1 osd0, 2 osd_e, 3 osd_cs.
+ * sort_tie_policy: 0 stable (ties keep ascending bit index), 1 ties descending index.
+ * weight_fn: 0 sum log(1/p_i) in index order (ldpc v2), 1 Hamming weight (ldpc v1). */
+typedef struct {
+    int32_t bp_method;
+    double ms_scaling_factor; /* 0 => 1 - 2^-it */
+    int32_t max_iter;         /* 0 => n */
+    int32_t osd_method;
+    int32_t osd_order;
+    int32_t sort_tie_policy;
+    int32_t weight_fn;
+} oracle_config;
+
+/* pcm as CSR with sorted column indices; channel_probs[n]. Returns 0 or <0. */
+int oracle_create(const oracle_config *cfg, const int32_t *indptr, const int32_t *indices,
+                  int32_t m, int32_t n, const double *channel_probs, oracle_decoder **out);
+void oracle_destroy(oracle_decoder *d);
+int oracle_update_channel_probs(oracle_decoder *d, const double *channel_probs);
+int oracle_rank(const oracle_decoder *d);
+int oracle_num_candidates(const oracle_decoder *d);
+
+/* One syndrome (uint8[m], 0/1).  Outputs uint8[n] each (nullable), double llr[n] (nullable). */
+int oracle_decode(oracle_decoder *d, const uint8_t *syndrome, uint8_t *osdw, uint8_t *osd0,
+                  uint8_t *bp, uint8_t *converged, int32_t *iters, double *llr);
+
+/* B syndromes row-major; serial loop over oracle_decode. */
+int oracle_decode_batch(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,
+                        uint8_t *osd0, uint8_t *bp, uint8_t *converged, int32_t *iters,
+                        double *llr);
+
+/* OSD alone on caller-supplied LLRs (used to pin OSD semantics independently of BP). */
+int oracle_osd(oracle_decoder *d, const uint8_t *syndrome, const double *llr, uint8_t *osdw,
+               uint8_t *osd0, int32_t *order_out /* n, nullable */,
+               int32_t *pivot_flag_out /* n by sorted position, nullable */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

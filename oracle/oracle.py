@@ -1,0 +1,138 @@
+"""ctypes binding of oracle/_build/libbposd_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+The C restatement follows SURVEY.md Appendix A; option names mirror the reference's
+ctor kwargs (/root/reference/README.md:178-187,
+/root/reference/src/bposd/css_decode_sim.py:444-463).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libbposd_oracle.so")
+_lib = None
+
+
+class _Cfg(C.Structure):
+    _fields_ = [
+        ("bp_method", C.c_int32),
+        ("ms_scaling_factor", C.c_double),
+        ("max_iter", C.c_int32),
+        ("osd_method", C.c_int32),
+        ("osd_order", C.c_int32),
+        ("sort_tie_policy", C.c_int32),
+        ("weight_fn", C.c_int32),
+    ]
+
+
+def build_oracle(force: bool = False) -> str:
+    src = os.path.join(_HERE, "bposd_oracle.c")
+    stale = (not os.path.exists(_SO)) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        _lib = C.CDLL(_SO)
+        vp = C.c_void_p
+        _lib.oracle_create.argtypes = [C.POINTER(_Cfg), vp, vp, C.c_int32, C.c_int32, vp, C.POINTER(vp)]
+        _lib.oracle_create.restype = C.c_int
+        _lib.oracle_destroy.argtypes = [vp]
+        _lib.oracle_update_channel_probs.argtypes = [vp, vp]
+        _lib.oracle_rank.argtypes = [vp]
+        _lib.oracle_num_candidates.argtypes = [vp]
+        _lib.oracle_decode_batch.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+        _lib.oracle_decode_batch.restype = C.c_int
+        _lib.oracle_osd.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        _lib.oracle_osd.restype = C.c_int
+    return _lib
+
+
+_BP = {"product_sum": 0, "prod_sum": 0, "ps": 0, "0": 0, "minimum_sum": 1, "min_sum": 1, "ms": 1, "1": 1}
+_OSD = {"osd_off": 0, "off": 0, "osd_0": 1, "osd0": 1, "0": 1, "osd_e": 2, "e": 2, "exhaustive": 2,
+        "osd_cs": 3, "cs": 3, "combination_sweep": 3}
+
+
+class OracleDecoder:
+    def __init__(self, pcm, error_rate=None, channel_probs=None, max_iter=0, bp_method="ms",
+                 ms_scaling_factor=1.0, osd_method="osd0", osd_order=0, sort_tie_policy=0, weight_fn=0):
+        lib = _load()
+        h = sp.csr_matrix(pcm).astype(np.uint8)
+        h.eliminate_zeros()
+        h.sort_indices()
+        self.m, self.n = h.shape
+        if channel_probs is None or (len(channel_probs) == 1 and channel_probs[0] is None):
+            probs = np.full(self.n, float(error_rate), dtype=np.float64)
+        else:
+            probs = np.ascontiguousarray(channel_probs, dtype=np.float64)
+        self._indptr = np.ascontiguousarray(h.indptr, dtype=np.int32)
+        self._indices = np.ascontiguousarray(h.indices, dtype=np.int32)
+        cfg = _Cfg(_BP[str(bp_method).lower()], float(ms_scaling_factor), int(max_iter),
+                   _OSD[str(osd_method).lower()], int(osd_order), int(sort_tie_policy), int(weight_fn))
+        self._h = C.c_void_p()
+        rc = lib.oracle_create(C.byref(cfg), self._indptr.ctypes.data, self._indices.ctypes.data,
+                               self.m, self.n, probs.ctypes.data, C.byref(self._h))
+        if rc != 0:
+            raise ValueError(f"oracle_create failed ({rc})")
+        self.rank = lib.oracle_rank(self._h)
+        self.num_candidates = lib.oracle_num_candidates(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _load().oracle_destroy(self._h)
+            self._h = None
+
+    def update_channel_probs(self, probs):
+        probs = np.ascontiguousarray(probs, dtype=np.float64)
+        assert probs.shape == (self.n,)
+        _load().oracle_update_channel_probs(self._h, probs.ctypes.data)
+
+    def decode_batch(self, syndromes, want_llr=True):
+        s = np.ascontiguousarray(np.asarray(syndromes) & 1, dtype=np.uint8)
+        if s.ndim == 1:
+            s = s[None, :]
+        B = s.shape[0]
+        assert s.shape[1] == self.m
+        out = {
+            "osdw": np.zeros((B, self.n), np.uint8),
+            "osd0": np.zeros((B, self.n), np.uint8),
+            "bp": np.zeros((B, self.n), np.uint8),
+            "converged": np.zeros(B, np.uint8),
+            "iters": np.zeros(B, np.int32),
+            "llr": np.zeros((B, self.n), np.float64) if want_llr else None,
+        }
+        rc = _load().oracle_decode_batch(
+            self._h, s.ctypes.data, B, out["osdw"].ctypes.data, out["osd0"].ctypes.data,
+            out["bp"].ctypes.data, out["converged"].ctypes.data, out["iters"].ctypes.data,
+            out["llr"].ctypes.data if want_llr else None)
+        if rc != 0:
+            raise RuntimeError(f"oracle_decode_batch failed ({rc})")
+        return out
+
+    def decode(self, syndrome):
+        r = self.decode_batch(syndrome)
+        return {k: (v[0] if v is not None else None) for k, v in r.items()}
+
+    def osd(self, syndrome, llr):
+        s = np.ascontiguousarray(np.asarray(syndrome) & 1, dtype=np.uint8)
+        l = np.ascontiguousarray(llr, dtype=np.float64)
+        osdw = np.zeros(self.n, np.uint8)
+        osd0 = np.zeros(self.n, np.uint8)
+        order = np.zeros(self.n, np.int32)
+        piv = np.zeros(self.n, np.int32)
+        rc = _load().oracle_osd(self._h, s.ctypes.data, l.ctypes.data, osdw.ctypes.data, osd0.ctypes.data,
+                                order.ctypes.data, piv.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"oracle_osd failed ({rc})")
+        return {"osdw": osdw, "osd0": osd0, "order": order, "pivot_flag": piv}

@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def surface13():
+    from bp_osd_amd.codes import surface13 as f
+
+    return f()
+
+
+@pytest.fixture(scope="session")
+def h1922():
+    from bp_osd_amd.codes import h1922 as f
+
+    return f()
+
+
+@pytest.fixture(scope="session")
+def hgp400():
+    import numpy as np
+    from bp_osd_amd.codes import hgp
+
+    seed = np.loadtxt(os.path.join(ROOT, "tests", "golden", "mkmn_16_4_6.txt")).astype(np.uint8)
+    return hgp(seed)
