@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the BP+OSD decode hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W      (N > 1, one rank per GPU)
+
+A "step" is one pass of the hot path (BP kernel, then OSD kernel on the non-converged syndromes)
+over one batch of synthetic syndromes that is already resident in HBM, followed -- for N > 1 -- by
+the one exchange step the path has: the gather of the corrections to rank 0 over RCCL.  Syndromes
+are independent, so the batch is sharded across ranks with no other collective (weak scaling:
+per-GPU batch fixed at 131072 = 2^20 / 8, i.e. BASELINE.json configs[3] at N = 8).
+
+Workload (BASELINE.json metric / north_star): [[1922,50]] hypergraph-product code, min-sum BP with
+the variable scaling factor, max_iter = n = 1922, osd_cs order 7, iid bit-flip noise p = 0.05.
+Other BASELINE configs are selectable with --config (parity-test cases, not the bench line).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (bp_method, ms_scaling_factor, max_iter, osd_method, osd_order, per-GPU batch)
+    "h1922_ms_cs7": ("ms", 0.0, 0, "osd_cs", 7, 131072),    # configs[3]: the metric's configuration
+    "h1922_ms_osd0": ("ms", 0.0, 0, "osd0", 0, 65536),      # configs[1]
+    "h1922_ps_cs60": ("ps", 0.0, 0, "osd_cs", 60, 65536),   # configs[2]
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def make_batch(H, q, B, seed, chunk=16384):
+    """iid bit-flip errors e = rng.random((B, n)) < q (numpy PCG64), syndromes s = H e mod 2."""
+    rng = np.random.default_rng(seed)
+    m, n = H.shape
+    Hc = H.tocsr().astype(np.int32)
+    syn = np.empty((B, m), dtype=np.uint8)
+    err = np.empty((B, n), dtype=np.uint8)
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        e = rng.random((hi - lo, n)) < q
+        err[lo:hi] = e
+        syn[lo:hi] = (np.asarray(Hc @ e.T.astype(np.int32)) % 2).T
+    return err, syn
+
+
+def cpu_baseline_worker(args):
+    """Decode a slice with the CPU oracle (separate process, never touches the GPU)."""
+    hz_indptr, hz_indices, shape, kw, syn = args
+    import scipy.sparse as sp
+    from oracle import OracleDecoder
+
+    H = sp.csr_matrix((np.ones(len(hz_indices), dtype=np.uint8), hz_indices, hz_indptr), shape=shape)
+    dec = OracleDecoder(H, **kw)
+    t0 = time.perf_counter()
+    r = dec.decode_batch(syn, want_llr=False)
+    dt = time.perf_counter() - t0
+    return dt, r["osdw"], r["converged"], r["iters"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="h1922_ms_cs7", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--p", type=float, default=0.05, help="bit-flip probability q")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="syndromes timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--variant", type=int, default=0, help="BP workgroup shape (0 auto, 1, 2, 4)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gather")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    bp_method, ms, max_iter, osd_method, osd_order, B = CONFIGS[args.config]
+    if args.batch:
+        B = args.batch
+    q = args.p
+
+    from bp_osd_amd.codes import h1922
+
+    code = h1922(compute_logicals=(rank == 0))
+    H = code.hz
+    m, n = H.shape
+    E = H.nnz
+    kw = dict(error_rate=q, max_iter=max_iter, bp_method=bp_method, ms_scaling_factor=ms,
+              osd_method=osd_method, osd_order=osd_order)
+
+    nbatch = max(1, min(args.steps, 2))
+    batches = [make_batch(H, q, B, seed=1000 * rank + k) for k in range(nbatch)]
+
+    # ---- CPU baseline leg (rank 0, N = 1 only), before the GPU is initialised in this process.
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        ns = min(args.cpu_sample, B)
+        sample = np.ascontiguousarray(batches[0][1][:ns])
+        dt, c_osdw, c_conv, c_it = cpu_baseline_worker((H.indptr, H.indices, H.shape, kw, sample))
+        cpu = dict(n=ns, dt=dt, osdw=c_osdw, conv=c_conv, iters=c_it)
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from bp_osd_amd import BpOsdDecoder
+
+    dec = BpOsdDecoder(H, device=local_rank, **kw)
+    if args.variant:
+        dec.set_bp_variant(args.variant)
+
+    dev = torch.device("cuda", local_rank)
+    d_syn = [torch.from_numpy(b[1]).to(dev) for b in batches]
+    d_osdw = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    d_conv = torch.empty(B, dtype=torch.uint8, device=dev)
+    d_iters = torch.empty(B, dtype=torch.int32, device=dev)
+    gather_list = None
+    if world > 1 and not args.no_gather and rank == 0:
+        gather_list = [torch.empty((B, n), dtype=torch.uint8, device=dev) for _ in range(world)]
+
+    def step(k):
+        dec.decode_batch_device(d_syn[k % nbatch].data_ptr(), B, d_osdw.data_ptr(), None, None,
+                                d_conv.data_ptr(), d_iters.data_ptr(), None)
+        dec.synchronize()  # the library runs on its own stream
+        if world > 1 and not args.no_gather:
+            dist.gather(d_osdw, gather_list, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    bp_ms, osd_ms, iters_tot, osd_tot = [], [], 0, 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+        t = dec.last_timing()  # HIP events on the library's stream (already synchronised)
+        bp_ms.append(t["bp_ms"])
+        osd_ms.append(t["osd_ms"])
+        iters_tot += t["bp_iterations"]
+        osd_tot += t["osd_invocations"]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- one more decode of batch 0 for verification / LER (outside the timed region)
+    dec.decode_batch_device(d_syn[0].data_ptr(), B, d_osdw.data_ptr(), None, None, d_conv.data_ptr(),
+                            d_iters.data_ptr(), None)
+    dec.synchronize()
+    t_last = dec.last_timing()
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        value = world * B * steps / elapsed
+        # algorithmic bytes of the dominant kernel (BP): SURVEY.md §8(d)
+        bytes_per_iter = (4 * E + 2 * n) * 8
+        avg_bp_ms = float(np.mean(bp_ms)) if bp_ms else float("nan")
+        avg_iters = iters_tot / steps
+        algo_bytes = avg_iters * bytes_per_iter + B * (m + n)
+        achieved = algo_bytes / (avg_bp_ms * 1e-3) / 1e9 if avg_bp_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+
+        # LER of this rank's shard (osdw), definitions of css_decode_sim.py:257-280 for one sector
+        err0 = torch.from_numpy(batches[0][0]).to(dev)
+        lz = torch.from_numpy(code.lz.astype(np.float32)).to(dev)
+        fails = 0
+        for lo in range(0, B, 16384):
+            resid = (d_osdw[lo:lo + 16384] ^ err0[lo:lo + 16384]).to(torch.float32)
+            fails += int((((resid @ lz.T) % 2).sum(dim=1) > 0).sum().item())
+        ler = fails / B
+        conv_frac = float(d_conv.to(torch.float32).mean().item())
+        it_cpu = d_iters.cpu().numpy()
+
+        out = {
+            "metric": "syndromes decoded/sec (whole node) + logical error rate, HGP [[1922,50]] p=0.05",
+            "value": value,
+            "unit": "syndromes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: [[1922,50]] HGP (31x31 circulant 1+x^2+x^5) hz 961x1922, "
+                            f"{'min-sum' if bp_method == 'ms' else 'product-sum'} BP"
+                            f"{' variable scaling' if bp_method == 'ms' and ms == 0 else ''}, max_iter=1922, "
+                            f"{osd_method} order {osd_order}, iid bit-flip q={q}",
+                "per_gpu_batch": B,
+                "global_batch": B * world,
+                "sharding": f"independent syndromes, contiguous shards x{world}" +
+                            ("" if world == 1 or args.no_gather else ", RCCL gather of corrections to rank 0"),
+                "bp_variant": args.variant,
+            },
+            "logical_error_rate": ler,
+            "logical_error_rate_eb": float(np.sqrt(ler * (1 - ler) / B)),
+            "bp_converged_fraction": conv_frac,
+            "bp_iterations_mean": float(it_cpu.mean()),
+            "bp_iterations_p50_p99_max": [float(np.percentile(it_cpu, 50)), float(np.percentile(it_cpu, 99)),
+                                          int(it_cpu.max())],
+            "osd_invocations_per_step": osd_tot / steps,
+            "kernel_ms": {"bp": avg_bp_ms, "osd": float(np.mean(osd_ms)) if osd_ms else 0.0},
+            "kernel_only_syndromes_per_s_per_gpu": B / ((avg_bp_ms + float(np.mean(osd_ms))) * 1e-3),
+            "roofline": {
+                "kernel": "bp_kernel (BP message passing, LDS-resident)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "bytes_per_iteration_per_syndrome": bytes_per_iter,
+                "avg_launch_ms": avg_bp_ms,
+                "note": "algorithmic fp64 message bytes (4E+2n)*8 per executed iteration; messages stay in "
+                        "LDS, so the fraction can exceed 1 and measured HBM traffic is far lower",
+            },
+        }
+        if cpu is not None:
+            got = d_osdw[:cpu["n"]].cpu().numpy()
+            same = bool((got == cpu["osdw"]).all() and (it_cpu[:cpu["n"]] == cpu["iters"]).all())
+            out["cpu_baseline"] = {
+                "value": cpu["n"] / cpu["dt"],
+                "unit": "syndromes/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": f"first {cpu['n']} syndromes of batch 0, decoded one at a time by oracle/bposd_oracle.c "
+                          f"(single thread, {cpu['dt']:.1f} s); the reference's ldpc/Cython path is not installable here",
+                "host_cores_available": len(os.sched_getaffinity(0)),
+                "gpu_matches_cpu_bit_for_bit": same,
+            }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

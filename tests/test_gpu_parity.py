@@ -1,0 +1,342 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against
+the CPU oracle on the same seeded inputs, against the committed golden vectors, and -- at the
+benchmark's full batch size -- through size-independent properties.
+
+Bars: bit-exact on every integer output (osdw, osd0, bp, converge, iter) for min-sum AND bit-exact on
+the fp64 LLRs (the OSD column order depends on every bit of them).  Product-sum uses device tanh/log,
+which differ from glibc at the ulp level: LLRs to 1e-9 relative, integer outputs equal wherever BP
+converged on both sides, mismatches elsewhere counted and bounded.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_ready():
+    from bp_osd_amd import _lib
+
+    lib = _lib.load()  # raises loudly if the HIP extension is missing
+    assert lib.bposd_device_count() > 0, "no MI355X visible"
+    return lib
+
+
+def _syndromes(H, q, B, seed):
+    rng = np.random.default_rng(seed)
+    err = (rng.random((B, H.shape[1])) < q).astype(np.uint8)
+    syn = np.asarray((H @ err.T) % 2).T.astype(np.uint8)
+    return err, np.ascontiguousarray(syn)
+
+
+def _syndrome_of(H, X, chunk=8192):
+    """(H @ X^T mod 2)^T for X uint8 [B, n], chunked to bound host memory."""
+    Hc = H.tocsr().astype(np.int32) if hasattr(H, "tocsr") else None
+    out = np.empty((X.shape[0], H.shape[0]), dtype=np.uint8)
+    for lo in range(0, X.shape[0], chunk):
+        x = X[lo:lo + chunk].T.astype(np.int32)
+        y = (Hc @ x) if Hc is not None else (np.asarray(H, dtype=np.int32) @ x)
+        out[lo:lo + chunk] = (np.asarray(y) % 2).T
+    return out
+
+
+def _compare_exact(gpu, ref, llr_rows=None):
+    got = gpu["osdw"]
+    assert (gpu["converged"] == ref["converged"].astype(bool)).all(), "converge flags differ"
+    assert (gpu["iters"] == ref["iters"]).all(), "iteration counts differ"
+    assert (gpu["bp"] == ref["bp"]).all(), "bp_decoding differs"
+    assert (gpu["osd0"] == ref["osd0"]).all(), "osd0_decoding differs"
+    assert (got == ref["osdw"]).all(), "osdw_decoding differs"
+    if gpu.get("llr") is not None and ref.get("llr") is not None:
+        a, b = gpu["llr"], ref["llr"]
+        if llr_rows is not None:
+            a, b = a[:llr_rows], b[:llr_rows]
+        assert (np.ascontiguousarray(a).view(np.uint64) == np.ascontiguousarray(b).view(np.uint64)).all(), "LLR bits differ"
+
+
+def _gpu_decode(dec, syn, want_llr=True):
+    osdw = dec.decode_batch(syn, want_osd0=True, want_bp=True, want_llr=want_llr)
+    return dict(osdw=osdw, osd0=dec.batch_osd0, bp=dec.batch_bp, converged=dec.batch_converge,
+                iters=dec.batch_iter, llr=dec.batch_llr)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_readme_known_answer(gpu_ready, surface13):
+    """README.md:178-216 through the legacy-name class."""
+    from bp_osd_amd import bposd_decoder
+
+    bpd = bposd_decoder(surface13.hz, error_rate=0.05, channel_probs=[None], max_iter=surface13.N,
+                        bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=7)
+    error = np.zeros(surface13.N).astype(int)
+    error[[5, 12]] = 1
+    syndrome = surface13.hz @ error % 2
+    out = bpd.decode(syndrome)
+    expect = np.zeros(13, dtype=int)
+    expect[8] = 1
+    assert (bpd.osdw_decoding == expect).all() and (out == expect).all()
+    assert out.dtype == syndrome.dtype
+    residual = (bpd.osdw_decoding + error) % 2
+    assert not (surface13.lz @ residual % 2).any()
+    assert bpd.converge is True and bpd.iter == 2
+    assert (bpd.osd0_decoding == expect).all() and (bpd.bp_decoding == expect).all()
+
+
+@pytest.mark.parametrize("name", __import__("tests.golden_util", fromlist=["x"]).golden_files())
+def test_gpu_matches_golden(gpu_ready, name):
+    from bp_osd_amd import BpOsdDecoder
+    from tests.golden_util import load
+
+    g = load(name)
+    dec = BpOsdDecoder(g["H"], **g["cfg"])
+    r = _gpu_decode(dec, g["syn"])
+    tol_ps = g["cfg"]["bp_method"] == "ps"
+    if tol_ps:
+        k = len(g["llr"])
+        assert np.allclose(np.clip(r["llr"][:k], -30, 30), np.clip(g["llr"], -30, 30), rtol=1e-9, atol=1e-9)
+        both = r["converged"] & g["converged"].astype(bool)
+        assert (r["osdw"][both] == g["osdw"][both]).all()
+        assert (r["osdw"] != g["osdw"]).any(axis=1).mean() <= 0.05
+    else:
+        _compare_exact(r, g, llr_rows=len(g["llr"]))
+
+
+@pytest.mark.parametrize("ms", [0.0, 0.625, 1.0])
+@pytest.mark.parametrize("osd", [("osd0", 0), ("osd_e", 7), ("osd_cs", 7), ("osd_cs", 4)])
+def test_s13_exhaustive_vs_oracle(gpu_ready, surface13, ms, osd):
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    syn = np.array(list(itertools.product([0, 1], repeat=6)), dtype=np.uint8)
+    for max_iter in (1, 3, 13):
+        kw = dict(error_rate=0.05, max_iter=max_iter, bp_method="ms", ms_scaling_factor=ms,
+                  osd_method=osd[0], osd_order=osd[1])
+        r = _gpu_decode(BpOsdDecoder(surface13.hz, **kw), syn)
+        ref = OracleDecoder(surface13.hz, **kw).decode_batch(syn)
+        _compare_exact(r, ref)
+
+
+def test_hamming_and_rep_codes_vs_oracle(gpu_ready):
+    """Tiny irregular codes: degree-1 checks/bits, m < 64, full coverage of syndromes."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hamming_code, rep_code
+    from oracle import OracleDecoder
+
+    for H in (hamming_code(3), rep_code(5), np.array([[1, 0, 0, 1], [0, 1, 0, 0]], dtype=np.uint8)):
+        m, n = H.shape
+        syn = np.array(list(itertools.product([0, 1], repeat=m)), dtype=np.uint8)
+        from bp_osd_amd.codes import gf2_rank
+
+        kp = n - gf2_rank(H)
+        for osd in (("osd0", 0), ("osd_cs", min(2, kp)), ("osd_e", min(2, kp))):
+            kw = dict(error_rate=0.1, max_iter=2, bp_method="ms", ms_scaling_factor=0.75,
+                      osd_method=osd[0], osd_order=osd[1])
+            r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
+            ref = OracleDecoder(H, **kw).decode_batch(syn)
+            _compare_exact(r, ref)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(q=0.07, max_iter=8, ms=0.0, osd=("osd_cs", 10)),
+    dict(q=0.05, max_iter=0, ms=0.625, osd=("osd_cs", 42)),  # examples/qldpc_decode_example.py settings
+    dict(q=0.09, max_iter=5, ms=1.0, osd=("osd_e", 9)),
+    dict(q=0.09, max_iter=5, ms=0.0, osd=("osd0", 0)),
+])
+def test_hgp400_vs_oracle(gpu_ready, hgp400, cfg):
+    """Irregular degrees (check weight 7, bit weights 3/4) -> predicated generic kernels."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    for H, seed in ((hgp400.hx, 1), (hgp400.hz, 2)):
+        _, syn = _syndromes(H, cfg["q"], 192, seed)
+        kw = dict(error_rate=cfg["q"], max_iter=cfg["max_iter"], bp_method="ms", ms_scaling_factor=cfg["ms"],
+                  osd_method=cfg["osd"][0], osd_order=cfg["osd"][1])
+        r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
+        ref = OracleDecoder(H, **kw).decode_batch(syn)
+        _compare_exact(r, ref)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4])
+def test_h1922_p05_vs_oracle_all_shapes(gpu_ready, h1922, variant):
+    """Benchmark settings (min-sum, variable scaling, max_iter = n, osd_cs 7, p = 0.05), 2048 shots,
+    every workgroup shape of the BP kernel; LLR doubles compared for every shot."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    q = 0.05
+    _, syn = _syndromes(h1922.hz, q, 2048, 5)
+    kw = dict(error_rate=q, max_iter=0, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=7)
+    dec = BpOsdDecoder(h1922.hz, **kw)
+    dec.set_bp_variant(variant)
+    r = _gpu_decode(dec, syn)
+    ref = OracleDecoder(h1922.hz, **kw).decode_batch(syn)
+    _compare_exact(r, ref)
+    t = dec.last_timing()
+    assert t["bp_iterations"] == int(ref["iters"].sum())
+    assert t["osd_invocations"] == int((ref["converged"] == 0).sum())
+
+
+@pytest.mark.parametrize("osd", [("osd0", 0), ("osd_cs", 7), ("osd_cs", 60), ("osd_e", 12), ("osd_cs", 64)])
+def test_h1922_osd_heavy_vs_oracle(gpu_ready, h1922, osd):
+    """Elevated noise + short BP: (almost) every shot goes through the GF(2) elimination kernel."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    q = 0.075
+    _, syn = _syndromes(h1922.hx, q, 160, 17)
+    kw = dict(error_rate=q, max_iter=25, bp_method="ms", ms_scaling_factor=0, osd_method=osd[0], osd_order=osd[1])
+    r = _gpu_decode(BpOsdDecoder(h1922.hx, **kw), syn)
+    ref = OracleDecoder(h1922.hx, **kw).decode_batch(syn)
+    assert (~r["converged"]).sum() >= 100
+    _compare_exact(r, ref)
+
+
+def test_sort_tie_policy_switch(gpu_ready, h1922):
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    q = 0.08
+    _, syn = _syndromes(h1922.hz, q, 48, 23)
+    for pol in (0, 1):
+        kw = dict(error_rate=q, max_iter=3, bp_method="ms", ms_scaling_factor=1.0, osd_method="osd_cs",
+                  osd_order=5, sort_tie_policy=pol)
+        r = _gpu_decode(BpOsdDecoder(h1922.hz, **kw), syn)
+        ref = OracleDecoder(h1922.hz, **kw).decode_batch(syn)
+        _compare_exact(r, ref)
+
+
+def test_nonuniform_channel_and_update(gpu_ready, hgp400):
+    """a1/a12: per-bit channel_probs and update_channel_probs (BP priors; OSD-0; Hamming-weight OSD-W)."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = hgp400.hx
+    rng = np.random.default_rng(9)
+    p1 = rng.uniform(0.02, 0.15, size=400)
+    p2 = rng.uniform(0.02, 0.15, size=400)
+    _, syn = _syndromes(H, 0.08, 128, 4)
+    for osd, wf in ((("osd0", 0), 0), (("osd_cs", 8), 1)):
+        kw = dict(channel_probs=p1, max_iter=6, bp_method="ms", ms_scaling_factor=0.9, osd_method=osd[0],
+                  osd_order=osd[1], weight_fn=wf)
+        g, c = BpOsdDecoder(H, **kw), OracleDecoder(H, **kw)
+        _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
+        g.update_channel_probs(p2)
+        c.update_channel_probs(p2)
+        assert np.allclose(g.channel_probs, p2)
+        _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
+    with pytest.raises(ValueError, match="non-uniform"):
+        BpOsdDecoder(H, channel_probs=p1, osd_method="osd_cs", osd_order=4)
+
+
+def test_product_sum_vs_oracle(gpu_ready, h1922):
+    """a5: device tanh/log differ from glibc by ulps -> tolerance parity, stated here:
+    LLRs within 1e-9 (relative/absolute) on shots that converge in the same iteration on both
+    sides, after clipping to +-30 (a message saturates to +-inf exactly when tanh rounds to 1, which
+    is itself an ulp-level event: log((1+x)/(1-x)) jumps from 37.4 to inf); integer outputs identical
+    on those shots; the rest counted and bounded at 2%."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    q = 0.05
+    _, syn = _syndromes(h1922.hz, q, 512, 31)
+    kw = dict(error_rate=q, max_iter=60, bp_method="ps", osd_method="osd_cs", osd_order=10)
+    r = _gpu_decode(BpOsdDecoder(h1922.hz, **kw), syn)
+    ref = OracleDecoder(h1922.hz, **kw).decode_batch(syn)
+    same = (r["iters"] == ref["iters"]) & (r["converged"] == ref["converged"].astype(bool))
+    assert same.mean() >= 0.98
+    conv = same & r["converged"]
+    assert (r["osdw"][conv] == ref["osdw"][conv]).all()
+    assert np.allclose(np.clip(r["llr"][conv], -30, 30), np.clip(ref["llr"][conv], -30, 30), rtol=1e-9, atol=1e-9)
+    Hd = h1922.hz.toarray()
+    assert ((r["osdw"] @ Hd.T) % 2 == syn).all()
+    nonconv = same & ~r["converged"]
+    if nonconv.any():
+        assert ((r["osdw"][nonconv] != ref["osdw"][nonconv]).any(axis=1)).mean() <= 0.25
+
+
+def test_edge_cases(gpu_ready, surface13, h1922):
+    from bp_osd_amd import BpOsdDecoder, bposd_decoder
+
+    dec = BpOsdDecoder(h1922.hz, error_rate=0.05, osd_method="osd_cs", osd_order=7, bp_method="ms", ms_scaling_factor=0)
+    # empty batch
+    out = dec.decode_batch(np.zeros((0, 961), dtype=np.uint8))
+    assert out.shape == (0, 1922)
+    # all-zero syndromes: zeros, converge, iter 0 (Appendix A.2)
+    out = dec.decode_batch(np.zeros((5, 961), dtype=np.int64))
+    assert not out.any() and dec.batch_converge.all() and (dec.batch_iter == 0).all()
+    assert not dec.batch_osd0.any() and not dec.batch_bp.any()
+    # wrong lengths
+    with pytest.raises(ValueError):
+        dec.decode(np.zeros(960, dtype=int))
+    with pytest.raises(ValueError):
+        dec.decode_batch(np.zeros((3, 962), dtype=np.uint8))
+    # integer dtypes and values that are not 0/1 are taken mod 2
+    e = np.zeros(1922, dtype=np.int64)
+    e[[3, 700, 1500]] = 1
+    s = (h1922.hz @ e) % 2
+    a = dec.decode(s.astype(np.int64))
+    b = dec.decode((s + 2).astype(np.int32))
+    assert (a == b).all() and a.dtype == np.int64 and b.dtype == np.int32
+    assert (dec.osdw_decoding == e).all() and dec.converge
+    # dense ndarray pcm, legacy ctor, osd_order=-1 default
+    d2 = bposd_decoder(surface13.hz.toarray(), error_rate=0.1)
+    assert d2.bp_method == "product_sum" and d2.osd_method == "osd_0" and d2.max_iter == 13
+    d2.decode(np.array([1, 0, 0, 0, 0, 0]))
+    assert (surface13.hz @ d2.osdw_decoding % 2 == [1, 0, 0, 0, 0, 0]).all()
+    # unsupported sizes fail loudly instead of falling back
+    with pytest.raises(ValueError, match="osd_order"):
+        BpOsdDecoder(surface13.hz, error_rate=0.1, osd_method="osd_e", osd_order=8)
+
+
+def test_full_batch_properties(gpu_ready, h1922):
+    """BASELINE config sizes (B = 65536, H1922, min-sum, osd_cs 7, p = 0.05): size-independent
+    properties -- every correction reproduces its syndrome; converged rows have osd0 = osdw = bp;
+    weight(osdw) <= weight(osd0); decoding is a function of the syndrome alone (permutation
+    invariance across the batch / idempotence across calls); first 512 rows equal the oracle."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    q = 0.05
+    B = 65536
+    err, syn = _syndromes(h1922.hz, q, B, 2024)
+    kw = dict(error_rate=q, max_iter=0, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=7)
+    dec = BpOsdDecoder(h1922.hz, **kw)
+    r = _gpu_decode(dec, syn, want_llr=False)
+    assert (_syndrome_of(h1922.hz, r["osdw"]) == syn).all()
+    assert (_syndrome_of(h1922.hz, r["osd0"]) == syn).all()
+    conv = r["converged"]
+    assert conv.mean() > 0.99
+    assert (r["osd0"][conv] == r["bp"][conv]).all() and (r["osdw"][conv] == r["bp"][conv]).all()
+    assert (r["osdw"].sum(axis=1) <= r["osd0"].sum(axis=1)).all()
+    # permutation invariance / determinism
+    perm = np.random.default_rng(0).permutation(B)
+    r2 = _gpu_decode(dec, np.ascontiguousarray(syn[perm]), want_llr=False)
+    assert (r2["osdw"] == r["osdw"][perm]).all() and (r2["iters"] == r["iters"][perm]).all()
+    # logical error rate sanity (Monte-Carlo agreement is exact since outputs are identical)
+    import scipy.sparse as sp
+
+    ler = _syndrome_of(sp.csr_matrix(h1922.lz), r["osdw"] ^ err).any(axis=1).mean()
+    assert ler < 0.01
+    ref = OracleDecoder(h1922.hz, **kw).decode_batch(syn[:512], want_llr=False)
+    assert (r["osdw"][:512] == ref["osdw"]).all() and (r["iters"][:512] == ref["iters"]).all()
+
+
+def test_device_pointer_api_with_torch(gpu_ready, h1922):
+    """bposd_decode_batch_device: inputs already resident in HBM (torch tensors only as plumbing)."""
+    import torch
+    from bp_osd_amd import BpOsdDecoder
+
+    q = 0.05
+    _, syn = _syndromes(h1922.hz, q, 1024, 77)
+    dec = BpOsdDecoder(h1922.hz, error_rate=q, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=7)
+    host = dec.decode_batch(syn)
+    d_syn = torch.from_numpy(syn).cuda()
+    d_out = torch.empty((1024, 1922), dtype=torch.uint8, device="cuda")
+    d_conv = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    d_it = torch.empty(1024, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    dec.decode_batch_device(d_syn.data_ptr(), 1024, d_out.data_ptr(), None, None, d_conv.data_ptr(), d_it.data_ptr(), None)
+    dec.synchronize()
+    assert (d_out.cpu().numpy() == host).all()
+    assert (d_it.cpu().numpy() == dec.batch_iter).all()
