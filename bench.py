@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096, help="syndromes timed on the CPU oracle (0 = skip)")
     ap.add_argument("--variant", type=int, default=0, help="BP workgroup shape (0 auto, 1, 2, 4)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gather")
+    ap.add_argument("--max-iter", type=int, default=-1, help="override max_iter (diagnostics; -1 = the config's)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,6 +94,8 @@ def main():
     bp_method, ms, max_iter, osd_method, osd_order, B = CONFIGS[args.config]
     if args.batch:
         B = args.batch
+    if args.max_iter >= 0:
+        max_iter = args.max_iter
     q = args.p
 
     from bp_osd_amd.codes import h1922
@@ -220,7 +223,7 @@ def main():
             "config": {
                 "workload": f"{args.config}: [[1922,50]] HGP (31x31 circulant 1+x^2+x^5) hz 961x1922, "
                             f"{'min-sum' if bp_method == 'ms' else 'product-sum'} BP"
-                            f"{' variable scaling' if bp_method == 'ms' and ms == 0 else ''}, max_iter=1922, "
+                            f"{' variable scaling' if bp_method == 'ms' and ms == 0 else ''}, max_iter={max_iter or n}, "
                             f"{osd_method} order {osd_order}, iid bit-flip q={q}",
                 "per_gpu_batch": B,
                 "global_batch": B * world,

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbposd_mi355x.so")
+LIB_PATH = os.environ.get("BPOSD_LIB") or os.path.join(_HERE, "libbposd_mi355x.so")
 
 BPOSD_OK = 0
 BPOSD_ERR_INVALID = -1

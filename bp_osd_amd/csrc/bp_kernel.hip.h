@@ -7,16 +7,22 @@
 //   * one workgroup decodes one syndrome at a time and pulls the next one from a
 //     global atomic queue (iteration counts are wildly bimodal: 5 ... max_iter);
 //   * the E edge messages of the Tanner graph live in LDS for the whole decode, in a
-//     check-major structure-of-arrays layout  msg[k * m + c]  (k-th edge of check c),
-//     and are updated IN PLACE: the check pass overwrites bit->check messages with
-//     check->bit messages, the bit pass overwrites them back (every edge belongs to
-//     exactly one check and one bit, so no thread reads what another one writes
-//     inside a pass).  HBM traffic is m bytes in, a few n bytes out per syndrome;
-//   * per-thread graph tables (edge positions of "my" bits) and the running LLRs are
-//     held in registers: a thread owns the same checks / bits for every syndrome;
-//   * convergence (H * decoding == syndrome) is tracked incrementally: a bit whose
-//     hard decision flips toggles its checks' mismatch bits with LDS atomics and
-//     updates one mismatch counter, so the test per iteration is one LDS read.
+//     check-major structure-of-arrays layout  msg[k * MP + c]  (k-th edge of check c,
+//     MP = checks padded to threads x CPT), and are updated IN PLACE: the check pass
+//     overwrites bit->check messages with check->bit messages, the bit pass overwrites
+//     them back (every edge belongs to exactly one check and one bit, so no thread reads
+//     what another one writes inside a pass).  Consecutive lanes own consecutive checks
+//     => conflict-free ds_read_b64 / ds_write_b64 with immediate offsets in the check
+//     pass.  HBM traffic is m bytes in, a few n bytes out per syndrome;
+//   * per-thread graph tables (LDS slots of "my" bits' edges, priors) and the running
+//     LLRs are held in registers: a thread owns the same checks / bits for every syndrome;
+//     padded checks / bits point at a dummy LDS slot so both passes are branch-free;
+//   * convergence (H * decoding == syndrome) is tracked incrementally: a bit whose hard
+//     decision flips toggles its checks' bits in an LDS mismatch bitmap (fire-and-forget
+//     ds_xor); at the top of the next iteration every check thread looks at its own bit
+//     and a wave with any mismatch raises an LDS flag that is read after the barrier the
+//     check pass needs anyway.  The check pass of the iteration that discovers
+//     convergence is speculative work (one pass per syndrome).
 //
 // Arithmetic is fp64 and mirrors the association order of the reference algorithm
 // (prefix sums from the top of a column, suffix sums from the bottom, one multiply
@@ -28,19 +34,28 @@
 
 namespace bposd {
 
+// LDS message array type: volatile LDS-address-space accesses stop hipcc from fusing pairs into
+// ds_read2st64_b64 / ds_write2st64_b64 (half the LDS rate of two ds_read_b64 on gfx950,
+// MI355X_MICROARCH.md §LDS; measured here: BP kernel 38.8 -> 35.2 ms).  -DBPOSD_LDS_MERGED restores
+// the fused form for A/B runs.
+#ifndef BPOSD_LDS_MERGED
+typedef volatile __attribute__((address_space(3))) double* msg_ptr;
+#else
+typedef double* msg_ptr;
+#endif
+
 struct BpParams {
     int m, n;
     long long B;
     int max_iter;
     double ms_scaling;  // 0 => 1 - 2^-it
     int osd_enabled;    // 0: osd off, results = bp decoding even when not converged
-    int dc_rt;          // number of edge slots per check in the LDS layout (== template DC)
+    int mp;             // padded check count = blockDim.x * CPT (stride of the LDS layout)
     const uint8_t* __restrict__ synd;   // [B, m]
     const double* __restrict__ llr0;    // [n]
     const int* __restrict__ chk_deg;    // [m]
     const int* __restrict__ var_deg;    // [n]
-    const int* __restrict__ var_pos;    // [DVmax * n], entry d*n+i = k*m + c
-    const int* __restrict__ var_row;    // [DVmax * n], entry d*n+i = c
+    const int* __restrict__ var_pos;    // [DVmax * n], entry d*n+i = k*mp + c
     uint8_t* __restrict__ out_bp;       // [B, n] nullable
     uint8_t* __restrict__ out_osd0;     // [B, n] nullable
     uint8_t* __restrict__ out_osdw;     // [B, n]
@@ -53,6 +68,11 @@ struct BpParams {
     unsigned long long* __restrict__ iter_total;  // sum of iterations executed
 };
 
+__host__ __device__ inline size_t bp_lds_bytes(int DC, int mp) {
+    // messages (+1 dummy slot, padded to 16 B) + mismatch bitmap + 8 control words
+    return ((size_t)DC * mp + 2) * 8 + (size_t)(mp / 32 + 2) * 4 + 8 * 4;
+}
+
 __device__ __forceinline__ double alpha_for_iteration(double ms_scaling, int it) {
     // a4: alpha = ms_scaling_factor, or 1 - 2^-it when the factor is 0 (README.md:184).
     if (ms_scaling != 0.0) return ms_scaling;
@@ -60,45 +80,59 @@ __device__ __forceinline__ double alpha_for_iteration(double ms_scaling, int it)
     return 1.0 - __builtin_ldexp(1.0, -it);
 }
 
+// r = min(t, |v|) exactly as `a = fabs(v); if (a < t) t = a;` for every non-NaN t:
+// v_min_f64 returns the non-NaN operand, and t never is NaN (it starts at DBL_MAX).
+__device__ __forceinline__ double min_abs(double t, double v) {
+    double r;
+    asm("v_min_f64 %0, %1, |%2|" : "=v"(r) : "v"(t), "v"(v));
+    return r;
+}
+__device__ __forceinline__ double min_pos(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// x with its sign flipped when `flip` (exact: IEEE multiplication is sign-symmetric, so
+// mag * (-alpha) == -(mag * alpha) bit for bit)
+__device__ __forceinline__ double flip_sign(double x, bool flip) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return __longlong_as_double((long long)(u ^ (flip ? 0x8000000000000000ull : 0ull)));
+}
+
 // DC / DV: edge slots per check / per bit (compile-time maxima)
 // CPT / VPT: checks / bits owned by one thread;  blockDim.x * CPT >= m, blockDim.x * VPT >= n
 // REG: every check has exactly DC edges and every bit exactly DV (no predication)
 // METHOD: 0 product-sum, 1 min-sum
 // MINW: minimum waves per SIMD the register allocation must allow (occupancy target)
-template <int DC, int DV, int CPT, int VPT, int MAXNT, int MINW, bool REG, int METHOD>
+// MPT: compile-time check stride (0 = take P.mp); always a power of two and == blockDim.x * CPT,
+//      so LDS offsets k * MP * 8 become instruction immediates
+template <int DC, int DV, int CPT, int VPT, int MAXNT, int MINW, bool REG, int METHOD, int MPT>
 __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n;
-    const int NT = blockDim.x;
+    const int MP = MPT > 0 ? MPT : P.mp;  // power of two, == blockDim.x * CPT
+    const int NT = MPT > 0 ? MPT / CPT : (int)blockDim.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
-    double* msg = reinterpret_cast<double*>(smem);
-    const int dwords = (m + 31) >> 5;
-    unsigned int* diffw = reinterpret_cast<unsigned int*>(msg + (size_t)DC * m);
-    int* sh = reinterpret_cast<int*>(diffw + ((dwords + 1) & ~1));  // [0] mismatch [1] syndrome id [2] slot
+    double* msg_plain = reinterpret_cast<double*>(smem);
+    msg_ptr msg = (msg_ptr)msg_plain;
+    const int dummy = DC * MP;  // slot nobody's result depends on
+    unsigned int* diffw = reinterpret_cast<unsigned int*>(msg_plain + (size_t)DC * MP + 2);
+    int* sh = reinterpret_cast<int*>(diffw + (MP / 32 + 2));  // [0],[1] mismatch flags, [2] syndrome id, [3] slot
 
     // ---- per-thread graph tables (same for every syndrome this workgroup decodes)
-    int vpos[VPT][DV], vrow[VPT][DV], vdeg[VPT];
+    int vaddr[VPT][DV], vdeg[VPT];
+    bool vvalid[VPT];
     double l0[VPT];
 #pragma unroll
     for (int r = 0; r < VPT; ++r) {
         const int i = tid + r * NT;
-        vdeg[r] = 0;
-        l0[r] = 0.0;
+        vvalid[r] = i < n;
+        vdeg[r] = vvalid[r] ? (REG ? DV : P.var_deg[i]) : 0;
+        l0[r] = vvalid[r] ? P.llr0[i] : 1.0;
 #pragma unroll
-        for (int d = 0; d < DV; ++d) { vpos[r][d] = 0; vrow[r][d] = 0; }
-        if (i < n) {
-            vdeg[r] = REG ? DV : P.var_deg[i];
-            l0[r] = P.llr0[i];
-#pragma unroll
-            for (int d = 0; d < DV; ++d) {
-                if (d < vdeg[r]) {
-                    vpos[r][d] = P.var_pos[(size_t)d * n + i];
-                    vrow[r][d] = P.var_row[(size_t)d * n + i];
-                }
-            }
-        }
+        for (int d = 0; d < DV; ++d) vaddr[r][d] = (d < vdeg[r]) ? P.var_pos[(size_t)d * n + i] : dummy;
     }
     int cdeg[CPT];
 #pragma unroll
@@ -111,25 +145,25 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
         // ---- pull the next syndrome
         if (tid == 0) {
             sh[0] = 0;
-            sh[1] = atomicAdd(&P.counters[0], 1);
+            sh[1] = 0;
+            sh[2] = atomicAdd(&P.counters[0], 1);
         }
         __syncthreads();
-        const long long s = sh[1];
+        const long long s = sh[2];
         if (s >= P.B) break;  // uniform: every wave reaches this with the same value
 
-        // ---- syndrome bits of my checks; mismatch bits start as the syndrome itself
-        int sbit[CPT];
+        // ---- syndrome bits of my checks; the mismatch bitmap starts as the syndrome itself
+        bool sbit[CPT];
 #pragma unroll
         for (int r = 0; r < CPT; ++r) {
             const int c = tid + r * NT;
-            sbit[r] = (c < m) ? (P.synd[(size_t)s * m + c] & 1) : 0;
+            sbit[r] = (c < m) ? ((P.synd[(size_t)s * m + c] & 1) != 0) : false;
             const unsigned long long bal = __ballot(sbit[r]);
             if (lane == 0) {
                 const int w0 = (c >> 5);  // c is a multiple of 64 for lane 0
-                if (w0 < dwords) diffw[w0] = (unsigned int)bal;
-                if (w0 + 1 < dwords) diffw[w0 + 1] = (unsigned int)(bal >> 32);
-                const int pc = __popcll(bal);
-                if (pc) atomicAdd(&sh[0], pc);
+                diffw[w0] = (unsigned int)bal;
+                diffw[w0 + 1] = (unsigned int)(bal >> 32);
+                if (bal) sh[0] = 1;
             }
         }
         // ---- a3: every edge's bit->check message starts at the prior
@@ -141,50 +175,68 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
             dec[r] = 0;
 #pragma unroll
             for (int d = 0; d < DV; ++d)
-                if (d < vdeg[r]) msg[vpos[r][d]] = l0[r];
+                if (REG || d < vdeg[r]) msg[vaddr[r][d]] = l0[r];
         }
         __syncthreads();
 
         int it_done = 0;
         bool conv = (sh[0] == 0);  // all-zero syndrome: zeros, converge = true, BP not run (A.2)
         if (!conv) {
-            for (int it = 1; it <= P.max_iter; ++it) {
-                // =================== check -> bit pass (a4 / a5) ===================
+#pragma clang loop unroll(disable)
+            for (int it = 1;; ++it) {
+                const int fi = it & 1;
+                // ---- convergence test of iteration it-1: does any of my checks still mismatch?
+                // (at it = 1 the bitmap is the non-zero syndrome itself, so the flag is raised)
+                {
+                    bool mis = false;
+#pragma unroll
+                    for (int r = 0; r < CPT; ++r) {
+                        const int c = tid + r * NT;
+                        mis |= ((diffw[c >> 5] >> (c & 31)) & 1u) != 0;
+                    }
+                    const unsigned long long anym = __ballot(mis);
+                    if (lane == 0 && anym) sh[fi] = 1;
+                }
+                if (it > P.max_iter) {  // only the test is left
+                    __syncthreads();
+                    conv = (sh[fi] == 0);
+                    it_done = P.max_iter;
+                    break;
+                }
+                // =================== check -> bit pass (a4 / a5), speculative for it >= 2 ===========
                 const double alpha = alpha_for_iteration(P.ms_scaling, it);
 #pragma unroll
                 for (int r = 0; r < CPT; ++r) {
                     const int c = tid + r * NT;
                     const int deg = cdeg[r];
-                    if (deg > 0) {
+                    if (REG || deg > 0) {
+                        msg_ptr mc = msg + c;
                         double v[DC];
 #pragma unroll
                         for (int k = 0; k < DC; ++k)
-                            if (REG || k < deg) v[k] = msg[k * m + c];
+                            if (REG || k < deg) v[k] = mc[k * MP];
                         if (METHOD == 1) {
-                            double pre[DC];
-                            int neg[DC];
-                            int par = sbit[r];
-                            double t = __DBL_MAX__;
+                            // parity of (syndrome bit + #non-positive inputs); zero counts as negative
+                            bool neg[DC];
+                            bool par = sbit[r];
+#pragma unroll
+                            for (int k = 0; k < DC; ++k) {
+                                neg[k] = (REG || k < deg) ? (v[k] <= 0.0) : false;
+                                par ^= neg[k];
+                            }
+                            // forward / backward running minima of |b2c|, both started at DBL_MAX
+                            double pre[DC], suf[DC];
+                            pre[0] = __DBL_MAX__;
+#pragma unroll
+                            for (int k = 1; k < DC; ++k) pre[k] = (REG || k - 1 < deg) ? min_abs(pre[k - 1], v[k - 1]) : pre[k - 1];
+                            suf[DC - 1] = __DBL_MAX__;
+#pragma unroll
+                            for (int k = DC - 2; k >= 0; --k) suf[k] = (REG || k + 1 < deg) ? min_abs(suf[k + 1], v[k + 1]) : suf[k + 1];
 #pragma unroll
                             for (int k = 0; k < DC; ++k) {
                                 if (REG || k < deg) {
-                                    neg[k] = (v[k] <= 0.0) ? 1 : 0;
-                                    par += neg[k];
-                                    pre[k] = t;
-                                    const double a = __builtin_fabs(v[k]);
-                                    if (a < t) t = a;
-                                }
-                            }
-                            t = __DBL_MAX__;
-#pragma unroll
-                            for (int k = DC - 1; k >= 0; --k) {
-                                if (REG || k < deg) {
-                                    double mag = pre[k];
-                                    if (t < mag) mag = t;
-                                    const double f = ((par + neg[k]) & 1) ? -alpha : alpha;
-                                    msg[k * m + c] = mag * f;
-                                    const double a = __builtin_fabs(v[k]);
-                                    if (a < t) t = a;
+                                    const double mag = (k == 0) ? suf[0] : (k == DC - 1 ? pre[DC - 1] : min_pos(pre[k], suf[k]));
+                                    mc[k * MP] = flip_sign(mag * alpha, par ^ neg[k]);
                                 }
                             }
                         } else {
@@ -204,7 +256,7 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                             for (int k = DC - 1; k >= 0; --k) {
                                 if (REG || k < deg) {
                                     const double x = pre[k] * t;
-                                    msg[k * m + c] = sg * log((1 + x) / (1 - x));
+                                    mc[k * MP] = sg * log((1 + x) / (1 - x));
                                     t *= th[k];
                                 }
                             }
@@ -212,52 +264,56 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                     }
                 }
                 __syncthreads();
+                if (sh[fi] == 0) {  // iteration it-1 had already converged
+                    conv = true;
+                    it_done = it - 1;
+                    break;
+                }
+                if (tid == 0) sh[fi ^ 1] = 0;  // next written after the barrier below, last read before the one above
                 // ============ bit pass: posterior, decision, bit -> check (a6 / a7) ============
-                int delta = 0;
+                double cm[VPT][DV];
+#pragma unroll
+                for (int r = 0; r < VPT; ++r)
+#pragma unroll
+                    for (int d = 0; d < DV; ++d) cm[r][d] = msg[vaddr[r][d]];
 #pragma unroll
                 for (int r = 0; r < VPT; ++r) {
                     const int deg = vdeg[r];
-                    if (tid + r * NT < n) {
-                        double cm[DV], pre[DV];
-                        double t = l0[r];
+                    double pre[DV];
+                    double t = l0[r];
 #pragma unroll
-                        for (int d = 0; d < DV; ++d)
-                            if (REG || d < deg) cm[d] = msg[vpos[r][d]];
+                    for (int d = 0; d < DV; ++d) {
+                        if (REG || d < deg) {
+                            pre[d] = t;  // prefix from the top of the column (prior included)
+                            t += cm[r][d];
+                        }
+                    }
+                    llr[r] = t;
+                    const int dnew = (t <= 0.0) ? 1 : 0;
+                    double suf = 0.0;  // suffix from the bottom of the column
+#pragma unroll
+                    for (int d = DV - 1; d >= 0; --d) {
+                        if (REG || d < deg) {
+                            msg[vaddr[r][d]] = pre[d] + suf;
+                            suf += cm[r][d];
+                        }
+                    }
+                    if (vvalid[r] && dnew != dec[r]) {
+                        dec[r] = dnew;
 #pragma unroll
                         for (int d = 0; d < DV; ++d) {
                             if (REG || d < deg) {
-                                pre[d] = t;  // prefix from the top of the column (prior included)
-                                t += cm[d];
-                            }
-                        }
-                        llr[r] = t;
-                        const int dnew = (t <= 0.0) ? 1 : 0;
-                        double suf = 0.0;  // suffix from the bottom of the column
-#pragma unroll
-                        for (int d = DV - 1; d >= 0; --d) {
-                            if (REG || d < deg) {
-                                msg[vpos[r][d]] = pre[d] + suf;
-                                suf += cm[d];
-                            }
-                        }
-                        if (dnew != dec[r]) {
-                            dec[r] = dnew;
-#pragma unroll
-                            for (int d = 0; d < DV; ++d) {
-                                if (REG || d < deg) {
-                                    const int c = vrow[r][d];
-                                    const unsigned int bit = 1u << (c & 31);
-                                    const unsigned int old = atomicXor(&diffw[c >> 5], bit);
-                                    delta += (old & bit) ? -1 : 1;
-                                }
+                                int pos = vaddr[r][d];
+                                // opaque copy: keeps the (rare-path) bitmap address / mask arithmetic inside
+                                // this branch instead of being hoisted out of the iteration loop and spilled
+                                asm volatile("" : "+v"(pos));
+                                const int c = pos & (MP - 1);
+                                atomicXor(&diffw[c >> 5], 1u << (c & 31));
                             }
                         }
                     }
                 }
-                if (delta != 0) atomicAdd(&sh[0], delta);
                 __syncthreads();
-                it_done = it;
-                if (sh[0] == 0) { conv = true; break; }
             }
         }
 
@@ -267,14 +323,14 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
             if (to_osd) {
                 const int slot = atomicAdd(&P.counters[1], 1);
                 P.osd_list[slot] = (int)s;
-                sh[2] = slot;
+                sh[3] = slot;
             }
             if (P.out_conv) P.out_conv[s] = conv ? 1 : 0;
             if (P.out_iters) P.out_iters[s] = it_done;
             if (it_done) atomicAdd(P.iter_total, (unsigned long long)it_done);
         }
-        __syncthreads();  // publishes sh[2]; also fences this syndrome's reads of sh[0]
-        const int slot = to_osd ? sh[2] : 0;
+        __syncthreads();  // publishes sh[3]; also fences this syndrome's reads of sh[0..1]
+        const int slot = to_osd ? sh[3] : 0;
 #pragma unroll
         for (int r = 0; r < VPT; ++r) {
             const int i = tid + r * NT;
@@ -291,8 +347,8 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                 if (P.out_llr) P.out_llr[o] = llr[r];
             }
         }
-        // the next iteration's first barrier orders these reads before sh[] is rewritten:
-        // tid 0 writes sh[0..1] only after it has itself passed the barrier above.
+        // tid 0 rewrites sh[] only after it has itself passed the barrier above, and every
+        // thread has read sh[3] by the time it reaches the next loop-top barrier.
         __syncthreads();
     }
 }

@@ -53,9 +53,9 @@ struct bposd_handle {
     std::vector<double> probs;
     // device tables
     int *d_rp = nullptr, *d_ci = nullptr;
-    int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr, *d_var_row = nullptr;
+    int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr;
     double* d_llr0 = nullptr;
-    int tab_dc = 0, tab_dv = 0;  // layout the tables were built for
+    int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
     // workspace (grow-only)
     DevBuf llr_ws, osd_list, io_synd, io_osdw, io_osd0, io_bp, io_conv, io_iters, io_llr;
     int* d_counters = nullptr;              // 4 ints
@@ -141,11 +141,6 @@ bool pick_pair(int dc, int dv, DegPair* out) {
     return false;
 }
 
-size_t bp_lds_bytes(int DC, int m) {
-    const int dwords = (m + 31) / 32;
-    return (size_t)DC * m * 8 + (size_t)((dwords + 1) & ~1) * 4 + 64;
-}
-
 int upload_priors(bposd_handle* h) {
     // a3: prior LLR = log((1 - p) / p), evaluated on the host in fp64 (same libm call the
     // CPU path makes) so that device arithmetic is add / compare / multiply only.
@@ -158,18 +153,18 @@ int upload_priors(bposd_handle* h) {
     return 0;
 }
 
-int build_tables(bposd_handle* h, int DC, int DV) {
+int build_tables(bposd_handle* h, int DC, int DV, int MP) {
+    // LDS slot of the k-th edge of check c is k * MP + c (MP = checks padded to threads x CPT)
     const int m = h->m, n = h->n;
     std::vector<int> chk_deg(m), var_deg(n, 0);
-    std::vector<int> var_pos((size_t)DV * n, 0), var_row((size_t)DV * n, 0);
+    std::vector<int> var_pos((size_t)DV * n, 0);
     for (int c = 0; c < m; ++c) {
         chk_deg[c] = h->rp[c + 1] - h->rp[c];
         for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
             const int k = e - h->rp[c];
             const int i = h->ci[e];
             const int d = var_deg[i]++;  // rows visited ascending => ascending row within a column
-            var_pos[(size_t)d * n + i] = k * m + c;
-            var_row[(size_t)d * n + i] = c;
+            var_pos[(size_t)d * n + i] = k * MP + c;
         }
     }
     auto up = [&](int** dst, const std::vector<int>& v) -> int {
@@ -182,26 +177,26 @@ int build_tables(bposd_handle* h, int DC, int DV) {
     if ((rc = up(&h->d_chk_deg, chk_deg))) return rc;
     if ((rc = up(&h->d_var_deg, var_deg))) return rc;
     if ((rc = up(&h->d_var_pos, var_pos))) return rc;
-    if ((rc = up(&h->d_var_row, var_row))) return rc;
     h->tab_dc = DC;
     h->tab_dv = DV;
+    h->tab_mp = MP;
     return 0;
 }
 
 // ------------------------------------------------------------------------------ BP launch
-template <int DC, int DV, int CPT, int VPT, int MAXNT, int MINW, bool REG>
+template <int DC, int DV, int CPT, int VPT, int MAXNT, int MINW, bool REG, int MPT>
 int launch_bp_t(bposd_handle* h, const BpParams& P, int NT) {
-    const size_t lds = bp_lds_bytes(DC, h->m);
+    const size_t lds = bp_lds_bytes(DC, P.mp);
     int wg_per_cu = (int)std::min<size_t>(h->lds_per_cu / lds, (size_t)(2048 / NT));
     wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
     long long grid = std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu);
     if (grid < 1) grid = 1;
     if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
-        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 1>;
+        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 1, MPT>;
         HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, P);
     } else {
-        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 0>;
+        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 0, MPT>;
         HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, P);
     }
@@ -209,25 +204,32 @@ int launch_bp_t(bposd_handle* h, const BpParams& P, int NT) {
     return 0;
 }
 
-int round64(int x) { return std::max(64, (x + 63) / 64 * 64); }
+int pow2_at_least(int x) {
+    int p = 64;
+    while (p < x) p <<= 1;
+    return p;
+}
 
-// shape id: 1 -> (CPT 1, VPT 2, <=1024 threads), 2 -> (2, 4, <=512), 4 -> (4, 8, <=256)
+// shape id: 1 -> (CPT 1, VPT 2, <=1024 threads), 2 -> (2, 4, <=512), 4 -> (4, 8, <=256).
+// Threads per workgroup are a power of two so that the check stride MP = threads * CPT is one.
+// The regular (6,3) kernels are compiled for MP = 1024 exactly (H1922: 961 checks, 1922 bits).
+bool is_reg63(const bposd_handle* h) { return h->regular && h->dc_max == 6 && h->dv_max == 3; }
+
 int shape_threads(const bposd_handle* h, int shape) {
     const int cpt = shape, vpt = 2 * shape;
-    return round64(std::max((h->m + cpt - 1) / cpt, (h->n + vpt - 1) / vpt));
+    int nt = pow2_at_least(std::max((h->m + cpt - 1) / cpt, (h->n + vpt - 1) / vpt));
+    if (is_reg63(h) && nt <= 1024 / shape) nt = 1024 / shape;
+    return nt;
 }
 
 int pick_shape(const bposd_handle* h) {
     const int caps[3][2] = {{1, 1024}, {2, 512}, {4, 256}};
     if (h->bp_variant) {
         for (auto& c : caps)
-            if (c[0] == h->bp_variant && shape_threads(h, c[0]) <= c[1]) return c[0];
+            if (c[0] == h->bp_variant && shape_threads(h, c[0]) <= c[1] && (c[0] != 4 || is_reg63(h))) return c[0];
     }
-    // auto: small codes keep one check per thread; otherwise the widest shape that fits
-    if (shape_threads(h, 1) <= 256) return 1;
-    if (h->regular && h->dc_max == 6 && h->dv_max == 3) {
-        if (shape_threads(h, 2) <= 512) return 2;
-    }
+    if (is_reg63(h) && shape_threads(h, 2) <= 512) return 2;
+    // generic kernels: one check per thread when that fits, else two
     if (shape_threads(h, 1) <= 1024) return 1;
     if (shape_threads(h, 2) <= 512) return 2;
     return 0;
@@ -237,10 +239,10 @@ template <int DC, int DV, bool REG>
 int launch_bp_shape(bposd_handle* h, const BpParams& P, int shape, int NT) {
     // occupancy targets: LDS admits 3 workgroups per CU for H1922 (46 KB each); the regular
     // (6,3) kernels are register-capped for that (2 x 1024, 3 x 512 or 3 x 256 threads per CU)
-    if (shape == 1) return launch_bp_t<DC, DV, 1, 2, 1024, (REG ? 8 : 4), REG>(h, P, NT);
-    if (shape == 2) return launch_bp_t<DC, DV, 2, 4, 512, (REG ? 6 : 2), REG>(h, P, NT);
+    if (shape == 1) return launch_bp_t<DC, DV, 1, 2, 1024, (REG ? 8 : 4), REG, (REG ? 1024 : 0)>(h, P, NT);
+    if (shape == 2) return launch_bp_t<DC, DV, 2, 4, 512, (REG ? 6 : 2), REG, (REG ? 1024 : 0)>(h, P, NT);
     if constexpr (REG) {
-        if (shape == 4) return launch_bp_t<DC, DV, 4, 8, 256, 3, REG>(h, P, NT);
+        if (shape == 4) return launch_bp_t<DC, DV, 4, 8, 256, 3, REG, 1024>(h, P, NT);
     }
     return fail(h, BPOSD_ERR_UNSUPPORTED, "no BP kernel shape %d for this code", shape);
 }
@@ -248,10 +250,20 @@ int launch_bp_shape(bposd_handle* h, const BpParams& P, int shape, int NT) {
 int launch_bp(bposd_handle* h, BpParams& P) {
     int shape = pick_shape(h);
     if (!shape) return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the LDS-resident BP kernel (m=%d n=%d)", h->m, h->n);
-    if (shape == 4 && !(h->regular && h->dc_max == 6 && h->dv_max == 3)) shape = 2;
     const int NT = shape_threads(h, shape);
-    P.dc_rt = h->tab_dc;
-    if (h->regular && h->dc_max == 6 && h->dv_max == 3) return launch_bp_shape<6, 3, true>(h, P, shape, NT);
+    const int MP = NT * shape;
+    if (MP != h->tab_mp) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        int rc = build_tables(h, h->tab_dc, h->tab_dv, MP);
+        if (rc) return rc;
+        P.chk_deg = h->d_chk_deg;
+        P.var_deg = h->d_var_deg;
+        P.var_pos = h->d_var_pos;
+    }
+    P.mp = MP;
+    if (bp_lds_bytes(h->tab_dc, MP) > h->lds_per_cu)
+        return fail(h, BPOSD_ERR_UNSUPPORTED, "BP messages (%zu B) exceed one CU's LDS", bp_lds_bytes(h->tab_dc, MP));
+    if (is_reg63(h) && MP == 1024) return launch_bp_shape<6, 3, true>(h, P, shape, NT);
     switch (h->tab_dc) {
         case 4: return launch_bp_shape<4, 2, false>(h, P, shape, NT);
         case 6: return launch_bp_shape<6, 3, false>(h, P, shape, NT);
@@ -265,7 +277,7 @@ int launch_bp(bposd_handle* h, BpParams& P) {
 // ----------------------------------------------------------------------------- OSD launch
 template <int W>
 int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
-    const int NT = std::min(1024, round64(h->m));
+    const int NT = std::min(1024, std::max(64, (h->m + 63) / 64 * 64));
     const size_t lds = osd_lds_bytes(h->n, P.nsort, W);
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
@@ -325,7 +337,7 @@ void bposd_destroy(bposd_handle* h) {
                       &h->io_conv, &h->io_iters, &h->io_llr})
         release(*b);
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
-                    (void*)h->d_var_pos, (void*)h->d_var_row, (void*)h->d_llr0, (void*)h->d_counters,
+                    (void*)h->d_var_pos, (void*)h->d_llr0, (void*)h->d_counters,
                     (void*)h->d_iter_total})
         if (p) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -423,17 +435,17 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     h->regular = (dc_min == h->dc_max) && (dv_min == h->dv_max);
 
     DegPair pair;
-    if (h->regular && h->dc_max == 6 && h->dv_max == 3) pair = {6, 3};
+    if (is_reg63(h)) pair = {6, 3};
     else if (!pick_pair(h->dc_max, h->dv_max, &pair)) {
         fail(nullptr, BPOSD_ERR_UNSUPPORTED, "check degree %d / bit degree %d exceed the built kernels (16 / 8)",
              h->dc_max, h->dv_max);
         bposd_destroy(h);
         return BPOSD_ERR_UNSUPPORTED;
     }
-    if (bp_lds_bytes(pair.dc, m) > h->lds_per_cu || !pick_shape(h)) {
+    if (!pick_shape(h) || bp_lds_bytes(pair.dc, shape_threads(h, pick_shape(h)) * pick_shape(h)) > h->lds_per_cu) {
         fail(nullptr, BPOSD_ERR_UNSUPPORTED,
              "code too large for the LDS-resident BP kernel (m=%d n=%d needs %zu B of LDS): large-code path not built yet",
-             m, n, bp_lds_bytes(pair.dc, m));
+             m, n, bp_lds_bytes(pair.dc, ((m + 63) / 64) * 64));
         bposd_destroy(h);
         return BPOSD_ERR_UNSUPPORTED;
     }
@@ -479,7 +491,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(hipMalloc((void**)&h->d_iter_total, sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counters, sizeof(int) * 4));
     CREATE_TRY(hipHostMalloc((void**)&h->h_iter_total, sizeof(unsigned long long)));
-    CREATE_RC(build_tables(h, pair.dc, pair.dv));
+    CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, pick_shape(h)) * pick_shape(h)));
     CREATE_RC(upload_priors(h));
     if (h->cfg.osd_method >= BPOSD_OSD_E && h->cfg.osd_order > 0 && h->cfg.weight_fn == 0 && !h->probs_uniform) {
         fail(nullptr, BPOSD_ERR_UNSUPPORTED,
@@ -567,7 +579,6 @@ int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.chk_deg = h->d_chk_deg;
     P.var_deg = h->d_var_deg;
     P.var_pos = h->d_var_pos;
-    P.var_row = h->d_var_row;
     P.out_bp = d_bp;
     P.out_osd0 = d_osd0;
     P.out_osdw = d_osdw;
