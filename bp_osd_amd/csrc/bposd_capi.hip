@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,7 +58,9 @@ struct bposd_handle {
     double* d_llr0 = nullptr;
     int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
     // workspace (grow-only)
+    DevBuf osd_rows_ws;  // OSD kernel's per-workgroup spill area for finished row words
     DevBuf llr_ws, osd_list, io_synd, io_osdw, io_osd0, io_bp, io_conv, io_iters, io_llr;
+    long long* d_osd_dbg = nullptr;         // diagnostics (BPOSD_OSD_DEBUG=1): phase timestamps
     int* d_counters = nullptr;              // 4 ints
     unsigned long long* d_iter_total = nullptr;
     int* h_counters = nullptr;              // pinned: 4 ints
@@ -277,13 +280,19 @@ int launch_bp(bposd_handle* h, BpParams& P) {
 // ----------------------------------------------------------------------------- OSD launch
 template <int W>
 int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
-    const int NT = std::min(1024, std::max(64, (h->m + 63) / 64 * 64));
+    // OSD_RPT rows per thread: 4 waves cover 1024 rows
+    const int rows_per_thread = OSD_RPT;
+    const int NT = std::min(64 * OSD_MAXW, std::max(64, ((h->m + rows_per_thread - 1) / rows_per_thread + 63) / 64 * 64));
     const size_t lds = osd_lds_bytes(h->n, P.nsort, W);
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
+    int rc = ensure(h, h->osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
+    if (rc) return rc;
+    OsdParams Q = P;
+    Q.rows_ws = (unsigned long long*)h->osd_rows_ws.p;
     auto k = osd_kernel<W>;
     HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, P);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, Q);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
@@ -333,12 +342,12 @@ void bposd_destroy(bposd_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->llr_ws, &h->osd_list, &h->io_synd, &h->io_osdw, &h->io_osd0, &h->io_bp,
+    for (DevBuf* b : {&h->osd_rows_ws, &h->llr_ws, &h->osd_list, &h->io_synd, &h->io_osdw, &h->io_osd0, &h->io_bp,
                       &h->io_conv, &h->io_iters, &h->io_llr})
         release(*b);
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
                     (void*)h->d_var_pos, (void*)h->d_llr0, (void*)h->d_counters,
-                    (void*)h->d_iter_total})
+                    (void*)h->d_iter_total, (void*)h->d_osd_dbg})
         if (p) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->h_iter_total) (void)hipHostFree(h->h_iter_total);
@@ -613,8 +622,25 @@ int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.counters = h->d_counters;
         Q.out_osd0 = d_osd0;
         Q.out_osdw = d_osdw;
+        Q.dbg = nullptr;
+        const char* dbg_env = getenv("BPOSD_OSD_DEBUG");
+        if (dbg_env && dbg_env[0] == '1') {
+            if (!h->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->d_osd_dbg, 2048 * sizeof(long long)));
+            HIP_TRY(h, hipMemsetAsync(h->d_osd_dbg, 0, 2048 * sizeof(long long), h->stream));
+            Q.dbg = h->d_osd_dbg;
+        }
         if ((rc = launch_osd(h, Q, B))) return rc;
         h->ran_osd = true;
+        if (Q.dbg) {
+            static long long st[2048];
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipMemcpy(st, h->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
+            if (const char* dump = getenv("BPOSD_OSD_DUMP")) {
+                if (FILE* f = fopen(dump, "wb")) { fwrite(st, sizeof(long long), 2048, f); fclose(f); }
+            }
+            fprintf(stderr, "[bposd osd phases, s_memtime ticks] sort %lld  rowbuild %lld  eliminate %lld  osd0 %lld  sweep %lld  write %lld\n",
+                    st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5]);
+        }
     }
     HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));

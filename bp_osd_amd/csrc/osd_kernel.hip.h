@@ -5,25 +5,37 @@
 // /root/reference/src/bposd/css_decode_sim.py:257-258,294-295).
 //
 // One workgroup post-processes one non-converged syndrome at a time (persistent, pulls
-// from the list the BP kernel appended to).  Thread r owns row r of the parity-check
-// matrix as W 64-bit words HELD IN REGISTERS -- the columns are physically permuted
-// into reliability order first, so "process columns in sorted order" becomes a sweep
-// over bit positions with compile-time word indices.  The syndrome rides along as the
-// last bit of the last word.
+// from the list the BP kernel appended to).  A thread owns RPT rows of the parity-check
+// matrix (row = tid + k * blockDim.x), each as W 64-bit words HELD IN REGISTERS -- the
+// columns are physically permuted into reliability order first, so "process columns in
+// sorted order" becomes a sweep over bit positions.  The register array always holds the
+// words from the current 64-column panel onwards (word 0 = current panel): when a panel is
+// finished its word is final, is flushed to a per-thread spill area in global memory
+// (only ever re-read by the thread that wrote it) and the array shifts down by one, so
+// every register index is a compile-time constant while the panel loop stays a real loop.
+// The syndrome rides along as the last bit of the last word.  Few, fat waves (8 for H1922,
+// two per SIMD) keep the per-column bookkeeping -- which every wave executes -- cheap.
 //
 //   1. a8  reliability sort: bitonic network in LDS on (order-preserving u64 image of the
 //          LLR, bit index) -- a strict total order, so the result equals a stable sort.
-//   2. a9  Gauss-Jordan sweep, one barrier per column: every wave ballots its candidate
-//          rows, speculatively publishes its first candidate row to LDS; after the
-//          barrier everybody knows the winning wave, and every row with a 1 in the
-//          column XORs the pivot row in (words >= current word only: a not-yet-used row
-//          has no support left of the sweep position).  Stops after `rank` pivots.
+//   2. a9  blocked Gauss-Jordan, panels of 64 columns (one register word):
+//          (i) panel phase, one barrier per column: every wave ballots its candidate rows
+//          and publishes (flag, panel word, combination mask) of its first candidate in
+//          its own LDS slot; after the barrier everyone reads all slots (one LDS round
+//          trip), the lowest flagged wave wins; every row with a 1 in the column XORs the
+//          pivot's panel word and records the pivot in its own 64-bit combination mask t
+//          (row = row_at_panel_start ^ XOR_{q in t} pivot_q_at_panel_start);
+//          (ii) trailing phase, once per panel: the <= 64 pivot rows publish their
+//          trailing words, 4-bit "four Russians" tables of their XOR combinations are
+//          built in LDS, and every row applies its mask with one table lookup per 4
+//          pivots and word.  A not-yet-used row has no support left of the sweep position,
+//          so only words >= the panel word are ever touched.  Stops after `rank` pivots.
 //          Pivot columns = the greedy independent set in sorted order, exactly the set
 //          any row-pivoting strategy finds; OSD-0 = the syndrome bit of each pivot row.
 //   3. a10/a11  OSD-W: in reduced form the solution for a candidate that switches on
 //          non-pivot columns {t} is  x_S = y ^ XOR_t A_t,  so its weight is a popcount:
-//          singles via per-wave ballots + LDS counters, pairs / exhaustive patterns via
-//          transposed column bit-vectors.  Selection is the lexicographic minimum of
+//          singles via per-wave ballots accumulated per lane, pairs / exhaustive patterns
+//          via transposed column bit-vectors.  Selection is the lexicographic minimum of
 //          (weight, enumeration index) with OSD-0 first, i.e. "replace only if strictly
 //          lighter, first found wins".
 //
@@ -34,6 +46,10 @@
 #include <stdint.h>
 
 namespace bposd {
+
+constexpr int OSD_RPT = 2;      // rows per thread
+constexpr int OSD_MAXW = 8;     // max waves per workgroup (512 threads)
+constexpr int OSD_MAXCV = 16;   // max ballot words per column vector (RPT * waves)
 
 struct OsdParams {
     int m, n;
@@ -50,7 +66,14 @@ struct OsdParams {
     int* __restrict__ counters;        // [1] = number of list entries, [2] = OSD work queue
     uint8_t* __restrict__ out_osd0;    // [B, n] nullable
     uint8_t* __restrict__ out_osdw;    // [B, n]
+    unsigned long long* __restrict__ rows_ws;  // [gridDim.x][W][blockDim.x * RPT] finished row words
+    long long* __restrict__ dbg;       // nullable: 8 phase timestamps (s_memtime) of list slot 0
 };
+
+#define OSD_STAMP(k)                                                                              \
+    do {                                                                                          \
+        if (P.dbg && tid == 0 && slot_id == 0) P.dbg[k] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
 
 __device__ __forceinline__ unsigned long long llr_sort_key(double x) {
     // order-preserving map double -> u64 (x + 0.0 folds -0.0 into +0.0: they compare equal)
@@ -58,60 +81,67 @@ __device__ __forceinline__ unsigned long long llr_sort_key(double x) {
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// LDS carve-up (bytes), all offsets 8-byte aligned
+// LDS carve-up, all offsets 8-byte aligned
 struct OsdLds {
-    unsigned long long* keys;     // [nsort]
-    unsigned short* kidx;         // [nsort]  -> order[j] after the sort
-    unsigned short* inv;          // [n] original column -> sorted position
-    short* pivrow;                // [nsort] sorted position -> pivot row, -1 if non-pivot
-    int* wt;                      // [nsort] weight of single candidate at sorted position
-    unsigned long long* rowbuf;   // [2][16][W]
-    unsigned long long* colvec;   // [64][16]
-    unsigned long long* yvec;     // [16]
-    unsigned int* slot;           // [2][16]
-    unsigned char* xout;          // [n]
+    unsigned long long* keys;     // [nsort]; after the sort: first 128 B reused as T-index -> position
+    unsigned long long* pbuf;     // [2][OSD_MAXW][4]  (flag, panel word, mask, pad) per wave
+    unsigned long long* prow;     // [64][W]   trailing words of this panel's pivots
+    unsigned long long* tab;      // [16][W][16] XOR combinations of 4 pivots
+    unsigned long long* colvec;   // [64][OSD_MAXCV]
+    unsigned long long* yvec;     // [OSD_MAXCV]
+    unsigned long long* npmask;   // [W] non-pivot positions per word
     unsigned long long* best64;   // [2]
+    int* wt;                      // [64 * W] weight of the single candidate at each sorted position
     int* misc;                    // [8]
+    unsigned short* kidx;         // [nsort]  -> order[j] after the sort
+    short* pivrow;                // [nsort] sorted position -> pivot row, -1 if non-pivot
+    unsigned short* inv;          // [n] original column -> sorted position
+    unsigned char* xout;          // [n]
 };
 
 __host__ __device__ inline size_t osd_lds_bytes(int n, int nsort, int W) {
     size_t b = 0;
-    b += (size_t)nsort * 8;                 // keys
-    b += (size_t)nsort * 2;                 // kidx
-    b += ((size_t)n * 2 + 7) & ~(size_t)7;  // inv
-    b += (size_t)nsort * 2;                 // pivrow
-    b += (size_t)nsort * 4;                 // wt
-    b += (size_t)2 * 16 * W * 8;            // rowbuf
-    b += (size_t)64 * 16 * 8;               // colvec
-    b += 16 * 8;                            // yvec
-    b += 2 * 16 * 4;                        // slot
-    b += ((size_t)n + 7) & ~(size_t)7;      // xout
-    b += 2 * 8;                             // best64
-    b += 8 * 4;                             // misc
+    b += (size_t)nsort * 8;                     // keys
+    b += (size_t)2 * OSD_MAXW * 4 * 8;          // pbuf
+    b += (size_t)64 * W * 8;                    // prow
+    b += (size_t)16 * W * 16 * 8;               // tab
+    b += (size_t)64 * OSD_MAXCV * 8;            // colvec
+    b += (size_t)OSD_MAXCV * 8;                 // yvec
+    b += (size_t)W * 8;                         // npmask
+    b += 2 * 8;                                 // best64
+    b += (size_t)64 * W * 4;                    // wt
+    b += 8 * 4;                                 // misc
+    b += (size_t)nsort * 2;                     // kidx
+    b += (size_t)nsort * 2;                     // pivrow
+    b += ((size_t)n * 2 + 7) & ~(size_t)7;      // inv
+    b += ((size_t)n + 7) & ~(size_t)7;          // xout
     return b + 64;
 }
 
 template <int W>
-__global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
+__global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RPT = OSD_RPT;
     const int m = P.m, n = P.n, NS = P.nsort;
     const int NT = blockDim.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = NT >> 6;
-    constexpr int SB = 64 * W - 1;  // bit position of the syndrome column
+    const int ncv = nwaves * RPT;  // ballot words per column vector; word index = k * nwaves + wave
 
     OsdLds L;
     {
         unsigned char* p = smem;
         L.keys = (unsigned long long*)p; p += (size_t)NS * 8;
-        L.rowbuf = (unsigned long long*)p; p += (size_t)2 * 16 * W * 8;
-        L.colvec = (unsigned long long*)p; p += (size_t)64 * 16 * 8;
-        L.yvec = (unsigned long long*)p; p += 16 * 8;
+        L.pbuf = (unsigned long long*)p; p += (size_t)2 * OSD_MAXW * 4 * 8;
+        L.prow = (unsigned long long*)p; p += (size_t)64 * W * 8;
+        L.tab = (unsigned long long*)p; p += (size_t)16 * W * 16 * 8;
+        L.colvec = (unsigned long long*)p; p += (size_t)64 * OSD_MAXCV * 8;
+        L.yvec = (unsigned long long*)p; p += (size_t)OSD_MAXCV * 8;
+        L.npmask = (unsigned long long*)p; p += (size_t)W * 8;
         L.best64 = (unsigned long long*)p; p += 2 * 8;
-        L.wt = (int*)p; p += (size_t)NS * 4;
-        L.slot = (unsigned int*)p; p += 2 * 16 * 4;
+        L.wt = (int*)p; p += (size_t)64 * W * 4;
         L.misc = (int*)p; p += 8 * 4;
         L.kidx = (unsigned short*)p; p += (size_t)NS * 2;
         L.pivrow = (short*)p; p += (size_t)NS * 2;
@@ -128,6 +158,7 @@ __global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
         const long long s = P.osd_list[slot_id];
         const double* llr = P.llr_ws + (size_t)slot_id * n;
 
+        OSD_STAMP(0);
         // ------------------------------------------------------------------ a8: sort
         for (int i = tid; i < NS; i += NT) {
             if (i < n) {
@@ -138,13 +169,13 @@ __global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
                 L.kidx[i] = (unsigned short)i;  // >= n: pads sort last
             }
             L.pivrow[i] = -1;
-            L.wt[i] = 1;
         }
+        for (int i = tid; i < 64 * W; i += NT) L.wt[i] = 1;
         __syncthreads();
         for (int k = 2; k <= NS; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int t = tid; t < (NS >> 1); t += NT) {
-                    // pair (lo, hi = lo ^ j) with bit j of lo clear
+                    // pair (lo, hi = lo | j) with bit j of lo clear
                     const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                     const int hi = lo | j;
                     const bool up = ((lo & k) == 0);
@@ -166,116 +197,235 @@ __global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
         for (int j = tid; j < n; j += NT) L.inv[L.kidx[j]] = (unsigned short)j;
         __syncthreads();
 
-        // ------------------------------------------- build my row in sorted column order
-        unsigned long long row[W];
+        OSD_STAMP(1);
+        // ------------------------------------------- build my rows in sorted column order
+        unsigned long long row[RPT][W];
 #pragma unroll
-        for (int w = 0; w < W; ++w) row[w] = 0ull;
-        if (tid < m) {
-            const int e0 = P.rp[tid], e1 = P.rp[tid + 1];
-            for (int e = e0; e < e1; ++e) {
-                const int j = L.inv[P.ci[e]];
-                const int jw = j >> 6;
-                const unsigned long long bit = 1ull << (j & 63);
+        for (int k = 0; k < RPT; ++k) {
 #pragma unroll
-                for (int w = 0; w < W; ++w) row[w] |= (jw == w) ? bit : 0ull;
+            for (int w = 0; w < W; ++w) row[k][w] = 0ull;
+            const int r = tid + k * NT;
+            if (r < m) {
+                const int e0 = P.rp[r], e1 = P.rp[r + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const int j = L.inv[P.ci[e]];
+                    const int jw = j >> 6;
+                    const unsigned long long bit = 1ull << (j & 63);
+#pragma unroll
+                    for (int w = 0; w < W; ++w) row[k][w] |= (jw == w) ? bit : 0ull;
+                }
+                if (P.synd[(size_t)s * m + r] & 1) row[k][W - 1] |= 1ull << 63;
             }
-            if (P.synd[(size_t)s * m + tid] & 1) row[W - 1] |= 1ull << 63;
         }
 
-        // ------------------------------------------------------- a9: Gauss-Jordan sweep
-        bool used = false;
-        int mypos = -1;
+        OSD_STAMP(2);
+        // ------------------------------------------------------- a9: blocked Gauss-Jordan
+        const int MR = NT * RPT;  // padded row count of the spill layout
+        unsigned long long* ws = P.rows_ws + (size_t)blockIdx.x * W * MR;  // [W][MR], word-major: coalesced
+        bool used[RPT];
+        int mypos[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { used[k] = false; mypos[k] = -1; }
         int nrank = 0;
-        int par = 0;   // rowbuf double buffer
-        int cur = 0;   // rotating candidate-wave mask word (3 deep, see below)
+        int par = 0;  // pbuf double buffer
         bool done = false;
-        if (tid < 3) L.slot[tid] = 0u;
-        __syncthreads();
-#pragma unroll
+        int wdone = 0;  // panels flushed so far; row[k][x] currently holds original word wdone + x
+#pragma clang loop unroll(disable)
         for (int w = 0; w < W; ++w) {
-            if (!done) {
-                for (int b = 0; b < 64; ++b) {
-                    const int j = w * 64 + b;
-                    if (j >= n || nrank >= P.rank) { done = true; break; }
-                    const bool bit = (row[w] >> b) & 1ull;
-                    const bool cand = bit && !used;
-                    const unsigned long long bal = __ballot(cand);
-                    const int first = bal ? (__ffsll((long long)bal) - 1) : -1;
-                    if (cand && lane == first) {
-                        // speculative publish: my wave's first candidate row, words >= w
-                        atomicOr(&L.slot[cur], 1u << wave);
-                        unsigned long long* dst = L.rowbuf + (size_t)(par * 16 + wave) * W;
+            if (done) break;
+            const int nvalid = W - 1 - w;  // live trailing words: row[k][1 .. nvalid]
+            // ---------------- (i) panel phase on the current word row[k][0]
+            unsigned long long t[RPT];
+            int myq[RPT];
 #pragma unroll
-                        for (int x = w; x < W; ++x) dst[x] = row[x];
-                    }
-                    __syncthreads();
-                    const unsigned int mask = L.slot[cur];
-                    // Mask word (cur+2)%3 was last read before this barrier and is next written
-                    // after the following one: safe to clear now.
-                    const int nxt2 = (cur >= 1) ? cur - 1 : 2;
-                    if (tid == 0) L.slot[nxt2] = 0u;
-                    if (mask) {
-                        const int wv = __ffs((int)mask) - 1;
-                        if (cand && wave == wv && lane == first) {
-                            used = true;
-                            mypos = j;
-                            L.pivrow[j] = (short)tid;
-                        } else if (bit) {
-                            const unsigned long long* src = L.rowbuf + (size_t)(par * 16 + wv) * W;
+            for (int k = 0; k < RPT; ++k) { t[k] = 0ull; myq[k] = -1; }
+            int npiv = 0;  // pivots found in this panel (uniform)
+#pragma clang loop unroll(disable)
+            for (int b = 0; b < 64; ++b) {
+                const int j = w * 64 + b;
+                if (j >= n || nrank >= P.rank) { done = true; break; }
+                const unsigned long long bmask = 1ull << b;
+                bool bit[RPT];
+                int ck = -1;     // first slot in which my wave has a candidate (uniform per wave)
+                int first = -1;  // its lane
 #pragma unroll
-                            for (int x = w; x < W; ++x) row[x] ^= src[x];
+                for (int k = 0; k < RPT; ++k) {
+                    bit[k] = (row[k][0] & bmask) != 0ull;
+                    const unsigned long long bal = __ballot(bit[k] && !used[k]);
+                    if (ck < 0 && bal) { ck = k; first = __ffsll((long long)bal) - 1; }
+                }
+                unsigned long long* mine = L.pbuf + (size_t)(par * OSD_MAXW + wave) * 4;
+                if (lane == (ck >= 0 ? first : 0)) {
+                    unsigned long long pw = 0ull, pt = 0ull;
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k)
+                        if (k == ck) { pw = row[k][0]; pt = t[k]; }
+                    mine[0] = (ck >= 0) ? 1ull : 0ull;
+                    mine[1] = pw;
+                    mine[2] = pt;
+                }
+                __syncthreads();
+                // everyone reads every wave's slot (one LDS round trip); lowest flagged wave wins
+                int wv = -1;
+                unsigned long long pw_p = 0ull, t_p = 0ull;
+                for (int q = nwaves - 1; q >= 0; --q) {
+                    const unsigned long long* sl = L.pbuf + (size_t)(par * OSD_MAXW + q) * 4;
+                    const unsigned long long f = sl[0], a = sl[1], c = sl[2];
+                    if (f) { wv = q; pw_p = a; t_p = c; }
+                }
+                if (wv >= 0) {
+                    const unsigned long long qbit = 1ull << npiv;
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const bool is_pivot = (wave == wv) && (k == ck) && (lane == first);
+                        if (is_pivot) {
+                            used[k] = true;
+                            mypos[k] = j;
+                            myq[k] = npiv;
+                            L.pivrow[j] = (short)(tid + k * NT);
+                        } else if (bit[k]) {
+                            row[k][0] ^= pw_p;
+                            t[k] ^= t_p ^ qbit;
                         }
-                        ++nrank;
                     }
-                    par ^= 1;
-                    cur = (cur == 2) ? 0 : cur + 1;
+                    ++npiv;
+                    ++nrank;
+                }
+                par ^= 1;
+            }
+            // ---------------- (ii) trailing phase on row[k][1 .. nvalid], in chunks of 8 words
+            if (nvalid > 0 && npiv > 0) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    if (myq[k] >= 0) {
+#pragma unroll
+                        for (int x = 1; x < W; ++x)
+                            if (x <= nvalid) L.prow[myq[k] * W + x] = row[k][x];
+                    }
+                }
+                __syncthreads();
+                const int ngroups = (npiv + 3) >> 2;
+                for (int e = tid; e < ngroups * 16 * nvalid; e += NT) {
+                    const int g = e / (16 * nvalid);
+                    const int rem = e - g * (16 * nvalid);
+                    const int x = 1 + (rem >> 4);
+                    const int idx = rem & 15;
+                    unsigned long long v = 0ull;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        if (((idx >> kk) & 1) && (4 * g + kk) < npiv) v ^= L.prow[(4 * g + kk) * W + x];
+                    L.tab[(g * W + x) * 16 + idx] = v;
+                }
+                __syncthreads();
+#pragma clang loop unroll(disable)
+                for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const int idx = (int)((t[k] >> (4 * g)) & 15ull);
+                        const unsigned long long* tg = L.tab + (size_t)g * W * 16 + idx;
+#pragma unroll
+                        for (int x0 = 1; x0 < W; x0 += 8) {
+                            if (x0 <= nvalid) {  // uniform
+#pragma unroll
+                                for (int x = x0; x < x0 + 8 && x < W; ++x) row[k][x] ^= tg[x * 16];
+                            }
+                        }
+                    }
                 }
             }
+            // ---------------- word w is final: flush it and shift the register window down
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                ws[(size_t)w * MR + tid + k * NT] = row[k][0];
+#pragma unroll
+                for (int x = 0; x + 1 < W; ++x) row[k][x] = row[k][x + 1];
+                row[k][W - 1] = 0ull;
+            }
+            wdone = w + 1;
         }
-        const int y = (int)((row[W - 1] >> 63) & 1ull);
+        // flush the words that were never reached as a panel (stop at rank / column n)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+#pragma unroll
+            for (int x = 0; x < W; ++x)
+                if (wdone + x < W) ws[(size_t)(wdone + x) * MR + tid + k * NT] = row[k][x];
+        }
+        OSD_STAMP(3);
+        bool y[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) y[k] = ((ws[(size_t)(W - 1) * MR + tid + k * NT] >> 63) & 1ull) != 0ull;
 
         // --------------------------------------------------------------- OSD-0 solution
         for (int i = tid; i < n; i += NT) L.xout[i] = 0;
-        {
-            const unsigned long long yb = __ballot(used && y);
-            if (lane == 0) L.yvec[wave] = yb;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const unsigned long long yb = __ballot(used[k] && y[k]);
+            if (lane == 0) L.yvec[k * nwaves + wave] = yb;
         }
         if (tid == 0) { L.best64[0] = ~0ull; L.best64[1] = ~0ull; }
         __syncthreads();  // also makes every pivrow[] write visible
-        if (used && y) L.xout[L.kidx[mypos]] = 1;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (used[k] && y[k]) L.xout[L.kidx[mypos[k]]] = 1;
+        // non-pivot position masks, one 64-bit word per panel
+        for (int w = wave; w < W; w += nwaves) {
+            const int j = w * 64 + lane;
+            const unsigned long long np = __ballot(j < n && L.pivrow[j] < 0);
+            if (lane == 0) L.npmask[w] = np;
+        }
         __syncthreads();
         if (P.out_osd0)
             for (int i = tid; i < n; i += NT) P.out_osd0[(size_t)s * n + i] = L.xout[i];
 
         int w0 = 0;
-        for (int q = 0; q < nwaves; ++q) w0 += __popcll(L.yvec[q]);
+        for (int q = 0; q < ncv; ++q) w0 += __popcll(L.yvec[q]);
 
+        OSD_STAMP(4);
         int sel_a = -1, sel_b = -1;  // sorted positions switched on by the winning candidate
         if (P.osd_method >= 2 && P.osd_order > 0) {
             // ---------------- a10/a11: singles weights + transposed columns of the first w non-pivots
             const int wspan = P.osd_order < 64 ? P.osd_order : 64;
+            unsigned short* tpos = (unsigned short*)L.keys;  // T-index -> sorted position (first 64)
             int tcount = 0;  // running T-index (uniform)
-#pragma unroll
+#pragma clang loop unroll(disable)
             for (int w = 0; w < W; ++w) {
-                for (int b = 0; b < 64; ++b) {
-                    const int j = w * 64 + b;
-                    if (j >= n) break;
-                    if (L.pivrow[j] >= 0) continue;  // uniform
-                    const int bit = (int)((row[w] >> b) & 1ull);
-                    if (P.osd_method == 3) {
-                        const unsigned long long d = __ballot(used && (bit ^ y));
-                        if (lane == 0 && d) atomicAdd(&L.wt[j], __popcll(d));
+                unsigned long long npm = L.npmask[w];
+                // make the mask wave-uniform for the scalar loop below; readfirstlane returns int, so go
+                // through unsigned before widening (a set bit 31 must not sign-extend into the high word)
+                npm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(npm >> 32)) << 32) |
+                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)npm);
+                if (!npm) continue;  // uniform
+                unsigned long long rw[RPT];
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) rw[k] = ws[(size_t)w * MR + tid + k * NT];  // my own words
+                int acc = 0;  // lane b accumulates the weight contribution of column w*64+b
+                while (npm) {
+                    const int b = __ffsll((long long)npm) - 1;
+                    npm &= npm - 1;
+                    const unsigned long long bmask = 1ull << b;
+                    int cnt = 0;
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const bool bitv = (rw[k] & bmask) != 0ull;
+                        if (P.osd_method == 3) cnt += __popcll(__ballot(used[k] && (bitv != y[k])));
+                        if (tcount < wspan) {
+                            const unsigned long long cb = __ballot(used[k] && bitv);
+                            if (lane == 0) L.colvec[tcount * OSD_MAXCV + k * nwaves + wave] = cb;
+                        }
                     }
-                    if (tcount < wspan) {
-                        const unsigned long long cb = __ballot(used && bit);
-                        if (lane == 0) L.colvec[tcount * 16 + wave] = cb;
-                    }
-                    if (tid == 0 && tcount < 64) ((unsigned short*)L.keys)[tcount] = (unsigned short)j;
+                    if (lane == b) acc += cnt;
+                    if (tid == 0 && tcount < 64) tpos[tcount] = (unsigned short)(w * 64 + b);
                     ++tcount;
                 }
+                if (P.osd_method == 3 && acc) atomicAdd(&L.wt[w * 64 + lane], acc);
             }
             __syncthreads();
-            const unsigned short* tpos = (const unsigned short*)L.keys;  // T-index -> sorted position (first 64)
+            if (P.dbg && slot_id == 0) {  // diagnostics: dump yvec, tpos, colvec behind the 8 stamps
+                for (int i = tid; i < OSD_MAXCV; i += NT) P.dbg[8 + i] = (long long)L.yvec[i];
+                for (int i = tid; i < 64; i += NT) P.dbg[8 + OSD_MAXCV + i] = (long long)tpos[i];
+                for (int i = tid; i < 64 * OSD_MAXCV; i += NT) P.dbg[8 + OSD_MAXCV + 64 + i] = (long long)L.colvec[i];
+                for (int i = tid; i < W; i += NT) P.dbg[8 + OSD_MAXCV + 64 + 64 * OSD_MAXCV + i] = (long long)L.npmask[i];
+            }
             if (P.osd_method == 3) {
                 // singles: all k' non-pivot positions, enumeration order == position order
                 for (int j = tid; j < n; j += NT) {
@@ -287,13 +437,12 @@ __global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
                 // pairs (a < b < w), a outer, b inner
                 const int npairs = wspan * (wspan - 1) / 2;
                 for (int pidx = tid; pidx < npairs; pidx += NT) {
-                    // decode pair index: rows of lengths wspan-1, wspan-2, ...
                     int a = 0, rem = pidx;
                     while (rem >= wspan - 1 - a) { rem -= wspan - 1 - a; ++a; }
                     const int bq = a + 1 + rem;
                     int wgt = 2;
-                    for (int q = 0; q < nwaves; ++q)
-                        wgt += __popcll(L.yvec[q] ^ L.colvec[a * 16 + q] ^ L.colvec[bq * 16 + q]);
+                    for (int q = 0; q < ncv; ++q)
+                        wgt += __popcll(L.yvec[q] ^ L.colvec[a * OSD_MAXCV + q] ^ L.colvec[bq * OSD_MAXCV + q]);
                     const unsigned long long key = ((unsigned long long)wgt << 32) | (unsigned)pidx;
                     atomicMin(&L.best64[1], key);
                 }
@@ -318,13 +467,13 @@ __global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
                 const unsigned int npat = (1u << wspan) - 1u;
                 for (unsigned int pat = tid + 1; pat <= npat; pat += NT) {
                     int wgt = __popc(pat);
-                    for (int q = 0; q < nwaves; ++q) {
+                    for (int q = 0; q < ncv; ++q) {
                         unsigned long long v = L.yvec[q];
                         unsigned int pp = pat;
                         while (pp) {
                             const int bq = __ffs((int)pp) - 1;
                             pp &= pp - 1;
-                            v ^= L.colvec[bq * 16 + q];
+                            v ^= L.colvec[bq * OSD_MAXCV + q];
                         }
                         wgt += __popcll(v);
                     }
@@ -334,13 +483,13 @@ __global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
                 __syncthreads();
                 const unsigned long long k1 = L.best64[0];
                 if (k1 != ~0ull && (int)(k1 >> 32) < w0) {
-                    // winner is a multi-column pattern: fold it into sel via misc
-                    sel_a = -2;
+                    sel_a = -2;  // winner is a multi-column pattern
                     sel_b = (int)(k1 & 0xffffffffu);
                 }
             }
         }
 
+        OSD_STAMP(5);
         // ------------------------------------------------- write the OSD-W solution
         if (sel_a == -1) {
             // OSD-0 stays the best
@@ -349,16 +498,16 @@ __global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
             __syncthreads();
             for (int i = tid; i < n; i += NT) L.xout[i] = 0;
             __syncthreads();
-            int xs = y;
+            bool xs[RPT];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) xs[k] = y[k];
             if (sel_a >= 0) {
                 // one or two switched-on columns at sorted positions sel_a, sel_b
-                int ba = 0, bb = 0;
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    if ((sel_a >> 6) == w) ba = (int)((row[w] >> (sel_a & 63)) & 1ull);
-                    if (sel_b >= 0 && (sel_b >> 6) == w) bb = (int)((row[w] >> (sel_b & 63)) & 1ull);
+                for (int k = 0; k < RPT; ++k) {
+                    xs[k] ^= ((ws[(size_t)(sel_a >> 6) * MR + tid + k * NT] >> (sel_a & 63)) & 1ull) != 0ull;
+                    if (sel_b >= 0) xs[k] ^= ((ws[(size_t)(sel_b >> 6) * MR + tid + k * NT] >> (sel_b & 63)) & 1ull) != 0ull;
                 }
-                xs ^= ba ^ bb;
                 if (tid == 0) {
                     L.xout[L.kidx[sel_a]] = 1;
                     if (sel_b >= 0) L.xout[L.kidx[sel_b]] = 1;
@@ -370,18 +519,19 @@ __global__ __launch_bounds__(1024) void osd_kernel(const OsdParams P) {
                     const int bq = __ffs((int)pp) - 1;
                     pp &= pp - 1;
                     const int pos = tpos[bq];
-                    int bv = 0;
 #pragma unroll
-                    for (int w = 0; w < W; ++w)
-                        if ((pos >> 6) == w) bv = (int)((row[w] >> (pos & 63)) & 1ull);
-                    xs ^= bv;
+                    for (int k = 0; k < RPT; ++k)
+                        xs[k] ^= ((ws[(size_t)(pos >> 6) * MR + tid + k * NT] >> (pos & 63)) & 1ull) != 0ull;
                     if (tid == 0) L.xout[L.kidx[pos]] = 1;
                 }
             }
-            if (used && xs) L.xout[L.kidx[mypos]] = 1;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k)
+                if (used[k] && xs[k]) L.xout[L.kidx[mypos[k]]] = 1;
             __syncthreads();
             for (int i = tid; i < n; i += NT) P.out_osdw[(size_t)s * n + i] = L.xout[i];
         }
+        OSD_STAMP(6);
         __syncthreads();
     }
 }
