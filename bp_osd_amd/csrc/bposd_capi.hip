@@ -56,6 +56,8 @@ struct bposd_handle {
     int *d_rp = nullptr, *d_ci = nullptr;
     int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr;
     double* d_llr0 = nullptr;
+    double* d_cost = nullptr;  // log(1/p_i): OSD-W weights of the ldpc-v2 weight function
+    bool fp_weights = false;   // non-uniform (or degenerate) channel: candidate weights need the fp64 sums
     int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
     // workspace (grow-only)
     DevBuf osd_rows_ws;  // OSD kernel's per-workgroup spill area for finished row words
@@ -153,6 +155,14 @@ int upload_priors(bposd_handle* h) {
     h->probs_uniform = true;
     for (int i = 1; i < h->n; ++i)
         if (h->probs[i] != h->probs[0]) { h->probs_uniform = false; break; }
+    // a11: weight(x) = sum over set bits of log(1/p_i) (ldpc v2).  For a uniform 0 < p < 1 every term is
+    // the same positive number, so the sums order candidates exactly like Hamming weights (identical
+    // partial sums, strictly increasing in the count) and the integer path is used.
+    std::vector<double> cost(h->n);
+    for (int i = 0; i < h->n; ++i) cost[i] = std::log(1 / h->probs[i]);
+    HIP_TRY(h, hipMemcpy(h->d_cost, cost.data(), sizeof(double) * h->n, hipMemcpyHostToDevice));
+    h->fp_weights = (h->cfg.weight_fn == 0) &&
+                    !(h->probs_uniform && h->probs[0] > 0.0 && h->probs[0] < 1.0);
     return 0;
 }
 
@@ -283,7 +293,7 @@ int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
     // OSD_RPT rows per thread: 4 waves cover 1024 rows
     const int rows_per_thread = OSD_RPT;
     const int NT = std::min(64 * OSD_MAXW, std::max(64, ((h->m + rows_per_thread - 1) / rows_per_thread + 63) / 64 * 64));
-    const size_t lds = osd_lds_bytes(h->n, P.nsort, W);
+    const size_t lds = osd_lds_bytes(h->n, P.nsort, W, NT * OSD_RPT);
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
     int rc = ensure(h, h->osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
@@ -299,7 +309,7 @@ int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
 
 int osd_words(int n) {
     const int need = (n + 1 + 63) / 64;
-    for (int w : {1, 2, 4, 8, 16, 32})
+    for (int w : {1, 2, 4, 8, 16, 31, 32})
         if (w >= need) return w;
     return 0;
 }
@@ -311,6 +321,7 @@ int launch_osd(bposd_handle* h, const OsdParams& P, long long B) {
         case 4: return launch_osd_t<4>(h, P, B);
         case 8: return launch_osd_t<8>(h, P, B);
         case 16: return launch_osd_t<16>(h, P, B);
+        case 31: return launch_osd_t<31>(h, P, B);
         case 32: return launch_osd_t<32>(h, P, B);
     }
     return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the register-resident OSD kernel (n=%d)", h->n);
@@ -346,7 +357,7 @@ void bposd_destroy(bposd_handle* h) {
                       &h->io_conv, &h->io_iters, &h->io_llr})
         release(*b);
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
-                    (void*)h->d_var_pos, (void*)h->d_llr0, (void*)h->d_counters,
+                    (void*)h->d_var_pos, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_counters,
                     (void*)h->d_iter_total, (void*)h->d_osd_dbg})
         if (p) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -496,19 +507,13 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(upi(&h->d_rp, h->rp));
     CREATE_TRY(upi(&h->d_ci, h->ci));
     CREATE_TRY(hipMalloc((void**)&h->d_llr0, sizeof(double) * n));
+    CREATE_TRY(hipMalloc((void**)&h->d_cost, sizeof(double) * n));
     CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(int) * 4));
     CREATE_TRY(hipMalloc((void**)&h->d_iter_total, sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counters, sizeof(int) * 4));
     CREATE_TRY(hipHostMalloc((void**)&h->h_iter_total, sizeof(unsigned long long)));
     CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, pick_shape(h)) * pick_shape(h)));
     CREATE_RC(upload_priors(h));
-    if (h->cfg.osd_method >= BPOSD_OSD_E && h->cfg.osd_order > 0 && h->cfg.weight_fn == 0 && !h->probs_uniform) {
-        fail(nullptr, BPOSD_ERR_UNSUPPORTED,
-             "OSD-W with non-uniform channel_probs needs the fp64 log-weight sweep, which is not built yet "
-             "(use weight_fn=1 / Hamming weight, osd0, or uniform probabilities)");
-        bposd_destroy(h);
-        return BPOSD_ERR_UNSUPPORTED;
-    }
     *out = h;
     return BPOSD_OK;
 #undef CREATE_TRY
@@ -522,17 +527,8 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
             return fail(h, BPOSD_ERR_INVALID, "channel_probs[%d] = %g is not a probability", i, channel_probs[i]);
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::vector<double> keep = h->probs;
     h->probs.assign(channel_probs, channel_probs + h->n);
-    int rc = upload_priors(h);
-    if (rc) return rc;
-    if (h->cfg.osd_method >= BPOSD_OSD_E && h->cfg.osd_order > 0 && h->cfg.weight_fn == 0 && !h->probs_uniform) {
-        h->probs = keep;
-        (void)upload_priors(h);
-        return fail(h, BPOSD_ERR_UNSUPPORTED,
-                    "OSD-W with non-uniform channel_probs needs the fp64 log-weight sweep, which is not built yet");
-    }
-    return BPOSD_OK;
+    return upload_priors(h);
 }
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
@@ -623,6 +619,7 @@ int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.out_osd0 = d_osd0;
         Q.out_osdw = d_osdw;
         Q.dbg = nullptr;
+        Q.cost = h->fp_weights ? h->d_cost : nullptr;
         const char* dbg_env = getenv("BPOSD_OSD_DEBUG");
         if (dbg_env && dbg_env[0] == '1') {
             if (!h->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->d_osd_dbg, 2048 * sizeof(long long)));

@@ -19,10 +19,10 @@
 //   1. a8  reliability sort: bitonic network in LDS on (order-preserving u64 image of the
 //          LLR, bit index) -- a strict total order, so the result equals a stable sort.
 //   2. a9  blocked Gauss-Jordan, panels of 64 columns (one register word):
-//          (i) panel phase, one barrier per column: every wave ballots its candidate rows
-//          and publishes (flag, panel word, combination mask) of its first candidate in
-//          its own LDS slot; after the barrier everyone reads all slots (one LDS round
-//          trip), the lowest flagged wave wins; every row with a 1 in the column XORs the
+//          (i) panel phase, one barrier per PIVOT: every wave proposes its lowest column
+//          that still has a candidate row (wave-min by ballot binary search) together with
+//          that row's panel word and combination mask; after the barrier the lowest
+//          proposal wins (skipped columns are non-pivot); every row with a 1 in the column XORs the
 //          pivot's panel word and records the pivot in its own 64-bit combination mask t
 //          (row = row_at_panel_start ^ XOR_{q in t} pivot_q_at_panel_start);
 //          (ii) trailing phase, once per panel: the <= 64 pivot rows publish their
@@ -39,8 +39,11 @@
 //          (weight, enumeration index) with OSD-0 first, i.e. "replace only if strictly
 //          lighter, first found wins".
 //
-// Integer / bitwise throughout; weights are Hamming weights, which order candidates
-// exactly like sum log(1/p) for uniform channel probabilities (host checks this).
+// Integer / bitwise throughout for uniform channel probabilities: weights are Hamming weights,
+// which order candidates exactly like sum log(1/p) then (host checks this).  With non-uniform
+// probabilities (P.cost != null) candidate weights are fp64 sums of log(1/p_i) over the set bits
+// of the candidate accumulated in ascending bit index, the reference's order, one candidate per
+// lane: bit-identical to the CPU sum, hence the same strict-< winner.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,6 +52,9 @@ namespace bposd {
 
 constexpr int OSD_RPT = 2;      // rows per thread
 constexpr int OSD_MAXW = 8;     // max waves per workgroup (512 threads)
+#ifndef OSD_CHUNK
+#define OSD_CHUNK 8
+#endif
 constexpr int OSD_MAXCV = 16;   // max ballot words per column vector (RPT * waves)
 
 struct OsdParams {
@@ -66,14 +72,22 @@ struct OsdParams {
     int* __restrict__ counters;        // [1] = number of list entries, [2] = OSD work queue
     uint8_t* __restrict__ out_osd0;    // [B, n] nullable
     uint8_t* __restrict__ out_osdw;    // [B, n]
+    const double* __restrict__ cost;   // nullable: log(1/p_i) per bit -> fp64 weights summed in bit order
+                                       // (ldpc v2 weight function with non-uniform channel_probs)
     unsigned long long* __restrict__ rows_ws;  // [gridDim.x][W][blockDim.x * RPT] finished row words
     long long* __restrict__ dbg;       // nullable: 8 phase timestamps (s_memtime) of list slot 0
 };
 
+// Diagnostics (phase timestamps + a dump of the sweep tables for list slot 0) are compiled in only with
+// -DBPOSD_OSD_DIAG: their address arithmetic otherwise costs registers in the hot loops.
+#ifdef BPOSD_OSD_DIAG
 #define OSD_STAMP(k)                                                                              \
     do {                                                                                          \
         if (P.dbg && tid == 0 && slot_id == 0) P.dbg[k] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define OSD_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned long long llr_sort_key(double x) {
     // order-preserving map double -> u64 (x + 0.0 folds -0.0 into +0.0: they compare equal)
@@ -84,7 +98,8 @@ __device__ __forceinline__ unsigned long long llr_sort_key(double x) {
 // LDS carve-up, all offsets 8-byte aligned
 struct OsdLds {
     unsigned long long* keys;     // [nsort]; after the sort: first 128 B reused as T-index -> position
-    unsigned long long* pbuf;     // [2][OSD_MAXW][4]  (flag, panel word, mask, pad) per wave
+    unsigned long long* pbuf;     // [2][OSD_MAXW][2]  (panel word, mask) of each wave's proposed pivot row
+    unsigned int* pcol;           // [2][OSD_MAXW]     proposed pivot column of each wave (64 = none)
     unsigned long long* prow;     // [64][W]   trailing words of this panel's pivots
     unsigned long long* tab;      // [16][W][16] XOR combinations of 4 pivots
     unsigned long long* colvec;   // [64][OSD_MAXCV]
@@ -99,13 +114,26 @@ struct OsdLds {
     unsigned char* xout;          // [n]
 };
 
-__host__ __device__ inline size_t osd_lds_bytes(int n, int nsort, int W) {
+__host__ __device__ inline size_t osd_align8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+// Elimination-phase buffers (prow, tab, colvec) and the fp64-weight tables of the non-uniform-channel
+// path are never live at the same time: they share one union region placed last in the carve-up.
+__host__ __device__ inline size_t osd_union_bytes(int n, int nsort, int W, int mr) {
+    const size_t elim = (size_t)64 * W * 8 + (size_t)16 * W * 16 * 8 + (size_t)64 * OSD_MAXCV * 8;
+    const size_t fpw = (size_t)mr * 8        // am: per-row entries in the first <= 64 non-pivot columns
+                     + (size_t)nsort * 8     // costs
+                     + (size_t)nsort * 8     // Mi
+                     + (size_t)64 * W * 8    // wd: single-candidate weights
+                     + (size_t)2016 * 8      // pair weights (order <= 64)
+                     + osd_align8((size_t)nsort * 2);  // info
+    return elim > fpw ? elim : fpw;
+}
+
+__host__ __device__ inline size_t osd_lds_bytes(int n, int nsort, int W, int mr) {
     size_t b = 0;
     b += (size_t)nsort * 8;                     // keys
-    b += (size_t)2 * OSD_MAXW * 4 * 8;          // pbuf
-    b += (size_t)64 * W * 8;                    // prow
-    b += (size_t)16 * W * 16 * 8;               // tab
-    b += (size_t)64 * OSD_MAXCV * 8;            // colvec
+    b += (size_t)2 * OSD_MAXW * 2 * 8;          // pbuf
+    b += osd_align8((size_t)2 * OSD_MAXW * 4);  // pcol
     b += (size_t)OSD_MAXCV * 8;                 // yvec
     b += (size_t)W * 8;                         // npmask
     b += 2 * 8;                                 // best64
@@ -113,8 +141,9 @@ __host__ __device__ inline size_t osd_lds_bytes(int n, int nsort, int W) {
     b += 8 * 4;                                 // misc
     b += (size_t)nsort * 2;                     // kidx
     b += (size_t)nsort * 2;                     // pivrow
-    b += ((size_t)n * 2 + 7) & ~(size_t)7;      // inv
-    b += ((size_t)n + 7) & ~(size_t)7;          // xout
+    b += osd_align8((size_t)n * 2);             // inv
+    b += osd_align8((size_t)n);                 // xout
+    b += osd_union_bytes(n, nsort, W, mr);      // prow | tab | colvec  /  fp64-weight tables
     return b + 64;
 }
 
@@ -134,10 +163,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
     {
         unsigned char* p = smem;
         L.keys = (unsigned long long*)p; p += (size_t)NS * 8;
-        L.pbuf = (unsigned long long*)p; p += (size_t)2 * OSD_MAXW * 4 * 8;
-        L.prow = (unsigned long long*)p; p += (size_t)64 * W * 8;
-        L.tab = (unsigned long long*)p; p += (size_t)16 * W * 16 * 8;
-        L.colvec = (unsigned long long*)p; p += (size_t)64 * OSD_MAXCV * 8;
+        L.pbuf = (unsigned long long*)p; p += (size_t)2 * OSD_MAXW * 2 * 8;
+        L.pcol = (unsigned int*)p; p += osd_align8((size_t)2 * OSD_MAXW * 4);
         L.yvec = (unsigned long long*)p; p += (size_t)OSD_MAXCV * 8;
         L.npmask = (unsigned long long*)p; p += (size_t)W * 8;
         L.best64 = (unsigned long long*)p; p += 2 * 8;
@@ -145,10 +172,14 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         L.misc = (int*)p; p += 8 * 4;
         L.kidx = (unsigned short*)p; p += (size_t)NS * 2;
         L.pivrow = (short*)p; p += (size_t)NS * 2;
-        L.inv = (unsigned short*)p; p += ((size_t)n * 2 + 7) & ~(size_t)7;
-        L.xout = p;
+        L.inv = (unsigned short*)p; p += osd_align8((size_t)n * 2);
+        L.xout = p; p += osd_align8((size_t)n);
+        // union region (last): elimination buffers ...
+        L.prow = (unsigned long long*)p;
+        L.tab = L.prow + (size_t)64 * W;
+        L.colvec = L.tab + (size_t)16 * W * 16;
     }
-
+    if (tid < 2 * OSD_MAXW) L.pcol[tid] = 64u;  // slots of waves that do not exist never propose
     for (;;) {
         if (tid == 0) L.misc[0] = atomicAdd(&P.counters[2], 1);
         __syncthreads();
@@ -234,63 +265,80 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         for (int w = 0; w < W; ++w) {
             if (done) break;
             const int nvalid = W - 1 - w;  // live trailing words: row[k][1 .. nvalid]
-            // ---------------- (i) panel phase on the current word row[k][0]
+            // ---------------- (i) panel phase on the current word row[k][0]: one barrier per PIVOT.
+            // Every wave proposes its lowest column that still has a candidate (an unused row with a 1);
+            // the lowest proposal over all waves is the next pivot column -- the columns skipped in
+            // between have no candidate anywhere, i.e. they are non-pivot.  Unused rows are zero in
+            // every column already passed, so no "columns >= b" masking is needed, only "columns < n".
             unsigned long long t[RPT];
             int myq[RPT];
 #pragma unroll
             for (int k = 0; k < RPT; ++k) { t[k] = 0ull; myq[k] = -1; }
             int npiv = 0;  // pivots found in this panel (uniform)
+            const int nb = n - w * 64;  // valid columns in this panel
+            if (nb <= 0) { done = true; break; }
+            const unsigned long long vmask = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
 #pragma clang loop unroll(disable)
-            for (int b = 0; b < 64; ++b) {
-                const int j = w * 64 + b;
-                if (j >= n || nrank >= P.rank) { done = true; break; }
-                const unsigned long long bmask = 1ull << b;
-                bool bit[RPT];
-                int ck = -1;     // first slot in which my wave has a candidate (uniform per wave)
-                int first = -1;  // its lane
+            for (;;) {
+                if (nrank >= P.rank) { done = true; break; }
+                // my lowest candidate column (64 = none) and the slot it lives in
+                int lb = 64, kb = 0;
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) {
-                    bit[k] = (row[k][0] & bmask) != 0ull;
-                    const unsigned long long bal = __ballot(bit[k] && !used[k]);
-                    if (ck < 0 && bal) { ck = k; first = __ffsll((long long)bal) - 1; }
+                    const unsigned long long cw = used[k] ? 0ull : (row[k][0] & vmask);
+                    const int l = cw ? (__ffsll((long long)cw) - 1) : 64;
+                    if (l < lb) { lb = l; kb = k; }
                 }
-                unsigned long long* mine = L.pbuf + (size_t)(par * OSD_MAXW + wave) * 4;
-                if (lane == (ck >= 0 ? first : 0)) {
+                // wave minimum of lb by a 7-step ballot binary search (values 0..64)
+                unsigned long long act = ~0ull;
+                int col = 0;
+#pragma unroll
+                for (int bitp = 6; bitp >= 0; --bitp) {
+                    const unsigned long long z = __ballot(((lb >> bitp) & 1) == 0) & act;
+                    if (z) act = z; else col |= (1 << bitp);
+                }
+                const int first = __ffsll((long long)act) - 1;  // lowest lane that attains the minimum
+                if (lane == first) {
                     unsigned long long pw = 0ull, pt = 0ull;
 #pragma unroll
                     for (int k = 0; k < RPT; ++k)
-                        if (k == ck) { pw = row[k][0]; pt = t[k]; }
-                    mine[0] = (ck >= 0) ? 1ull : 0ull;
-                    mine[1] = pw;
-                    mine[2] = pt;
+                        if (k == kb) { pw = row[k][0]; pt = t[k]; }
+                    L.pcol[par * OSD_MAXW + wave] = (unsigned int)col;
+                    L.pbuf[(size_t)(par * OSD_MAXW + wave) * 2 + 0] = pw;
+                    L.pbuf[(size_t)(par * OSD_MAXW + wave) * 2 + 1] = pt;
                 }
                 __syncthreads();
-                // everyone reads every wave's slot (one LDS round trip); lowest flagged wave wins
-                int wv = -1;
-                unsigned long long pw_p = 0ull, t_p = 0ull;
-                for (int q = nwaves - 1; q >= 0; --q) {
-                    const unsigned long long* sl = L.pbuf + (size_t)(par * OSD_MAXW + q) * 4;
-                    const unsigned long long f = sl[0], a = sl[1], c = sl[2];
-                    if (f) { wv = q; pw_p = a; t_p = c; }
-                }
-                if (wv >= 0) {
-                    const unsigned long long qbit = 1ull << npiv;
+                // all proposals (static unroll over OSD_MAXW; absent waves hold 64), lowest wave wins ties
+                int mincol = 64, wv = 0;
+                {
+                    unsigned int pc[OSD_MAXW];
 #pragma unroll
-                    for (int k = 0; k < RPT; ++k) {
-                        const bool is_pivot = (wave == wv) && (k == ck) && (lane == first);
-                        if (is_pivot) {
-                            used[k] = true;
-                            mypos[k] = j;
-                            myq[k] = npiv;
-                            L.pivrow[j] = (short)(tid + k * NT);
-                        } else if (bit[k]) {
-                            row[k][0] ^= pw_p;
-                            t[k] ^= t_p ^ qbit;
-                        }
-                    }
-                    ++npiv;
-                    ++nrank;
+                    for (int q = 0; q < OSD_MAXW; ++q) pc[q] = L.pcol[par * OSD_MAXW + q];
+#pragma unroll
+                    for (int q = OSD_MAXW - 1; q >= 0; --q)
+                        if ((int)pc[q] <= mincol) { mincol = (int)pc[q]; wv = q; }
                 }
+                if (mincol >= 64) { par ^= 1; break; }  // panel exhausted (uniform)
+                const unsigned long long pw_p = L.pbuf[(size_t)(par * OSD_MAXW + wv) * 2 + 0];
+                const unsigned long long t_p = L.pbuf[(size_t)(par * OSD_MAXW + wv) * 2 + 1];
+                const unsigned long long bmask = 1ull << mincol;
+                const unsigned long long qbit = 1ull << npiv;
+                const int j = w * 64 + mincol;
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const bool is_pivot = (wave == wv) && (lane == first) && (k == kb) && (col == mincol);
+                    if (is_pivot) {
+                        used[k] = true;
+                        mypos[k] = j;
+                        myq[k] = npiv;
+                        L.pivrow[j] = (short)(tid + k * NT);
+                    } else if (row[k][0] & bmask) {
+                        row[k][0] ^= pw_p;
+                        t[k] ^= t_p ^ qbit;
+                    }
+                }
+                ++npiv;
+                ++nrank;
                 par ^= 1;
             }
             // ---------------- (ii) trailing phase on row[k][1 .. nvalid], in chunks of 8 words
@@ -324,11 +372,14 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                         const int idx = (int)((t[k] >> (4 * g)) & 15ull);
                         const unsigned long long* tg = L.tab + (size_t)g * W * 16 + idx;
 #pragma unroll
-                        for (int x0 = 1; x0 < W; x0 += 8) {
+                        for (int x0 = 1; x0 < W; x0 += OSD_CHUNK) {
                             if (x0 <= nvalid) {  // uniform
 #pragma unroll
-                                for (int x = x0; x < x0 + 8 && x < W; ++x) row[k][x] ^= tg[x * 16];
+                                for (int x = x0; x < x0 + OSD_CHUNK && x < W; ++x) row[k][x] ^= tg[x * 16];
                             }
+                            // keep only one chunk's table loads in flight (else all 2 x 31 loads are
+                            // hoisted and the 2 x 32-word register window spills)
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
@@ -336,7 +387,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             // ---------------- word w is final: flush it and shift the register window down
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                ws[(size_t)w * MR + tid + k * NT] = row[k][0];
+                ws[(unsigned)(w * MR + tid + k * NT)] = row[k][0];
 #pragma unroll
                 for (int x = 0; x + 1 < W; ++x) row[k][x] = row[k][x + 1];
                 row[k][W - 1] = 0ull;
@@ -348,12 +399,12 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         for (int k = 0; k < RPT; ++k) {
 #pragma unroll
             for (int x = 0; x < W; ++x)
-                if (wdone + x < W) ws[(size_t)(wdone + x) * MR + tid + k * NT] = row[k][x];
+                if (wdone + x < W) ws[(unsigned)((wdone + x) * MR + tid + k * NT)] = row[k][x];
         }
         OSD_STAMP(3);
         bool y[RPT];
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) y[k] = ((ws[(size_t)(W - 1) * MR + tid + k * NT] >> 63) & 1ull) != 0ull;
+        for (int k = 0; k < RPT; ++k) y[k] = ((ws[(unsigned)((W - 1) * MR + tid + k * NT)] >> 63) & 1ull) != 0ull;
 
         // --------------------------------------------------------------- OSD-0 solution
         for (int i = tid; i < n; i += NT) L.xout[i] = 0;
@@ -387,6 +438,9 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             const int wspan = P.osd_order < 64 ? P.osd_order : 64;
             unsigned short* tpos = (unsigned short*)L.keys;  // T-index -> sorted position (first 64)
             int tcount = 0;  // running T-index (uniform)
+            unsigned long long amask[RPT];  // bit a = my row's entry in the a-th non-pivot column (a < wspan)
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) amask[k] = 0ull;
 #pragma clang loop unroll(disable)
             for (int w = 0; w < W; ++w) {
                 unsigned long long npm = L.npmask[w];
@@ -397,7 +451,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                 if (!npm) continue;  // uniform
                 unsigned long long rw[RPT];
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) rw[k] = ws[(size_t)w * MR + tid + k * NT];  // my own words
+                for (int k = 0; k < RPT; ++k) rw[k] = ws[(unsigned)(w * MR + tid + k * NT)];  // my own words
                 int acc = 0;  // lane b accumulates the weight contribution of column w*64+b
                 while (npm) {
                     const int b = __ffsll((long long)npm) - 1;
@@ -411,6 +465,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                         if (tcount < wspan) {
                             const unsigned long long cb = __ballot(used[k] && bitv);
                             if (lane == 0) L.colvec[tcount * OSD_MAXCV + k * nwaves + wave] = cb;
+                            if (bitv) amask[k] |= 1ull << tcount;
                         }
                     }
                     if (lane == b) acc += cnt;
@@ -420,13 +475,134 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                 if (P.osd_method == 3 && acc) atomicAdd(&L.wt[w * 64 + lane], acc);
             }
             __syncthreads();
+#ifdef BPOSD_OSD_DIAG
             if (P.dbg && slot_id == 0) {  // diagnostics: dump yvec, tpos, colvec behind the 8 stamps
                 for (int i = tid; i < OSD_MAXCV; i += NT) P.dbg[8 + i] = (long long)L.yvec[i];
                 for (int i = tid; i < 64; i += NT) P.dbg[8 + OSD_MAXCV + i] = (long long)tpos[i];
                 for (int i = tid; i < 64 * OSD_MAXCV; i += NT) P.dbg[8 + OSD_MAXCV + 64 + i] = (long long)L.colvec[i];
                 for (int i = tid; i < W; i += NT) P.dbg[8 + OSD_MAXCV + 64 + 64 * OSD_MAXCV + i] = (long long)L.npmask[i];
             }
-            if (P.osd_method == 3) {
+#endif
+            if (P.cost) {
+                // ================= fp64 log-weights (non-uniform channel), candidates one per lane
+                // scratch tables live in the (now idle) four-Russians table region
+                // ... reused here (colvec / prow / tab are dead once the sweep above is done)
+                unsigned long long* am = L.prow;                              // [MR] amask per row
+                double* costs = (double*)(am + MR);                           // [n]
+                unsigned long long* Mi = (unsigned long long*)(costs + NS);   // [n] per ORIGINAL bit: its entries
+                                                                              //     in the first wspan T-columns
+                double* wd = (double*)(Mi + NS);                              // [64 * W] single-candidate weights
+                double* pairw = wd + 64 * W;                                  // [<= 2016] pair weights
+                short* info = (short*)(pairw + 2016);                         // [n] pivot row of bit i, -1 if non-pivot
+                __syncthreads();  // every wave is done with colvec before it is overwritten
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) am[tid + k * NT] = amask[k];
+                for (int i = tid; i < n; i += NT) {
+                    costs[i] = P.cost[i];
+                    info[i] = L.pivrow[L.inv[i]];
+                }
+                __syncthreads();
+                for (int i = tid; i < n; i += NT) {
+                    const int pr = info[i];
+                    unsigned long long mi = 0ull;
+                    if (pr >= 0) {
+                        mi = am[pr];
+                    } else {
+                        const int pos = L.inv[i];
+                        for (int a = 0; a < wspan && a < tcount; ++a)
+                            if (tpos[a] == pos) mi = 1ull << a;
+                    }
+                    Mi[i] = mi;
+                }
+                __syncthreads();
+                // weight of OSD-0 (every lane redundantly: uniform broadcast reads)
+                double w0d = 0.0;
+                for (int i = 0; i < n; ++i)
+                    if (L.xout[i]) w0d += costs[i];
+                unsigned long long* bestw = L.best64;  // [0] singles / patterns, [1] pairs (weight bit patterns)
+                int* besti = L.misc + 2;                // [0], [1] first index attaining them
+                if (tid == 0) { besti[0] = 0x7fffffff; besti[1] = 0x7fffffff; }
+                if (P.osd_method == 3) {
+                    // ---- singles: lane c of the wave that owns word w evaluates column 64 w + c
+                    for (int w = wave; w < W; w += nwaves) {
+                        const int j = w * 64 + lane;
+                        double acc = 0.0;
+                        for (int i = 0; i < n; ++i) {
+                            const int pr = info[i];
+                            unsigned long long word;
+                            if (pr >= 0) {
+                                word = ws[(unsigned)(w * MR + pr)];
+                            } else {
+                                const int pos = L.inv[i];
+                                word = ((pos >> 6) == w) ? (1ull << (pos & 63)) : 0ull;
+                            }
+                            const int xi = (int)L.xout[i] ^ (int)((word >> lane) & 1ull);
+                            if (xi) acc += costs[i];
+                        }
+                        wd[j] = acc;
+                        if (j < n && L.pivrow[j] < 0) atomicMin(&bestw[0], (unsigned long long)__double_as_longlong(acc));
+                    }
+                    // ---- pairs (a < b < wspan)
+                    const int npairs = wspan * (wspan - 1) / 2;
+                    for (int pidx = tid; pidx < npairs; pidx += NT) {
+                        int a = 0, rem = pidx;
+                        while (rem >= wspan - 1 - a) { rem -= wspan - 1 - a; ++a; }
+                        const unsigned long long pat = (1ull << a) | (1ull << (a + 1 + rem));
+                        double acc = 0.0;
+                        for (int i = 0; i < n; ++i) {
+                            const int xi = (int)L.xout[i] ^ (__popcll(Mi[i] & pat) & 1);
+                            if (xi) acc += costs[i];
+                        }
+                        atomicMin(&bestw[1], (unsigned long long)__double_as_longlong(acc));
+                        // remember my value for pass 2 in LDS: pair weights array after the singles'
+                        pairw[pidx] = acc;
+                    }
+                    __syncthreads();
+                    // pass 2: first index attaining each minimum
+                    const unsigned long long ms = bestw[0], mp = bestw[1];
+                    for (int j = tid; j < n; j += NT)
+                        if (L.pivrow[j] < 0 && (unsigned long long)__double_as_longlong(wd[j]) == ms) atomicMin(&besti[0], j);
+                    for (int pidx = tid; pidx < npairs; pidx += NT)
+                        if ((unsigned long long)__double_as_longlong(pairw[pidx]) == mp) atomicMin(&besti[1], pidx);
+                    __syncthreads();
+                    double best = w0d;
+                    if (ms != ~0ull && __longlong_as_double((long long)ms) < best) {
+                        best = __longlong_as_double((long long)ms);
+                        sel_a = besti[0];
+                        sel_b = -1;
+                    }
+                    if (mp != ~0ull && __longlong_as_double((long long)mp) < best) {
+                        best = __longlong_as_double((long long)mp);
+                        int pidx = besti[1];
+                        int a = 0, rem = pidx;
+                        while (rem >= wspan - 1 - a) { rem -= wspan - 1 - a; ++a; }
+                        sel_a = tpos[a];
+                        sel_b = tpos[a + 1 + rem];
+                    }
+                } else {
+                    // ---- osd_e: patterns 1 .. 2^w - 1
+                    const unsigned int npat = (1u << wspan) - 1u;
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const unsigned long long target = bestw[0];
+                        for (unsigned int pat = tid + 1; pat <= npat; pat += NT) {
+                            double acc = 0.0;
+                            for (int i = 0; i < n; ++i) {
+                                const int xi = (int)L.xout[i] ^ (__popcll(Mi[i] & (unsigned long long)pat) & 1);
+                                if (xi) acc += costs[i];
+                            }
+                            const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
+                            if (pass == 0) atomicMin(&bestw[0], bits);
+                            else if (bits == target) atomicMin(&besti[0], (int)pat);
+                        }
+                        __syncthreads();
+                    }
+                    const unsigned long long ms = bestw[0];
+                    if (ms != ~0ull && __longlong_as_double((long long)ms) < w0d) {
+                        sel_a = -2;
+                        sel_b = besti[0];
+                    }
+                }
+            } else if (P.osd_method == 3) {
                 // singles: all k' non-pivot positions, enumeration order == position order
                 for (int j = tid; j < n; j += NT) {
                     if (L.pivrow[j] < 0) {
@@ -505,8 +681,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                 // one or two switched-on columns at sorted positions sel_a, sel_b
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) {
-                    xs[k] ^= ((ws[(size_t)(sel_a >> 6) * MR + tid + k * NT] >> (sel_a & 63)) & 1ull) != 0ull;
-                    if (sel_b >= 0) xs[k] ^= ((ws[(size_t)(sel_b >> 6) * MR + tid + k * NT] >> (sel_b & 63)) & 1ull) != 0ull;
+                    xs[k] ^= ((ws[(unsigned)((sel_a >> 6) * MR + tid + k * NT)] >> (sel_a & 63)) & 1ull) != 0ull;
+                    if (sel_b >= 0) xs[k] ^= ((ws[(unsigned)((sel_b >> 6) * MR + tid + k * NT)] >> (sel_b & 63)) & 1ull) != 0ull;
                 }
                 if (tid == 0) {
                     L.xout[L.kidx[sel_a]] = 1;
@@ -521,7 +697,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                     const int pos = tpos[bq];
 #pragma unroll
                     for (int k = 0; k < RPT; ++k)
-                        xs[k] ^= ((ws[(size_t)(pos >> 6) * MR + tid + k * NT] >> (pos & 63)) & 1ull) != 0ull;
+                        xs[k] ^= ((ws[(unsigned)((pos >> 6) * MR + tid + k * NT)] >> (pos & 63)) & 1ull) != 0ull;
                     if (tid == 0) L.xout[L.kidx[pos]] = 1;
                 }
             }

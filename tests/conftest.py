@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime: it must be loaded before libbposd_mi355x.so pulls in the
+    import torch  # noqa: F401  system one, or torch later reports "No HIP GPUs are available"
+except Exception:  # pragma: no cover - torch is plumbing for two tests only
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

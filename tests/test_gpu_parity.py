@@ -207,27 +207,35 @@ def test_sort_tie_policy_switch(gpu_ready, h1922):
         _compare_exact(r, ref)
 
 
-def test_nonuniform_channel_and_update(gpu_ready, hgp400):
-    """a1/a12: per-bit channel_probs and update_channel_probs (BP priors; OSD-0; Hamming-weight OSD-W)."""
+def test_nonuniform_channel_and_update(gpu_ready, hgp400, h1922):
+    """a1/a11/a12: per-bit channel_probs and update_channel_probs.  With non-uniform probabilities the
+    OSD-W weights are the ldpc-v2 sums of log(1/p_i) in bit order (fp64) -- the winner must equal the
+    oracle's for osd_cs (singles + pairs) and osd_e, as well as with the legacy Hamming weights."""
     from bp_osd_amd import BpOsdDecoder
     from oracle import OracleDecoder
 
-    H = hgp400.hx
     rng = np.random.default_rng(9)
-    p1 = rng.uniform(0.02, 0.15, size=400)
-    p2 = rng.uniform(0.02, 0.15, size=400)
-    _, syn = _syndromes(H, 0.08, 128, 4)
-    for osd, wf in ((("osd0", 0), 0), (("osd_cs", 8), 1)):
-        kw = dict(channel_probs=p1, max_iter=6, bp_method="ms", ms_scaling_factor=0.9, osd_method=osd[0],
-                  osd_order=osd[1], weight_fn=wf)
-        g, c = BpOsdDecoder(H, **kw), OracleDecoder(H, **kw)
-        _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
-        g.update_channel_probs(p2)
-        c.update_channel_probs(p2)
-        assert np.allclose(g.channel_probs, p2)
-        _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
-    with pytest.raises(ValueError, match="non-uniform"):
-        BpOsdDecoder(H, channel_probs=p1, osd_method="osd_cs", osd_order=4)
+    for H, B in ((hgp400.hx, 128), (h1922.hz, 96)):
+        n = H.shape[1]
+        p1 = rng.uniform(0.02, 0.15, size=n)
+        p2 = rng.uniform(0.02, 0.15, size=n)
+        _, syn = _syndromes(H, 0.08, B, 4)
+        for osd, wf in ((("osd0", 0), 0), (("osd_cs", 8), 1), (("osd_cs", 8), 0), (("osd_cs", 30), 0), (("osd_e", 6), 0)):
+            kw = dict(channel_probs=p1, max_iter=6, bp_method="ms", ms_scaling_factor=0.9, osd_method=osd[0],
+                      osd_order=osd[1], weight_fn=wf)
+            g, c = BpOsdDecoder(H, **kw), OracleDecoder(H, **kw)
+            _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
+            g.update_channel_probs(p2)
+            c.update_channel_probs(p2)
+            assert np.allclose(g.channel_probs, p2)
+            _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
+    # the "x->z" channel update of the reference harness produces two-valued probability vectors
+    # (css_decode_sim.py:217-227): many exact weight ties -> exercises first-found-wins
+    H = h1922.hz
+    two = np.where(rng.random(1922) < 0.1, 1.0 / 3.0, 0.0172)
+    _, syn = _syndromes(H, 0.07, 64, 8)
+    kw = dict(channel_probs=two, max_iter=5, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=10)
+    _compare_exact(_gpu_decode(BpOsdDecoder(H, **kw), syn), OracleDecoder(H, **kw).decode_batch(syn))
 
 
 def _ps_llr_mismatch_fraction(a, b):
