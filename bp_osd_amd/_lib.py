@@ -26,6 +26,8 @@ EXPORTED_SYMBOLS = (
     "bposd_update_channel_probs",
     "bposd_decode_batch",
     "bposd_decode_batch_device",
+    "bposd_decode_batch_select",
+    "bposd_decode_batch_select_device",
     "bposd_synchronize",
     "bposd_last_timing",
     "bposd_info",
@@ -74,6 +76,10 @@ def load():
     lib.bposd_decode_batch.restype = C.c_int
     lib.bposd_decode_batch_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     lib.bposd_decode_batch_device.restype = C.c_int
+    lib.bposd_decode_batch_select.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.bposd_decode_batch_select.restype = C.c_int
+    lib.bposd_decode_batch_select_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.bposd_decode_batch_select_device.restype = C.c_int
     lib.bposd_synchronize.argtypes = [vp]
     lib.bposd_synchronize.restype = C.c_int
     lib.bposd_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -28,6 +28,7 @@ __all__ = [
     "gf2_pivot_rows",
     "hgp",
     "HgpCode",
+    "CssCode",
     "h1922",
     "surface13",
     "regular_ldpc_seed",
@@ -261,6 +262,25 @@ class HgpCode:
         if ((hx.astype(np.int64) @ lz.T) % 2).any():
             return False
         return gf2_rank((lx @ lz.T) % 2) == self.K
+
+
+class CssCode:
+    """CSS code from a pair (hx, hz): the attributes the reference's ``css_code`` exposes to the harness
+    (/root/reference/src/bposd/css.py:7-95; used at css_decode_sim.py:376-380): hx, hz, lx, lz, N, K."""
+
+    def __init__(self, hx, hz):
+        self.hx = sp.csr_matrix(_dense(hx)).astype(np.uint8)
+        self.hz = sp.csr_matrix(_dense(hz)).astype(np.uint8)
+        self.hx.sort_indices()
+        self.hz.sort_indices()
+        self.N = self.hx.shape[1]
+        if self.N != self.hz.shape[1]:
+            raise ValueError("Code block length (N) inconsistent!")
+        self.K = self.N - gf2_rank(self.hx) - gf2_rank(self.hz)  # css.py:46-51
+        self.lx = HgpCode._logicals(self.hz, self.hx)  # css.py:75-95: ker(hz) modulo rowspace(hx)
+        self.lz = HgpCode._logicals(self.hx, self.hz)
+
+    test = HgpCode.test
 
 
 def hgp(h1, h2=None, compute_logicals: bool = True) -> HgpCode:

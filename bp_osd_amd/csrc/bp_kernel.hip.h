@@ -53,6 +53,8 @@ struct BpParams {
     int mp;             // padded check count = blockDim.x * CPT (stride of the LDS layout)
     const uint8_t* __restrict__ synd;   // [B, m]
     const double* __restrict__ llr0;    // [n]
+    const uint8_t* __restrict__ sel;    // [B, n] nullable: per-syndrome choice between llr0 and llr0_alt
+    const double* __restrict__ llr0_alt;  // [n] priors of the alternative channel (used where sel != 0)
     const int* __restrict__ chk_deg;    // [m]
     const int* __restrict__ var_deg;    // [n]
     const int* __restrict__ var_pos;    // [DVmax * n], entry d*n+i = k*mp + c
@@ -164,6 +166,14 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                 diffw[w0] = (unsigned int)bal;
                 diffw[w0 + 1] = (unsigned int)(bal >> 32);
                 if (bal) sh[0] = 1;
+            }
+        }
+        // ---- per-syndrome two-valued channel (css_decode_sim.py:207-248): pick this shot's priors
+        if (P.sel) {
+#pragma unroll
+            for (int r = 0; r < VPT; ++r) {
+                const int i = tid + r * NT;
+                if (i < n) l0[r] = P.sel[(size_t)s * n + i] ? P.llr0_alt[i] : P.llr0[i];
             }
         }
         // ---- a3: every edge's bit->check message starts at the prior

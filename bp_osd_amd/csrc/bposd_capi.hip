@@ -57,6 +57,8 @@ struct bposd_handle {
     int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr;
     double* d_llr0 = nullptr;
     double* d_cost = nullptr;  // log(1/p_i): OSD-W weights of the ldpc-v2 weight function
+    double *d_llr0_alt = nullptr, *d_cost_alt = nullptr;  // alternative channel of the two-valued per-shot form
+    DevBuf io_sel;
     bool fp_weights = false;   // non-uniform (or degenerate) channel: candidate weights need the fp64 sums
     int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
     // workspace (grow-only)
@@ -353,11 +355,11 @@ void bposd_destroy(bposd_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->osd_rows_ws, &h->llr_ws, &h->osd_list, &h->io_synd, &h->io_osdw, &h->io_osd0, &h->io_bp,
+    for (DevBuf* b : {&h->io_sel, &h->osd_rows_ws, &h->llr_ws, &h->osd_list, &h->io_synd, &h->io_osdw, &h->io_osd0, &h->io_bp,
                       &h->io_conv, &h->io_iters, &h->io_llr})
         release(*b);
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
-                    (void*)h->d_var_pos, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_counters,
+                    (void*)h->d_var_pos, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt, (void*)h->d_counters,
                     (void*)h->d_iter_total, (void*)h->d_osd_dbg})
         if (p) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -508,6 +510,8 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(upi(&h->d_ci, h->ci));
     CREATE_TRY(hipMalloc((void**)&h->d_llr0, sizeof(double) * n));
     CREATE_TRY(hipMalloc((void**)&h->d_cost, sizeof(double) * n));
+    CREATE_TRY(hipMalloc((void**)&h->d_llr0_alt, sizeof(double) * n));
+    CREATE_TRY(hipMalloc((void**)&h->d_cost_alt, sizeof(double) * n));
     CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(int) * 4));
     CREATE_TRY(hipMalloc((void**)&h->d_iter_total, sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counters, sizeof(int) * 4));
@@ -555,9 +559,9 @@ int bposd_synchronize(bposd_handle* h) {
     return BPOSD_OK;
 }
 
-int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B, uint8_t* d_osdw,
-                              uint8_t* d_osd0, uint8_t* d_bp, uint8_t* d_conv, int32_t* d_iters,
-                              double* d_llr) {
+static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B, const uint8_t* d_sel,
+                              uint8_t* d_osdw, uint8_t* d_osd0, uint8_t* d_bp, uint8_t* d_conv,
+                              int32_t* d_iters, double* d_llr) {
     if (!h) return BPOSD_ERR_INVALID;
     if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
     if (B == 0) return BPOSD_OK;
@@ -581,6 +585,8 @@ int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.osd_enabled = osd_on ? 1 : 0;
     P.synd = d_synd;
     P.llr0 = h->d_llr0;
+    P.sel = d_sel;
+    P.llr0_alt = h->d_llr0_alt;
     P.chk_deg = h->d_chk_deg;
     P.var_deg = h->d_var_deg;
     P.var_pos = h->d_var_pos;
@@ -619,7 +625,9 @@ int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.out_osd0 = d_osd0;
         Q.out_osdw = d_osdw;
         Q.dbg = nullptr;
-        Q.cost = h->fp_weights ? h->d_cost : nullptr;
+        Q.cost = (h->fp_weights || (d_sel && h->cfg.weight_fn == 0)) ? h->d_cost : nullptr;
+        Q.sel = d_sel;
+        Q.cost_alt = h->d_cost_alt;
         const char* dbg_env = getenv("BPOSD_OSD_DEBUG");
         if (dbg_env && dbg_env[0] == '1') {
             if (!h->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->d_osd_dbg, 2048 * sizeof(long long)));
@@ -647,8 +655,58 @@ int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     return BPOSD_OK;
 }
 
+int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B, uint8_t* d_osdw,
+                              uint8_t* d_osd0, uint8_t* d_bp, uint8_t* d_conv, int32_t* d_iters,
+                              double* d_llr) {
+    return decode_device_impl(h, d_synd, B, nullptr, d_osdw, d_osd0, d_bp, d_conv, d_iters, d_llr);
+}
+
+static int upload_alt_channel(bposd_handle* h, const double* alt) {
+    if (!alt) return fail(h, BPOSD_ERR_INVALID, "channel_probs_alt is required");
+    std::vector<double> l0(h->n), cost(h->n);
+    for (int i = 0; i < h->n; ++i) {
+        if (!(alt[i] >= 0.0 && alt[i] <= 1.0))
+            return fail(h, BPOSD_ERR_INVALID, "channel_probs_alt[%d] = %g is not a probability", i, alt[i]);
+        l0[i] = std::log((1 - alt[i]) / alt[i]);
+        cost[i] = std::log(1 / alt[i]);
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // the previous call may still read the old tables
+    HIP_TRY(h, hipMemcpy(h->d_llr0_alt, l0.data(), sizeof(double) * h->n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_cost_alt, cost.data(), sizeof(double) * h->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int bposd_decode_batch_select_device(bposd_handle* h, const uint8_t* d_synd, int64_t B, const uint8_t* d_sel,
+                                     const double* alt, uint8_t* d_osdw, uint8_t* d_osd0, uint8_t* d_bp,
+                                     uint8_t* d_conv, int32_t* d_iters, double* d_llr) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (!d_sel) return fail(h, BPOSD_ERR_INVALID, "select is required");
+    int rc = upload_alt_channel(h, alt);
+    if (rc) return rc;
+    return decode_device_impl(h, d_synd, B, d_sel, d_osdw, d_osd0, d_bp, d_conv, d_iters, d_llr);
+}
+
+static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, const uint8_t* sel, uint8_t* osdw,
+                            uint8_t* osd0, uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr);
+
 int bposd_decode_batch(bposd_handle* h, const uint8_t* synd, int64_t B, uint8_t* osdw, uint8_t* osd0,
                        uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr) {
+    return decode_host_impl(h, synd, B, nullptr, osdw, osd0, bp, conv, iters, llr);
+}
+
+int bposd_decode_batch_select(bposd_handle* h, const uint8_t* synd, int64_t B, const uint8_t* sel,
+                              const double* alt, uint8_t* osdw, uint8_t* osd0, uint8_t* bp, uint8_t* conv,
+                              int32_t* iters, double* llr) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (!sel) return fail(h, BPOSD_ERR_INVALID, "select is required");
+    int rc = upload_alt_channel(h, alt);
+    if (rc) return rc;
+    return decode_host_impl(h, synd, B, sel, osdw, osd0, bp, conv, iters, llr);
+}
+
+static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, const uint8_t* sel, uint8_t* osdw,
+                            uint8_t* osd0, uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr) {
     if (!h) return BPOSD_ERR_INVALID;
     if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
     if (B == 0) return BPOSD_OK;
@@ -664,7 +722,12 @@ int bposd_decode_batch(bposd_handle* h, const uint8_t* synd, int64_t B, uint8_t*
     if (iters && (rc = ensure(h, h->io_iters, sizeof(int) * (size_t)B))) return rc;
     if (llr && (rc = ensure(h, h->io_llr, sizeof(double) * bn))) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->io_synd.p, synd, bm, hipMemcpyHostToDevice, h->stream));
-    rc = bposd_decode_batch_device(h, (const uint8_t*)h->io_synd.p, B, (uint8_t*)h->io_osdw.p,
+    if (sel) {
+        if ((rc = ensure(h, h->io_sel, bn))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->io_sel.p, sel, bn, hipMemcpyHostToDevice, h->stream));
+    }
+    rc = decode_device_impl(h, (const uint8_t*)h->io_synd.p, B, sel ? (const uint8_t*)h->io_sel.p : nullptr,
+                                   (uint8_t*)h->io_osdw.p,
                                    osd0 ? (uint8_t*)h->io_osd0.p : nullptr, bp ? (uint8_t*)h->io_bp.p : nullptr,
                                    conv ? (uint8_t*)h->io_conv.p : nullptr, iters ? (int32_t*)h->io_iters.p : nullptr,
                                    llr ? (double*)h->io_llr.p : nullptr);

@@ -74,6 +74,8 @@ struct OsdParams {
     uint8_t* __restrict__ out_osdw;    // [B, n]
     const double* __restrict__ cost;   // nullable: log(1/p_i) per bit -> fp64 weights summed in bit order
                                        // (ldpc v2 weight function with non-uniform channel_probs)
+    const uint8_t* __restrict__ sel;   // [B, n] nullable: per-syndrome choice between cost and cost_alt
+    const double* __restrict__ cost_alt;
     unsigned long long* __restrict__ rows_ws;  // [gridDim.x][W][blockDim.x * RPT] finished row words
     long long* __restrict__ dbg;       // nullable: 8 phase timestamps (s_memtime) of list slot 0
 };
@@ -498,10 +500,23 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) am[tid + k * NT] = amask[k];
                 for (int i = tid; i < n; i += NT) {
-                    costs[i] = P.cost[i];
+                    double ci = P.cost[i];
+                    if (P.sel) {  // per-syndrome two-valued channel (css_decode_sim.py:207-248)
+                        const unsigned int pick = P.sel[(size_t)s * n + i];
+                        const double ca = P.cost_alt[i];
+                        if (pick != 0u) ci = ca;
+                    }
+                    costs[i] = ci;
                     info[i] = L.pivrow[L.inv[i]];
                 }
                 __syncthreads();
+#ifdef BPOSD_OSD_DIAG
+                if (P.dbg && slot_id == 0) {  // diagnostics: the per-bit costs this syndrome is weighed with
+                    for (int i = tid; i < 512 && i < n; i += NT) P.dbg[1200 + i] = __double_as_longlong(costs[i]);
+                    if (tid == 0) { P.dbg[1199] = s; P.dbg[1198] = (long long)(P.sel != nullptr); }
+                    for (int i = tid; i < 64; i += NT) { P.dbg[1800 + i] = P.sel ? (long long)P.sel[(size_t)s * n + i] : -1; P.dbg[1870 + i] = __double_as_longlong(P.cost[i]); P.dbg[1940 + i] = __double_as_longlong(P.cost_alt[i]); }
+                }
+#endif
                 for (int i = tid; i < n; i += NT) {
                     const int pr = info[i];
                     unsigned long long mi = 0ull;

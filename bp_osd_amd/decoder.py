@@ -162,10 +162,16 @@ class BpOsdDecoder:
             self._h = None
 
     # ------------------------------------------------------------------ decode
-    def decode_batch(self, syndromes, want_osd0=True, want_bp=True, want_llr=False):
+    def decode_batch(self, syndromes, want_osd0=True, want_bp=True, want_llr=False, prior_select=None,
+                     alt_channel_probs=None):
         """Decode B syndromes (array [B, m], any integer dtype).  Returns the OSD-W (or BP, when BP
         converged) corrections as uint8 [B, n]; per-row ``batch_converge``, ``batch_iter`` and, if
-        requested, ``batch_osd0`` / ``batch_bp`` / ``batch_llr`` are left on the object."""
+        requested, ``batch_osd0`` / ``batch_bp`` / ``batch_llr`` are left on the object.
+
+        ``prior_select`` (uint8 [B, n]) with ``alt_channel_probs`` (n floats) gives every shot its own
+        two-valued channel: bit i of shot b uses ``alt_channel_probs[i]`` where ``prior_select[b, i]`` is
+        set and the decoder's ``channel_probs[i]`` elsewhere -- the batched form of the per-shot
+        ``update_channel_probs`` of css_decode_sim.py:207-248."""
         s = np.asarray(syndromes)
         if s.ndim != 2 or s.shape[1] != self.m:
             raise ValueError(f"The syndromes must have shape (B, {self.m}). Not {s.shape}.")
@@ -179,8 +185,23 @@ class BpOsdDecoder:
         iters = np.empty(B, np.int32)
         llr = np.empty((B, self.n), np.float64) if want_llr else None
         ptr = lambda a: a.ctypes.data if a is not None else None
-        rc = self._lib.bposd_decode_batch(self._h, s8.ctypes.data, B, ptr(osdw), ptr(osd0), ptr(bp),
-                                          ptr(conv), ptr(iters), ptr(llr))
+        if prior_select is not None:
+            sel = np.ascontiguousarray(np.asarray(prior_select) != 0, dtype=np.uint8)
+            if sel.shape != (B, self.n):
+                raise ValueError(f"prior_select must have shape ({B}, {self.n}), not {sel.shape}")
+            if alt_channel_probs is None:
+                raise ValueError("alt_channel_probs is required with prior_select")
+            alt = np.ascontiguousarray(alt_channel_probs, dtype=np.float64)
+            if alt.shape != (self.n,):
+                raise ValueError(f"alt_channel_probs must have length {self.n}")
+            if B == 0:
+                rc = 0
+            else:
+                rc = self._lib.bposd_decode_batch_select(self._h, s8.ctypes.data, B, sel.ctypes.data, alt.ctypes.data,
+                                                         ptr(osdw), ptr(osd0), ptr(bp), ptr(conv), ptr(iters), ptr(llr))
+        else:
+            rc = self._lib.bposd_decode_batch(self._h, s8.ctypes.data, B, ptr(osdw), ptr(osd0), ptr(bp),
+                                              ptr(conv), ptr(iters), ptr(llr))
         _lib.check(self._lib, self._h, rc)
         self.batch_converge = conv.astype(bool)
         self.batch_iter = iters

@@ -101,6 +101,27 @@ int bposd_decode_batch_device(bposd_handle *h, const uint8_t *d_syndromes, int64
                               uint8_t *d_osdw, uint8_t *d_osd0, uint8_t *d_bp,
                               uint8_t *d_converged, int32_t *d_iters, double *d_llr);
 
+/*
+ * Per-syndrome channel, two values per bit: bit i of syndrome b is decoded with probability
+ * channel_probs_alt[i] where select[b*n + i] != 0 and with the handle's channel_probs[i] elsewhere
+ * (BP priors and OSD-W weights alike).  This is exactly what the reference's per-shot Bayesian channel
+ * update produces -- /root/reference/src/bposd/css_decode_sim.py:207-248 sets, per shot,
+ * p_i = py/(px+py) where the first decoder flipped bit i and pz/(1-px-py) elsewhere, then calls
+ * `.update_channel_probs(p)` before the second `.decode` -- batched over B shots.
+ * Host-pointer form, synchronous; `select` and `channel_probs_alt` are required here.
+ */
+int bposd_decode_batch_select(bposd_handle *h, const uint8_t *syndromes, int64_t B,
+                              const uint8_t *select, const double *channel_probs_alt, uint8_t *osdw,
+                              uint8_t *osd0, uint8_t *bp, uint8_t *converged, int32_t *iters,
+                              double *llr);
+
+/* Device-pointer form of the above (d_select on the device; channel_probs_alt stays a HOST array of n
+ * doubles, it is uploaded by the call).  Asynchronous like bposd_decode_batch_device. */
+int bposd_decode_batch_select_device(bposd_handle *h, const uint8_t *d_syndromes, int64_t B,
+                                     const uint8_t *d_select, const double *channel_probs_alt,
+                                     uint8_t *d_osdw, uint8_t *d_osd0, uint8_t *d_bp,
+                                     uint8_t *d_converged, int32_t *d_iters, double *d_llr);
+
 /* Wait for all work queued on the handle's stream. */
 int bposd_synchronize(bposd_handle *h);
 

@@ -366,3 +366,50 @@ def test_device_pointer_api_with_torch(gpu_ready, h1922):
     dec.synchronize()
     assert (d_out.cpu().numpy() == host).all()
     assert (d_it.cpu().numpy() == dec.batch_iter).all()
+
+
+def test_prior_select_two_valued_channel_vs_oracle(gpu_ready, h1922, hgp400):
+    """f3: per-syndrome two-valued channel (decode_batch(prior_select=..., alt_channel_probs=...)) equals the
+    reference semantics of update_channel_probs-then-decode, shot by shot (css_decode_sim.py:207-248)."""
+    from bp_osd_amd import BpOsdDecoder
+    from tests.sim_util import OracleAdapter
+
+    rng = np.random.default_rng(12)
+    for H, B, q in ((h1922.hz, 48, 0.06), (hgp400.hx, 96, 0.07)):
+        n = H.shape[1]
+        base = np.full(n, 2 * q / 3)
+        alt = np.full(n, 0.5)
+        _, syn = _syndromes(H, q, B, 21)
+        sel = (rng.random((B, n)) < 0.08).astype(np.uint8)
+        for osd in (("osd_cs", 7), ("osd0", 0), ("osd_e", 5)):
+            kw = dict(channel_probs=base, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method=osd[0],
+                      osd_order=osd[1])
+            g = BpOsdDecoder(H, **kw)
+            c = OracleAdapter(H, **kw)
+            got = g.decode_batch(syn, prior_select=sel, alt_channel_probs=alt)
+            ref = c.decode_batch(syn, prior_select=sel, alt_channel_probs=alt)
+            assert (g.batch_converge == c.batch_converge).all() and (g.batch_iter == c.batch_iter).all()
+            assert (g.batch_bp == c.batch_bp).all() and (g.batch_osd0 == c.batch_osd0).all()
+            assert (got == ref).all()
+            # and the handle's own channel is untouched afterwards
+            again = g.decode_batch(syn)
+            assert (again == c.decode_batch(syn)).all()
+    with pytest.raises(ValueError):
+        g.decode_batch(syn, prior_select=sel[:, :-1], alt_channel_probs=alt)
+
+
+@pytest.mark.parametrize("channel_update", [None, "x->z"])
+def test_harness_on_gpu_equals_harness_on_oracle(gpu_ready, hgp400, channel_update):
+    """f1: the batched css_decode_sim with MI355X decoders produces the same counters as with the CPU
+    oracle (same seed, same RNG stream) -- LER agreement is exact, not statistical."""
+    from bp_osd_amd.sim import css_decode_sim
+    from tests.sim_util import OracleAdapter
+
+    opts = dict(error_rate=0.09, xyz_error_bias=[1, 1, 1], target_runs=400, seed=5, channel_update=channel_update,
+                bp_method="ms", ms_scaling_factor=0, max_iter=0, osd_method="osd_cs", osd_order=6, tqdm_disable=1)
+    gpu = css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, batch_size=256, **opts)
+    cpu = css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, batch_size=128, decoder_factory=OracleAdapter, **opts)
+    for k in ("run_count", "osdw_success_count", "osd0_success_count", "bp_success_count", "bp_converge_count_x",
+              "bp_converge_count_z", "min_logical_weight", "osdw_logical_error_rate", "osdw_word_error_rate"):
+        assert getattr(gpu, k) == getattr(cpu, k), (k, getattr(gpu, k), getattr(cpu, k))
+    assert gpu.osdw_success_count <= 400 and gpu.K == 16 and gpu.N == 400
