@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "bposd_decode_batch_device",
     "bposd_decode_batch_select",
     "bposd_decode_batch_select_device",
+    "bposd_pack_rows_device",
     "bposd_synchronize",
     "bposd_last_timing",
     "bposd_info",
@@ -80,6 +81,8 @@ def load():
     lib.bposd_decode_batch_select.restype = C.c_int
     lib.bposd_decode_batch_select_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.bposd_decode_batch_select_device.restype = C.c_int
+    lib.bposd_pack_rows_device.argtypes = [vp, vp, C.c_int64, C.c_int32, vp]
+    lib.bposd_pack_rows_device.restype = C.c_int
     lib.bposd_synchronize.argtypes = [vp]
     lib.bposd_synchronize.restype = C.c_int
     lib.bposd_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -338,6 +338,22 @@ int num_candidates(const bposd_handle* h) {
 
 }  // namespace
 
+__global__ void pack_rows_kernel(const uint8_t* __restrict__ in, long long B, int n, int wpr,
+                                 unsigned long long* __restrict__ out) {
+    // one wave per 64-bit output word: lane l supplies bit l (ballot); grid-stride over words
+    const long long nwords = B * wpr;
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwave = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long w = wave0; w < nwords; w += nwave) {
+        const long long b = w / wpr;
+        const int i = (int)(w - b * wpr) * 64 + lane;
+        const bool bit = (i < n) && (in[b * n + i] & 1);
+        const unsigned long long v = __ballot(bit);
+        if (lane == 0) out[w] = v;
+    }
+}
+
 // ================================================================================ C-ABI
 extern "C" {
 
@@ -549,6 +565,22 @@ int bposd_info(bposd_handle* h, int32_t* rank, int32_t* ncand, int32_t* max_iter
     if (ncand) *ncand = h->ncand;
     if (max_iter) *max_iter = h->max_iter;
     if (nnz) *nnz = h->E;
+    return BPOSD_OK;
+}
+
+int bposd_pack_rows_device(bposd_handle* h, const uint8_t* d_bytes, int64_t B, int32_t n, uint64_t* d_words) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (B < 0 || n <= 0 || (B > 0 && (!d_bytes || !d_words))) return fail(h, BPOSD_ERR_INVALID, "bad pack arguments");
+    if (B == 0) return BPOSD_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int wpr = (n + 63) / 64;
+    const long long nwords = (long long)B * wpr;
+    const int threads = 256;
+    const long long want = (nwords * 64 + threads - 1) / threads;
+    const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 16);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(threads), 0, h->stream, d_bytes, (long long)B, (int)n, wpr,
+                       (unsigned long long*)d_words);
+    HIP_TRY(h, hipGetLastError());
     return BPOSD_OK;
 }
 

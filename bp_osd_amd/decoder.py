@@ -232,6 +232,10 @@ class BpOsdDecoder:
                                                  d_converged, d_iters, d_llr)
         _lib.check(self._lib, self._h, rc)
 
+    def pack_rows_device(self, d_bytes, B, n, d_words):
+        """Bit-pack B device rows of n 0/1 bytes into ceil(n/64) uint64 words each (asynchronous)."""
+        _lib.check(self._lib, self._h, self._lib.bposd_pack_rows_device(self._h, d_bytes, int(B), int(n), d_words))
+
     def synchronize(self):
         _lib.check(self._lib, self._h, self._lib.bposd_synchronize(self._h))
 

@@ -122,6 +122,14 @@ int bposd_decode_batch_select_device(bposd_handle *h, const uint8_t *d_syndromes
                                      uint8_t *d_osdw, uint8_t *d_osd0, uint8_t *d_bp,
                                      uint8_t *d_converged, int32_t *d_iters, double *d_llr);
 
+/*
+ * Bit-pack B rows of n 0/1 bytes (device) into B rows of ceil(n/64) little-endian 64-bit words (device):
+ * bit (i & 63) of word (i >> 6) of row b = d_bytes[b*n + i] & 1.  Used to shrink the one exchange step of
+ * the multi-GPU path (the gather of corrections) 8x.  Asynchronous on the handle's stream.
+ */
+int bposd_pack_rows_device(bposd_handle *h, const uint8_t *d_bytes, int64_t B, int32_t n,
+                           uint64_t *d_words);
+
 /* Wait for all work queued on the handle's stream. */
 int bposd_synchronize(bposd_handle *h);
 

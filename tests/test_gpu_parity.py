@@ -413,3 +413,23 @@ def test_harness_on_gpu_equals_harness_on_oracle(gpu_ready, hgp400, channel_upda
               "bp_converge_count_z", "min_logical_weight", "osdw_logical_error_rate", "osdw_word_error_rate"):
         assert getattr(gpu, k) == getattr(cpu, k), (k, getattr(gpu, k), getattr(cpu, k))
     assert gpu.osdw_success_count <= 400 and gpu.K == 16 and gpu.N == 400
+
+
+def test_pack_rows_device(gpu_ready, h1922):
+    """Bit-packing kernel used before the multi-GPU gather: bit (i & 63) of word (i >> 6) = byte i."""
+    import torch
+    from bp_osd_amd import BpOsdDecoder
+
+    dec = BpOsdDecoder(h1922.hz, error_rate=0.05, bp_method="ms", osd_method="osd0")
+    rng = np.random.default_rng(3)
+    for B, n in ((257, 1922), (3, 64), (5, 1)):
+        x = (rng.random((B, n)) < 0.3).astype(np.uint8)
+        d_x = torch.from_numpy(x).cuda()
+        wpr = (n + 63) // 64
+        d_w = torch.zeros((B, wpr), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        dec.pack_rows_device(d_x.data_ptr(), B, n, d_w.data_ptr())
+        dec.synchronize()
+        w = d_w.cpu().numpy().view(np.uint64)
+        back = np.unpackbits(w.view(np.uint8).reshape(B, -1), axis=1, bitorder="little")[:, :n]
+        assert (back == x).all()
