@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "bposd_synchronize",
     "bposd_last_timing",
     "bposd_info",
+    "bposd_layout_info",
     "bposd_set_bp_variant",
     "bposd_last_error",
     "bposd_destroy",
@@ -91,6 +92,8 @@ def load():
     lib.bposd_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                C.POINTER(C.c_int32)]
     lib.bposd_info.restype = C.c_int
+    lib.bposd_layout_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.bposd_layout_info.restype = C.c_int
     lib.bposd_set_bp_variant.argtypes = [vp, C.c_int32]
     lib.bposd_set_bp_variant.restype = C.c_int
     lib.bposd_last_error.argtypes = [vp]

@@ -56,8 +56,11 @@ struct BpParams {
     const uint8_t* __restrict__ sel;    // [B, n] nullable: per-syndrome choice between llr0 and llr0_alt
     const double* __restrict__ llr0_alt;  // [n] priors of the alternative channel (used where sel != 0)
     const int* __restrict__ chk_deg;    // [m]
-    const int* __restrict__ var_deg;    // [n]
-    const int* __restrict__ var_pos;    // [DVmax * n], entry d*n+i = k*mp + c
+    int np;             // bit positions = blockDim.x * VPT; position p is owned by thread p % blockDim.x
+    const int* __restrict__ pos_bit;    // [np] bit handled at position p, -1 = padding.  The order is chosen by
+                                        // the host so that the bit pass's LDS gathers are bank-conflict free
+    const int* __restrict__ var_deg;    // [np]
+    const int* __restrict__ var_pos;    // [DVmax * np], entry d*np+p = k*mp + c
     uint8_t* __restrict__ out_bp;       // [B, n] nullable
     uint8_t* __restrict__ out_osd0;     // [B, n] nullable
     uint8_t* __restrict__ out_osdw;     // [B, n]
@@ -127,14 +130,16 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
     int vaddr[VPT][DV], vdeg[VPT];
     bool vvalid[VPT];
     double l0[VPT];
+    const int NP = P.np;
 #pragma unroll
     for (int r = 0; r < VPT; ++r) {
-        const int i = tid + r * NT;
-        vvalid[r] = i < n;
-        vdeg[r] = vvalid[r] ? (REG ? DV : P.var_deg[i]) : 0;
-        l0[r] = vvalid[r] ? P.llr0[i] : 1.0;
+        const int p = tid + r * NT;
+        const int bit = P.pos_bit[p];
+        vvalid[r] = bit >= 0;
+        vdeg[r] = vvalid[r] ? (REG ? DV : P.var_deg[p]) : 0;
+        l0[r] = vvalid[r] ? P.llr0[bit] : 1.0;
 #pragma unroll
-        for (int d = 0; d < DV; ++d) vaddr[r][d] = (d < vdeg[r]) ? P.var_pos[(size_t)d * n + i] : dummy;
+        for (int d = 0; d < DV; ++d) vaddr[r][d] = (d < vdeg[r]) ? P.var_pos[(size_t)d * NP + p] : dummy;
     }
     int cdeg[CPT];
 #pragma unroll
@@ -172,8 +177,8 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
         if (P.sel) {
 #pragma unroll
             for (int r = 0; r < VPT; ++r) {
-                const int i = tid + r * NT;
-                if (i < n) l0[r] = P.sel[(size_t)s * n + i] ? P.llr0_alt[i] : P.llr0[i];
+                const int i = P.pos_bit[tid + r * NT];
+                if (i >= 0) l0[r] = P.sel[(size_t)s * n + i] ? P.llr0_alt[i] : P.llr0[i];
             }
         }
         // ---- a3: every edge's bit->check message starts at the prior
@@ -343,8 +348,8 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
         const int slot = to_osd ? sh[3] : 0;
 #pragma unroll
         for (int r = 0; r < VPT; ++r) {
-            const int i = tid + r * NT;
-            if (i < n) {
+            const int i = P.pos_bit[tid + r * NT];  // reloaded here (not kept in registers across the BP loop)
+            if (i >= 0) {
                 const size_t o = (size_t)s * n + i;
                 const uint8_t b = (uint8_t)dec[r];
                 if (P.out_bp) P.out_bp[o] = b;

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,7 +55,9 @@ struct bposd_handle {
     std::vector<double> probs;
     // device tables
     int *d_rp = nullptr, *d_ci = nullptr;
-    int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr;
+    int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr, *d_pos_bit = nullptr;
+    int tab_np = 0;
+    long layout_cost = 0, layout_cost_natural = 0, layout_cost_ideal = 0;  // simulated LDS cycles of the bit pass
     double* d_llr0 = nullptr;
     double* d_cost = nullptr;  // log(1/p_i): OSD-W weights of the ldpc-v2 weight function
     double *d_llr0_alt = nullptr, *d_cost_alt = nullptr;  // alternative channel of the two-valued per-shot form
@@ -168,18 +171,150 @@ int upload_priors(bposd_handle* h) {
     return 0;
 }
 
-int build_tables(bposd_handle* h, int DC, int DV, int MP) {
+// ---------------------------------------------------------------------------------------------
+// Bit-pass layout.  The check pass is bank-conflict free by construction (lane c <-> slot k*MP + c).
+// The bit pass gathers/scatters slot (k*MP + c) for the d-th edge of each of 64 lanes; its conflicts
+// depend only on which bits share a 32-lane (ds_read_b64: 64 banks) / 16-lane (ds_write_b64: 32 banks)
+// group.  The order of bits over lanes is free (tables are position-indexed), so the host simulates
+// the LDS cycles (MI355X_MICROARCH.md §LDS banking model) of a family of orders -- natural, and
+// two-block orders where each block of (outer x inner) bits is laid out inner-major or outer-major with
+// groups padded to a multiple of 32 lanes (the shapes hypergraph-product codes have) -- and keeps the
+// cheapest.  For H1922 (31x31 | 31x31) the outer-major order of the first block is conflict free.
+struct EdgeSlot { int slot; };
+
+static long bit_pass_cycles(const std::vector<int>& bit_of_pos, int NP, int NT, int VPT, int dv_max,
+                            const std::vector<int>& cptr, const std::vector<int>& eslot, long stop_at) {
+    long total = 0;
+    int cnt[64];
+    int first[64];
+    for (int r = 0; r < VPT; ++r) {
+        for (int w0 = 0; w0 < NT; w0 += 64) {
+            for (int d = 0; d < dv_max; ++d) {
+                int slots[64];
+                bool any = false;
+                for (int l = 0; l < 64; ++l) {
+                    const int p = r * NT + w0 + l;
+                    const int i = p < NP ? bit_of_pos[p] : -1;
+                    slots[l] = (i >= 0 && cptr[i] + d < cptr[i + 1]) ? eslot[cptr[i] + d] : -1;
+                    any |= slots[l] >= 0;
+                }
+                if (!any) continue;
+                // reads: two 32-lane groups, an 8-byte access covers banks 2*slot, 2*slot+1 of 64
+                for (int g = 0; g < 64; g += 32) {
+                    int worst = 0;
+                    for (int b = 0; b < 32; ++b) { cnt[b] = 0; first[b] = -1; }
+                    for (int l = g; l < g + 32; ++l) {
+                        if (slots[l] < 0) continue;
+                        const int b = slots[l] & 31;
+                        // distinct addresses on the same bank serialise (identical ones broadcast; cannot
+                        // happen here: every edge has its own slot)
+                        ++cnt[b];
+                        worst = std::max(worst, cnt[b]);
+                    }
+                    total += std::max(worst, 1);
+                }
+                // writes: four 16-lane groups, 32 banks -> 16 slot classes
+                for (int g = 0; g < 64; g += 16) {
+                    int worst = 0;
+                    for (int b = 0; b < 16; ++b) cnt[b] = 0;
+                    for (int l = g; l < g + 16; ++l) {
+                        if (slots[l] < 0) continue;
+                        const int b = slots[l] & 15;
+                        ++cnt[b];
+                        worst = std::max(worst, cnt[b]);
+                    }
+                    total += std::max(worst, 1);
+                }
+                if (total >= stop_at) return total;
+            }
+        }
+    }
+    return total;
+}
+
+static int round32(int x) { return (x + 31) / 32 * 32; }
+
+// positions of a block of `count` bits starting at bit `b0`, viewed as outer x inner with the given inner
+// size, laid out inner-major (transposed = false) or outer-major (transposed = true), groups padded to 32
+static int place_block(std::vector<int>& bit_of_pos, int p0, int b0, int count, int inner, bool transposed, int NP) {
+    if (count == 0) return p0;
+    if (inner <= 0 || count % inner != 0) return -1;
+    const int outer = count / inner;
+    const int gsz = transposed ? round32(outer) : round32(inner);
+    const int ngr = transposed ? inner : outer;
+    if ((long)p0 + (long)gsz * ngr > NP) return -1;
+    for (int a = 0; a < outer; ++a)
+        for (int b = 0; b < inner; ++b) {
+            const int p = transposed ? p0 + b * gsz + a : p0 + a * gsz + b;
+            bit_of_pos[p] = b0 + a * inner + b;
+        }
+    return p0 + gsz * ngr;
+}
+
+static void choose_bit_layout(bposd_handle* h, int MP, int NT, int VPT, std::vector<int>& best_bit_of_pos) {
+    const int n = h->n, NP = NT * VPT;
+    // CSC view with the LDS slot of every edge
+    std::vector<int> cptr(n + 1, 0), fill(n, 0);
+    for (int e = 0; e < h->E; ++e) cptr[h->ci[e] + 1]++;
+    for (int i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
+    std::vector<int> eslot(h->E);
+    for (int c = 0; c < h->m; ++c)
+        for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
+            const int i = h->ci[e];
+            eslot[cptr[i] + fill[i]++] = (e - h->rp[c]) * MP + c;  // ascending row within a column
+        }
+    std::vector<int> cand(NP, -1);
+    for (int i = 0; i < n; ++i) cand[i] = i;
+    long best = bit_pass_cycles(cand, NP, NT, VPT, h->dv_max, cptr, eslot, LONG_MAX);
+    best_bit_of_pos = cand;
+    h->layout_cost_natural = best;
+    // ideal: every instruction that touches a real bit costs 2 read + 4 write group-cycles
+    long ninstr = 0;
+    for (int r = 0; r < VPT; ++r)
+        for (int w0 = 0; w0 < NT; w0 += 64)
+            if (r * NT + w0 < n) ninstr += h->dv_max;
+    h->layout_cost_ideal = ninstr * 6;
+    if (best <= h->layout_cost_ideal + h->layout_cost_ideal / 20) { h->layout_cost = best; return; }
+    // two-block family: bits [0, s) as (s/p1 x p1), bits [s, n) as ((n-s)/p2 x p2)
+    for (int p1 = 2; p1 <= 64; ++p1) {
+        for (int o1 = 0; o1 <= 64 && o1 * p1 <= n; ++o1) {
+            const int s0 = o1 * p1;
+            const int rest = n - s0;
+            for (int p2 = 2; p2 <= 64; ++p2) {
+                if (rest % p2 != 0 || rest / p2 > 64) continue;
+                if (s0 == 0 && p1 != 2) continue;  // a single block: p1 is irrelevant, visit once
+                for (int t = 0; t < 4; ++t) {
+                    std::fill(cand.begin(), cand.end(), -1);
+                    int q = place_block(cand, 0, 0, s0, p1, (t & 1) != 0, NP);
+                    if (q < 0) continue;
+                    q = place_block(cand, q, s0, rest, p2, (t & 2) != 0, NP);
+                    if (q < 0) continue;
+                    const long c = bit_pass_cycles(cand, NP, NT, VPT, h->dv_max, cptr, eslot, best);
+                    if (c < best) { best = c; best_bit_of_pos = cand; }
+                }
+            }
+        }
+    }
+    h->layout_cost = best;
+}
+
+int build_tables(bposd_handle* h, int DC, int DV, int MP, int NT, int VPT) {
     // LDS slot of the k-th edge of check c is k * MP + c (MP = checks padded to threads x CPT)
-    const int m = h->m, n = h->n;
-    std::vector<int> chk_deg(m), var_deg(n, 0);
-    std::vector<int> var_pos((size_t)DV * n, 0);
+    const int m = h->m, n = h->n, NP = NT * VPT;
+    std::vector<int> bit_of_pos;
+    choose_bit_layout(h, MP, NT, VPT, bit_of_pos);
+    std::vector<int> pos_of_bit(n, -1);
+    for (int p = 0; p < NP; ++p)
+        if (bit_of_pos[p] >= 0) pos_of_bit[bit_of_pos[p]] = p;
+    std::vector<int> chk_deg(m), var_deg(NP, 0);
+    std::vector<int> var_pos((size_t)DV * NP, 0);
     for (int c = 0; c < m; ++c) {
         chk_deg[c] = h->rp[c + 1] - h->rp[c];
         for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
             const int k = e - h->rp[c];
-            const int i = h->ci[e];
-            const int d = var_deg[i]++;  // rows visited ascending => ascending row within a column
-            var_pos[(size_t)d * n + i] = k * MP + c;
+            const int p = pos_of_bit[h->ci[e]];
+            const int d = var_deg[p]++;  // rows visited ascending => ascending row within a column
+            var_pos[(size_t)d * NP + p] = k * MP + c;
         }
     }
     auto up = [&](int** dst, const std::vector<int>& v) -> int {
@@ -192,9 +327,11 @@ int build_tables(bposd_handle* h, int DC, int DV, int MP) {
     if ((rc = up(&h->d_chk_deg, chk_deg))) return rc;
     if ((rc = up(&h->d_var_deg, var_deg))) return rc;
     if ((rc = up(&h->d_var_pos, var_pos))) return rc;
+    if ((rc = up(&h->d_pos_bit, bit_of_pos))) return rc;
     h->tab_dc = DC;
     h->tab_dv = DV;
     h->tab_mp = MP;
+    h->tab_np = NP;
     return 0;
 }
 
@@ -255,7 +392,10 @@ int launch_bp_shape(bposd_handle* h, const BpParams& P, int shape, int NT) {
     // occupancy targets: LDS admits 3 workgroups per CU for H1922 (46 KB each); the regular
     // (6,3) kernels are register-capped for that (2 x 1024, 3 x 512 or 3 x 256 threads per CU)
     if (shape == 1) return launch_bp_t<DC, DV, 1, 2, 1024, (REG ? 8 : 4), REG, (REG ? 1024 : 0)>(h, P, NT);
-    if (shape == 2) return launch_bp_t<DC, DV, 2, 4, 512, (REG ? 6 : 2), REG, (REG ? 1024 : 0)>(h, P, NT);
+#ifndef BPOSD_SHAPE2_MINW
+#define BPOSD_SHAPE2_MINW 6
+#endif
+    if (shape == 2) return launch_bp_t<DC, DV, 2, 4, 512, (REG ? BPOSD_SHAPE2_MINW : 2), REG, (REG ? 1024 : 0)>(h, P, NT);
     if constexpr (REG) {
         if (shape == 4) return launch_bp_t<DC, DV, 4, 8, 256, 3, REG, 1024>(h, P, NT);
     }
@@ -267,15 +407,18 @@ int launch_bp(bposd_handle* h, BpParams& P) {
     if (!shape) return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the LDS-resident BP kernel (m=%d n=%d)", h->m, h->n);
     const int NT = shape_threads(h, shape);
     const int MP = NT * shape;
-    if (MP != h->tab_mp) {
+    const int NPOS = NT * 2 * shape;
+    if (MP != h->tab_mp || NPOS != h->tab_np) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        int rc = build_tables(h, h->tab_dc, h->tab_dv, MP);
+        int rc = build_tables(h, h->tab_dc, h->tab_dv, MP, NT, 2 * shape);
         if (rc) return rc;
         P.chk_deg = h->d_chk_deg;
         P.var_deg = h->d_var_deg;
         P.var_pos = h->d_var_pos;
+        P.pos_bit = h->d_pos_bit;
     }
     P.mp = MP;
+    P.np = NPOS;
     if (bp_lds_bytes(h->tab_dc, MP) > h->lds_per_cu)
         return fail(h, BPOSD_ERR_UNSUPPORTED, "BP messages (%zu B) exceed one CU's LDS", bp_lds_bytes(h->tab_dc, MP));
     if (is_reg63(h) && MP == 1024) return launch_bp_shape<6, 3, true>(h, P, shape, NT);
@@ -375,7 +518,7 @@ void bposd_destroy(bposd_handle* h) {
                       &h->io_conv, &h->io_iters, &h->io_llr})
         release(*b);
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
-                    (void*)h->d_var_pos, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt, (void*)h->d_counters,
+                    (void*)h->d_var_pos, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt, (void*)h->d_counters,
                     (void*)h->d_iter_total, (void*)h->d_osd_dbg})
         if (p) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -532,7 +675,8 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(hipMalloc((void**)&h->d_iter_total, sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counters, sizeof(int) * 4));
     CREATE_TRY(hipHostMalloc((void**)&h->h_iter_total, sizeof(unsigned long long)));
-    CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, pick_shape(h)) * pick_shape(h)));
+    CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, pick_shape(h)) * pick_shape(h),
+                           shape_threads(h, pick_shape(h)), 2 * pick_shape(h)));
     CREATE_RC(upload_priors(h));
     *out = h;
     return BPOSD_OK;
@@ -584,6 +728,14 @@ int bposd_pack_rows_device(bposd_handle* h, const uint8_t* d_bytes, int64_t B, i
     return BPOSD_OK;
 }
 
+int bposd_layout_info(bposd_handle* h, int64_t* natural, int64_t* chosen, int64_t* ideal) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (natural) *natural = h->layout_cost_natural;
+    if (chosen) *chosen = h->layout_cost;
+    if (ideal) *ideal = h->layout_cost_ideal;
+    return BPOSD_OK;
+}
+
 int bposd_synchronize(bposd_handle* h) {
     if (!h) return BPOSD_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -622,6 +774,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.chk_deg = h->d_chk_deg;
     P.var_deg = h->d_var_deg;
     P.var_pos = h->d_var_pos;
+    P.pos_bit = h->d_pos_bit;
     P.out_bp = d_bp;
     P.out_osd0 = d_osd0;
     P.out_osdw = d_osdw;

@@ -247,6 +247,12 @@ class BpOsdDecoder:
         _lib.check(self._lib, self._h, rc)
         return {"bp_ms": a.value, "osd_ms": b.value, "bp_iterations": it.value, "osd_invocations": no.value}
 
+    def layout_info(self):
+        """dict(natural, chosen, ideal): simulated LDS cycles of one bit pass for the bit orders considered."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(self._lib, self._h, self._lib.bposd_layout_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"natural": a.value, "chosen": b.value, "ideal": c.value}
+
     def set_bp_variant(self, variant: int):
         _lib.check(self._lib, self._h, self._lib.bposd_set_bp_variant(self._h, int(variant)))
 

@@ -149,6 +149,10 @@ int bposd_last_timing(bposd_handle *h, double *bp_ms, double *osd_ms, int64_t *b
 int bposd_info(bposd_handle *h, int32_t *rank, int32_t *num_candidates, int32_t *max_iter,
                int32_t *nnz);
 
+/* Diagnostics: simulated LDS cycles of one bit pass (bank-conflict model) for the natural bit order, the
+ * order the library chose, and the conflict-free ideal.  Any pointer may be NULL. */
+int bposd_layout_info(bposd_handle *h, int64_t *natural_cycles, int64_t *chosen_cycles, int64_t *ideal_cycles);
+
 /* Tuning knob (not part of the reference surface): BP workgroup shape variant
  * 0 = auto, 1 = 1 check/thread, 2 = 2 checks/thread, 4 = 4 checks/thread. */
 int bposd_set_bp_variant(bposd_handle *h, int32_t variant);

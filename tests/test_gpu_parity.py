@@ -433,3 +433,60 @@ def test_pack_rows_device(gpu_ready, h1922):
         w = d_w.cpu().numpy().view(np.uint64)
         back = np.unpackbits(w.view(np.uint8).reshape(B, -1), axis=1, bitorder="little")[:, :n]
         assert (back == x).all()
+
+
+def test_bit_layout_is_conflict_free_for_hgp_codes(gpu_ready, h1922, hgp400):
+    """The host-side layout search finds a bank-conflict-free lane order of the bits for the benchmark code
+    (both hx and hz) and never does worse than the natural order."""
+    from bp_osd_amd import BpOsdDecoder
+
+    for H in (h1922.hz, h1922.hx):
+        info = BpOsdDecoder(H, error_rate=0.05, bp_method="ms", osd_method="osd0").layout_info()
+        assert info["chosen"] == info["ideal"] < info["natural"], info
+    for H in (hgp400.hx, hgp400.hz):
+        info = BpOsdDecoder(H, error_rate=0.05, bp_method="ms", osd_method="osd0").layout_info()
+        assert info["ideal"] <= info["chosen"] <= info["natural"], info
+
+
+def test_random_irregular_codes_vs_oracle(gpu_ready):
+    """Randomized sparse parity-check matrices (irregular degrees, rank-deficient, isolated bits, degree-1
+    checks) x random decoder settings: every integer output and the LLR bits equal the oracle's."""
+    import scipy.sparse as sp
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import gf2_rank
+    from oracle import OracleDecoder
+
+    rng = np.random.default_rng(2718)
+    done = 0
+    for trial in range(60):
+        m = int(rng.integers(2, 70))
+        n = int(rng.integers(m, 3 * m + 8))
+        H = np.zeros((m, n), dtype=np.uint8)
+        for c in range(m):
+            w = int(rng.integers(1, min(8, n) + 1))
+            H[c, rng.choice(n, size=w, replace=False)] = 1
+        if rng.random() < 0.3 and m > 3:  # make it rank deficient
+            H[-1] = H[0] ^ H[1]
+            if not H[-1].any():
+                H[-1, 0] = 1
+        if int(H.sum(axis=0).max()) > 8:
+            continue
+        rank = gf2_rank(H)
+        kp = n - rank
+        q = float(rng.choice([0.03, 0.08, 0.15]))
+        osd = [("osd0", 0), ("osd_cs", min(kp, int(rng.integers(1, 9)))), ("osd_e", min(kp, int(rng.integers(1, 7))))][trial % 3]
+        if osd[0] != "osd0" and osd[1] == 0:
+            osd = ("osd0", 0)
+        nonuni = rng.random() < 0.4
+        probs = rng.uniform(0.01, 0.3, size=n) if nonuni else np.full(n, q)
+        kw = dict(channel_probs=probs, max_iter=int(rng.integers(1, 12)), bp_method="ms",
+                  ms_scaling_factor=float(rng.choice([0.0, 0.625, 1.0])), osd_method=osd[0], osd_order=osd[1],
+                  sort_tie_policy=int(rng.integers(0, 2)))
+        err = (rng.random((40, n)) < q).astype(np.uint8)
+        syn = (err @ H.T % 2).astype(np.uint8)
+        g = BpOsdDecoder(sp.csr_matrix(H), **kw)
+        c = OracleDecoder(sp.csr_matrix(H), **kw)
+        assert g.rank == c.rank == rank
+        _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
+        done += 1
+    assert done >= 40
