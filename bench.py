@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--config", default="h1922_ms_cs7", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--p", type=float, default=0.05, help="bit-flip probability q")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="syndromes timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="syndromes timed on the CPU oracle (0 = skip)")
     ap.add_argument("--variant", type=int, default=0, help="BP workgroup shape (0 auto, 1, 2, 4)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gather")
     ap.add_argument("--max-iter", type=int, default=-1, help="override max_iter (diagnostics; -1 = the config's)")

@@ -438,7 +438,7 @@ int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
     // OSD_RPT rows per thread: 4 waves cover 1024 rows
     const int rows_per_thread = OSD_RPT;
     const int NT = std::min(64 * OSD_MAXW, std::max(64, ((h->m + rows_per_thread - 1) / rows_per_thread + 63) / 64 * 64));
-    const size_t lds = osd_lds_bytes(h->n, P.nsort, W, NT * OSD_RPT);
+    const size_t lds = osd_lds_bytes(W, NT * OSD_RPT);
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
     int rc = ensure(h, h->osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
@@ -830,6 +830,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             }
             fprintf(stderr, "[bposd osd phases, s_memtime ticks] sort %lld  rowbuild %lld  eliminate %lld  osd0 %lld  sweep %lld  write %lld\n",
                     st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5]);
+            fprintf(stderr, "[bposd osd elimination] panel phase %lld  trailing phase %lld  pivots %lld\n", st[1190], st[1191], st[1192]);
         }
     }
     HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));

@@ -116,11 +116,19 @@ struct OsdLds {
     unsigned char* xout;          // [n]
 };
 
-__host__ __device__ inline size_t osd_align8(size_t x) { return (x + 7) & ~(size_t)7; }
+__host__ __device__ constexpr size_t osd_align8(size_t x) { return (x + 7) & ~(size_t)7; }
+
+// sort size: the power of two >= 64 * W (n <= 64 W - 1).  Compile-time, so that every LDS offset below is
+// an instruction immediate instead of a live register.
+__host__ __device__ constexpr int osd_nsort(int W) {
+    int ns = 2;
+    while (ns < 64 * W) ns <<= 1;
+    return ns;
+}
 
 // Elimination-phase buffers (prow, tab, colvec) and the fp64-weight tables of the non-uniform-channel
 // path are never live at the same time: they share one union region placed last in the carve-up.
-__host__ __device__ inline size_t osd_union_bytes(int n, int nsort, int W, int mr) {
+__host__ __device__ constexpr size_t osd_union_bytes(int nsort, int W, int mr) {
     const size_t elim = (size_t)64 * W * 8 + (size_t)16 * W * 16 * 8 + (size_t)64 * OSD_MAXCV * 8;
     const size_t fpw = (size_t)mr * 8        // am: per-row entries in the first <= 64 non-pivot columns
                      + (size_t)nsort * 8     // costs
@@ -131,7 +139,8 @@ __host__ __device__ inline size_t osd_union_bytes(int n, int nsort, int W, int m
     return elim > fpw ? elim : fpw;
 }
 
-__host__ __device__ inline size_t osd_lds_bytes(int n, int nsort, int W, int mr) {
+__host__ __device__ constexpr size_t osd_lds_bytes(int W, int mr) {
+    const int nsort = osd_nsort(W);
     size_t b = 0;
     b += (size_t)nsort * 8;                     // keys
     b += (size_t)2 * OSD_MAXW * 2 * 8;          // pbuf
@@ -143,9 +152,9 @@ __host__ __device__ inline size_t osd_lds_bytes(int n, int nsort, int W, int mr)
     b += 8 * 4;                                 // misc
     b += (size_t)nsort * 2;                     // kidx
     b += (size_t)nsort * 2;                     // pivrow
-    b += osd_align8((size_t)n * 2);             // inv
-    b += osd_align8((size_t)n);                 // xout
-    b += osd_union_bytes(n, nsort, W, mr);      // prow | tab | colvec  /  fp64-weight tables
+    b += (size_t)nsort * 2;                     // inv
+    b += (size_t)nsort;                         // xout
+    b += osd_union_bytes(nsort, W, mr);         // prow | tab | colvec  /  fp64-weight tables
     return b + 64;
 }
 
@@ -153,7 +162,8 @@ template <int W>
 __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RPT = OSD_RPT;
-    const int m = P.m, n = P.n, NS = P.nsort;
+    const int m = P.m, n = P.n;
+    constexpr int NS = osd_nsort(W);
     const int NT = blockDim.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -174,8 +184,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         L.misc = (int*)p; p += 8 * 4;
         L.kidx = (unsigned short*)p; p += (size_t)NS * 2;
         L.pivrow = (short*)p; p += (size_t)NS * 2;
-        L.inv = (unsigned short*)p; p += osd_align8((size_t)n * 2);
-        L.xout = p; p += osd_align8((size_t)n);
+        L.inv = (unsigned short*)p; p += (size_t)NS * 2;
+        L.xout = p; p += (size_t)NS;
         // union region (last): elimination buffers ...
         L.prow = (unsigned long long*)p;
         L.tab = L.prow + (size_t)64 * W;
@@ -262,11 +272,19 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         int nrank = 0;
         int par = 0;  // pbuf double buffer
         bool done = false;
-        int wdone = 0;  // panels flushed so far; row[k][x] currently holds original word wdone + x
+#ifdef BPOSD_OSD_DIAG
+        long long diag_panel = 0, diag_trail = 0, diag_t0 = 0;
+#define OSD_TICK() ((long long)__builtin_amdgcn_s_memtime())
+#endif
 #pragma clang loop unroll(disable)
         for (int w = 0; w < W; ++w) {
-            if (done) break;
+            // Once `done` (rank reached / past column n) the remaining iterations only flush word 0 and
+            // shift: every word leaves through the same single store, no tail flush with W addresses.
             const int nvalid = W - 1 - w;  // live trailing words: row[k][1 .. nvalid]
+            if (!done) {
+#ifdef BPOSD_OSD_DIAG
+            diag_t0 = OSD_TICK();
+#endif
             // ---------------- (i) panel phase on the current word row[k][0]: one barrier per PIVOT.
             // Every wave proposes its lowest column that still has a candidate (an unused row with a 1);
             // the lowest proposal over all waves is the next pivot column -- the columns skipped in
@@ -278,8 +296,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             for (int k = 0; k < RPT; ++k) { t[k] = 0ull; myq[k] = -1; }
             int npiv = 0;  // pivots found in this panel (uniform)
             const int nb = n - w * 64;  // valid columns in this panel
-            if (nb <= 0) { done = true; break; }
-            const unsigned long long vmask = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+            const unsigned long long vmask = nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
+            if (nb <= 0) done = true;
 #pragma clang loop unroll(disable)
             for (;;) {
                 if (nrank >= P.rank) { done = true; break; }
@@ -343,6 +361,9 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                 ++nrank;
                 par ^= 1;
             }
+#ifdef BPOSD_OSD_DIAG
+            { const long long t1 = OSD_TICK(); diag_panel += t1 - diag_t0; diag_t0 = t1; }
+#endif
             // ---------------- (ii) trailing phase on row[k][1 .. nvalid], in chunks of 8 words
             if (nvalid > 0 && npiv > 0) {
 #pragma unroll
@@ -386,6 +407,10 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                     }
                 }
             }
+#ifdef BPOSD_OSD_DIAG
+            diag_trail += OSD_TICK() - diag_t0;
+#endif
+            }  // if (!done)
             // ---------------- word w is final: flush it and shift the register window down
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
@@ -394,16 +419,11 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                 for (int x = 0; x + 1 < W; ++x) row[k][x] = row[k][x + 1];
                 row[k][W - 1] = 0ull;
             }
-            wdone = w + 1;
-        }
-        // flush the words that were never reached as a panel (stop at rank / column n)
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-#pragma unroll
-            for (int x = 0; x < W; ++x)
-                if (wdone + x < W) ws[(unsigned)((wdone + x) * MR + tid + k * NT)] = row[k][x];
         }
         OSD_STAMP(3);
+#ifdef BPOSD_OSD_DIAG
+        if (P.dbg && tid == 0 && slot_id == 0) { P.dbg[1190] = diag_panel; P.dbg[1191] = diag_trail; P.dbg[1192] = nrank; }
+#endif
         bool y[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) y[k] = ((ws[(unsigned)((W - 1) * MR + tid + k * NT)] >> 63) & 1ull) != 0ull;
