@@ -798,9 +798,6 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.osd_method = h->cfg.osd_order == 0 ? BPOSD_OSD_0 : h->cfg.osd_method;
         Q.osd_order = h->cfg.osd_order;
         Q.tie_policy = h->cfg.sort_tie_policy;
-        int ns = 2;
-        while (ns < h->n) ns <<= 1;
-        Q.nsort = ns;
         Q.synd = d_synd;
         Q.rp = h->d_rp;
         Q.ci = h->d_ci;

@@ -63,7 +63,6 @@ struct OsdParams {
     int osd_method;  // 1 osd0, 2 osd_e, 3 osd_cs
     int osd_order;
     int tie_policy;
-    int nsort;  // power of two >= n
     const uint8_t* __restrict__ synd;  // [B, m]
     const int* __restrict__ rp;        // CSR indptr [m+1]
     const int* __restrict__ ci;        // CSR indices [E]
