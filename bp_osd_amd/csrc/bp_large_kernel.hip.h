@@ -1,0 +1,261 @@
+// bp_large_kernel.hip.h -- belief propagation for codes whose messages do not fit one CU's LDS
+// (BASELINE configs[4]: 14520 x 29524, E = 159720 -> 1.28 MB of fp64 messages per syndrome).
+//
+// Same algorithm, arithmetic order and convergence bookkeeping as bp_kernel.hip.h (rows a3-a7 of
+// SURVEY.md §8), re-mapped for the HBM-bound regime:
+//   * one 512-thread workgroup per syndrome (persistent, atomic queue); a thread walks checks
+//     c = tid, tid + 512, ... in the check pass and bits i = tid, tid + 512, ... in the bit pass;
+//   * the E messages live in a per-workgroup slice of a global workspace in the same check-major
+//     structure-of-arrays layout  msg[k * MP + c]  -> the check pass streams fully coalesced
+//     (consecutive lanes = consecutive checks), the bit pass gathers / scatters 8-byte words whose
+//     cache lines are shared between neighbouring bits (hypergraph-product locality) and between
+//     the d = 0..DV-1 sweeps, so L1/L2 absorb the re-use and HBM sees ~ (4E + 2n) * 8 bytes per
+//     iteration -- the algorithmic figure SURVEY §8(d) prices this regime with;
+//   * graph tables (degrees, edge slots) are re-read from global memory every iteration (+E * 4 B);
+//   * hard decisions (bytes) and the mismatch bitmap stay in LDS; the final LLRs are written to the
+//     workspace only in the last iteration (or every iteration when the caller wants LLRs).
+// Visibility: messages written by one wave and read by another of the SAME workgroup go through
+// global memory between two __syncthreads() (workgroup-scope release/acquire; the waves share the
+// CU's L1).  No inter-workgroup communication exists.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bp_kernel.hip.h"
+
+namespace bposd {
+
+struct BpLargeParams {
+    int m, n;
+    long long B;
+    int max_iter;
+    double ms_scaling;
+    int osd_enabled;
+    int mp;                              // check stride of the message layout (m rounded up to 64)
+    const uint8_t* __restrict__ synd;    // [B, m]
+    const double* __restrict__ llr0;     // [n]
+    const uint8_t* __restrict__ sel;     // [B, n] nullable
+    const double* __restrict__ llr0_alt; // [n]
+    const int* __restrict__ chk_deg;     // [m]
+    const int* __restrict__ var_deg;     // [n]
+    const int* __restrict__ var_pos;     // [DV * n], entry d*n+i = k*mp + c
+    double* __restrict__ msg_ws;         // [gridDim.x][DC * mp]
+    double* __restrict__ llr_tmp;        // [gridDim.x][n]  LLRs of the current syndrome
+    uint8_t* __restrict__ out_bp;
+    uint8_t* __restrict__ out_osd0;
+    uint8_t* __restrict__ out_osdw;
+    uint8_t* __restrict__ out_conv;
+    int* __restrict__ out_iters;
+    double* __restrict__ out_llr;
+    double* __restrict__ llr_ws;         // [cap, n]
+    int* __restrict__ osd_list;
+    int* __restrict__ counters;
+    unsigned long long* __restrict__ iter_total;
+};
+
+__host__ __device__ inline size_t bp_large_lds_bytes(int m, int n) {
+    return (size_t)((n + 15) & ~15) + (size_t)((m + 31) / 32 + 2) * 4 + 8 * 4;
+}
+
+template <int DC, int DV, int METHOD>
+__global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m = P.m, n = P.n, MP = P.mp;
+    const int NT = blockDim.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    unsigned char* dec = smem;                                                        // [n] hard decisions
+    unsigned int* diffw = reinterpret_cast<unsigned int*>(smem + ((n + 15) & ~15));  // [m/32] mismatch bitmap
+    int* sh = reinterpret_cast<int*>(diffw + ((m + 31) / 32 + 2));                    // flags / ids
+    double* msg = P.msg_ws + (size_t)blockIdx.x * DC * MP;
+    double* llrt = P.llr_tmp + (size_t)blockIdx.x * n;
+
+    for (;;) {
+        if (tid == 0) {
+            sh[0] = 0;
+            sh[1] = 0;
+            sh[2] = atomicAdd(&P.counters[0], 1);
+        }
+        __syncthreads();
+        const long long s = sh[2];
+        if (s >= P.B) break;
+        const uint8_t* syn = P.synd + (size_t)s * m;
+
+        // mismatch bitmap = syndrome; messages = priors; decisions = 0
+        for (int c0 = tid - lane; c0 < m; c0 += NT) {
+            const int c = c0 + lane;
+            const bool sb = (c < m) && (syn[c] & 1);
+            const unsigned long long bal = __ballot(sb);
+            if (lane == 0) {
+                diffw[c0 >> 5] = (unsigned int)bal;
+                diffw[(c0 >> 5) + 1] = (unsigned int)(bal >> 32);
+                if (bal) sh[0] = 1;
+            }
+        }
+        for (int i = tid; i < n; i += NT) {
+            double l0 = P.llr0[i];
+            if (P.sel && P.sel[(size_t)s * n + i]) l0 = P.llr0_alt[i];
+            const int deg = P.var_deg[i];
+            for (int d = 0; d < deg; ++d) msg[P.var_pos[(size_t)d * n + i]] = l0;
+            dec[i] = 0;
+            llrt[i] = l0;
+        }
+        __syncthreads();
+
+        int it_done = 0;
+        bool conv = (sh[0] == 0);
+        if (!conv) {
+#pragma clang loop unroll(disable)
+            for (int it = 1;; ++it) {
+                const int fi = it & 1;
+                {
+                    bool mis = false;
+                    for (int c = tid; c < m; c += NT) mis |= ((diffw[c >> 5] >> (c & 31)) & 1u) != 0;
+                    const unsigned long long anym = __ballot(mis);
+                    if (lane == 0 && anym) sh[fi] = 1;
+                }
+                if (it > P.max_iter) {
+                    __syncthreads();
+                    conv = (sh[fi] == 0);
+                    it_done = P.max_iter;
+                    break;
+                }
+                // ---------------- check pass
+                const double alpha = alpha_for_iteration(P.ms_scaling, it);
+#pragma clang loop unroll(disable)
+                for (int c = tid; c < m; c += NT) {
+                    const int deg = P.chk_deg[c];
+                    const bool sbit = (syn[c] & 1) != 0;
+                    double* mc = msg + c;
+                    double v[DC];
+#pragma unroll
+                    for (int k = 0; k < DC; ++k)
+                        if (k < deg) v[k] = mc[(size_t)k * MP];
+                    if (METHOD == 1) {
+                        bool neg[DC];
+                        bool par = sbit;
+#pragma unroll
+                        for (int k = 0; k < DC; ++k) {
+                            neg[k] = (k < deg) ? (v[k] <= 0.0) : false;
+                            par ^= neg[k];
+                        }
+                        double pre[DC], suf[DC];
+                        pre[0] = __DBL_MAX__;
+#pragma unroll
+                        for (int k = 1; k < DC; ++k) pre[k] = (k - 1 < deg) ? min_abs(pre[k - 1], v[k - 1]) : pre[k - 1];
+                        suf[DC - 1] = __DBL_MAX__;
+#pragma unroll
+                        for (int k = DC - 2; k >= 0; --k) suf[k] = (k + 1 < deg) ? min_abs(suf[k + 1], v[k + 1]) : suf[k + 1];
+#pragma unroll
+                        for (int k = 0; k < DC; ++k) {
+                            if (k < deg) {
+                                const double mag = min_pos(pre[k], suf[k]);
+                                mc[(size_t)k * MP] = flip_sign(mag * alpha, par ^ neg[k]);
+                            }
+                        }
+                    } else {
+                        double pre[DC], th[DC];
+                        double t = 1.0;
+#pragma unroll
+                        for (int k = 0; k < DC; ++k) {
+                            if (k < deg) {
+                                pre[k] = t;
+                                th[k] = tanh(v[k] / 2);
+                                t *= th[k];
+                            }
+                        }
+                        t = 1.0;
+                        const double sg = sbit ? -1.0 : 1.0;
+#pragma unroll
+                        for (int k = DC - 1; k >= 0; --k) {
+                            if (k < deg) {
+                                const double x = pre[k] * t;
+                                mc[(size_t)k * MP] = sg * log((1 + x) / (1 - x));
+                                t *= th[k];
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (sh[fi] == 0) {
+                    conv = true;
+                    it_done = it - 1;
+                    break;
+                }
+                if (tid == 0) sh[fi ^ 1] = 0;
+                // ---------------- bit pass
+                const bool keep_llr = (it == P.max_iter) || (P.out_llr != nullptr);
+#pragma clang loop unroll(disable)
+                for (int i = tid; i < n; i += NT) {
+                    const int deg = P.var_deg[i];
+                    double l0 = P.llr0[i];
+                    if (P.sel && P.sel[(size_t)s * n + i]) l0 = P.llr0_alt[i];
+                    int pos[DV];
+                    double cm[DV], pre[DV];
+#pragma unroll
+                    for (int d = 0; d < DV; ++d)
+                        if (d < deg) {
+                            pos[d] = P.var_pos[(size_t)d * n + i];
+                            cm[d] = msg[pos[d]];
+                        }
+                    double t = l0;
+#pragma unroll
+                    for (int d = 0; d < DV; ++d)
+                        if (d < deg) {
+                            pre[d] = t;
+                            t += cm[d];
+                        }
+                    if (keep_llr) llrt[i] = t;
+                    const int dnew = (t <= 0.0) ? 1 : 0;
+                    double suf = 0.0;
+#pragma unroll
+                    for (int d = DV - 1; d >= 0; --d)
+                        if (d < deg) {
+                            msg[pos[d]] = pre[d] + suf;
+                            suf += cm[d];
+                        }
+                    if (dnew != (int)dec[i]) {
+                        dec[i] = (unsigned char)dnew;
+#pragma unroll
+                        for (int d = 0; d < DV; ++d)
+                            if (d < deg) {
+                                const int c = pos[d] % MP;
+                                atomicXor(&diffw[c >> 5], 1u << (c & 31));
+                            }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        const bool to_osd = (!conv) && P.osd_enabled;
+        if (tid == 0) {
+            if (to_osd) {
+                const int slot = atomicAdd(&P.counters[1], 1);
+                P.osd_list[slot] = (int)s;
+                sh[3] = slot;
+            }
+            if (P.out_conv) P.out_conv[s] = conv ? 1 : 0;
+            if (P.out_iters) P.out_iters[s] = it_done;
+            if (it_done) atomicAdd(P.iter_total, (unsigned long long)it_done);
+        }
+        __syncthreads();
+        const int slot = to_osd ? sh[3] : 0;
+        for (int i = tid; i < n; i += NT) {
+            const size_t o = (size_t)s * n + i;
+            const uint8_t b = dec[i];
+            if (P.out_bp) P.out_bp[o] = b;
+            if (!to_osd) {
+                P.out_osdw[o] = b;
+                if (P.out_osd0) P.out_osd0[o] = b;
+            } else {
+                P.llr_ws[(size_t)slot * n + i] = llrt[i];
+            }
+            if (P.out_llr) P.out_llr[o] = llrt[i];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace bposd

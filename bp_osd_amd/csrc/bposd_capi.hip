@@ -21,6 +21,8 @@
 #include <vector>
 
 #include "bp_kernel.hip.h"
+#include "bp_large_kernel.hip.h"
+#include "osd_large_kernel.hip.h"
 #include "osd_kernel.hip.h"
 
 using namespace bposd;
@@ -46,6 +48,9 @@ struct bposd_handle {
     int m = 0, n = 0, E = 0;
     int dc_max = 0, dv_max = 0;
     bool regular = false;
+    bool large = false;  // beyond the LDS-resident kernels: HBM-resident messages / matrix
+    DevBuf bpl_msg, bpl_llr;  // large BP workspaces
+    DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
     int max_iter = 0;
     int rank = 0, kprime = 0, ncand = 0;
     bool probs_uniform = true;
@@ -432,6 +437,62 @@ int launch_bp(bposd_handle* h, BpParams& P) {
     return fail(h, BPOSD_ERR_UNSUPPORTED, "no BP kernel for check degree %d / bit degree %d", h->dc_max, h->dv_max);
 }
 
+// ------------------------------------------------------------------------ large-code BP launch
+int build_tables_large(bposd_handle* h, int DV, int MP) {
+    const int m = h->m, n = h->n;
+    std::vector<int> chk_deg(m), var_deg(n, 0);
+    std::vector<int> var_pos((size_t)DV * n, 0);
+    for (int c = 0; c < m; ++c) {
+        chk_deg[c] = h->rp[c + 1] - h->rp[c];
+        for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
+            const int i = h->ci[e];
+            const int d = var_deg[i]++;
+            var_pos[(size_t)d * n + i] = (e - h->rp[c]) * MP + c;
+        }
+    }
+    auto up = [&](int** dst, const std::vector<int>& v) -> int {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        HIP_TRY(h, hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1)));
+        HIP_TRY(h, hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc;
+    if ((rc = up(&h->d_chk_deg, chk_deg))) return rc;
+    if ((rc = up(&h->d_var_deg, var_deg))) return rc;
+    if ((rc = up(&h->d_var_pos, var_pos))) return rc;
+    h->tab_mp = MP;
+    return 0;
+}
+
+template <int DC, int DV>
+int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
+    const size_t lds = bp_large_lds_bytes(h->m, h->n);
+    const int wg_per_cu = std::max<int>(1, std::min<size_t>(4, h->lds_per_cu / lds));
+    const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
+    int rc;
+    if ((rc = ensure(h, h->bpl_msg, sizeof(double) * (size_t)grid * DC * P.mp))) return rc;
+    if ((rc = ensure(h, h->bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
+    P.msg_ws = (double*)h->bpl_msg.p;
+    P.llr_tmp = (double*)h->bpl_llr.p;
+    if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
+        auto k = bp_large_kernel<DC, DV, 1>;
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->stream, P);
+    } else {
+        auto k = bp_large_kernel<DC, DV, 0>;
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->stream, P);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_bp_large(bposd_handle* h, BpLargeParams& P) {
+    if (h->dc_max <= 12 && h->dv_max <= 6) return launch_bp_large_t<12, 6>(h, P);
+    if (h->dc_max <= 16 && h->dv_max <= 8) return launch_bp_large_t<16, 8>(h, P);
+    return fail(h, BPOSD_ERR_UNSUPPORTED, "check degree %d / bit degree %d exceed the built kernels (16 / 8)", h->dc_max, h->dv_max);
+}
+
 // ----------------------------------------------------------------------------- OSD launch
 template <int W>
 int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
@@ -470,6 +531,104 @@ int launch_osd(bposd_handle* h, const OsdParams& P, long long B) {
         case 32: return launch_osd_t<32>(h, P, B);
     }
     return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the register-resident OSD kernel (n=%d)", h->n);
+}
+
+// ------------------------------------------------------------------ large-code OSD launch
+static int osdl_rpt(int m) {
+    for (int r : {2, 4, 8, 16})
+        if (m <= OSDL_NT * r) return r;
+    return 0;
+}
+
+int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_rank_out) {
+    const int RPT = osdl_rpt(h->m);
+    if (!RPT) return fail(h, BPOSD_ERR_UNSUPPORTED, "m=%d beyond the HBM-resident OSD kernel (16384)", h->m);
+    OsdLargeParams Q{};
+    Q.m = h->m; Q.n = h->n; Q.W = (h->n + 1 + 63) / 64;
+    Q.rank = P.rank; Q.osd_method = P.osd_method; Q.osd_order = P.osd_order; Q.tie_policy = P.tie_policy;
+    Q.nsort = 1;
+    while (Q.nsort < h->n) Q.nsort <<= 1;
+    Q.mrl = OSDL_NT * RPT;
+    Q.synd = P.synd; Q.rp = P.rp; Q.ci = P.ci; Q.llr_ws = P.llr_ws; Q.osd_list = P.osd_list; Q.counters = P.counters;
+    Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.rank_out = d_rank_out;
+    long long grid = std::min<long long>(B, h->num_cu);
+    if (grid < 1) grid = 1;
+    auto a256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // every sub-array is [grid][count], laid out back to back in one allocation
+    const size_t g = (size_t)grid;
+    const size_t sizes[8] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
+                             g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
+                             g * sizeof(int) * (size_t)Q.nsort,                    // kidx
+                             g * sizeof(int) * (size_t)h->n,                       // inv
+                             g * sizeof(int) * (size_t)64 * Q.W,                   // pivrow
+                             g * sizeof(int) * (size_t)Q.mrl,                      // rowpos
+                             g * sizeof(int) * (size_t)64 * Q.W,                   // wt
+                             g * (size_t)h->n};                                    // xout
+    size_t total = 0;
+    for (size_t b : sizes) total += a256(b);
+    int rc = ensure(h, h->osdl_ws, total);
+    if (rc) return rc;
+    unsigned char* ptrs[8];
+    {
+        unsigned char* base = (unsigned char*)h->osdl_ws.p;
+        for (int i = 0; i < 8; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
+    }
+    Q.mat = (unsigned long long*)ptrs[0];
+    Q.keys = (unsigned long long*)ptrs[1];
+    Q.kidx = (int*)ptrs[2];
+    Q.inv = (int*)ptrs[3];
+    Q.pivrow = (int*)ptrs[4];
+    Q.rowpos = (int*)ptrs[5];
+    Q.wt = (int*)ptrs[6];
+    Q.xout = (uint8_t*)ptrs[7];
+    const size_t lds = osd_large_lds_bytes(Q.W, RPT);
+    if (lds > h->lds_per_cu) return fail(h, BPOSD_ERR_UNSUPPORTED, "large OSD kernel needs %zu bytes of LDS", lds);
+#define OSDL_LAUNCH(R)                                                                                      \
+    case R: {                                                                                               \
+        auto k = osd_large_kernel<R>;                                                                       \
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(OSDL_NT), lds, h->stream, Q);                      \
+    } break;
+    switch (RPT) {
+        OSDL_LAUNCH(2)
+        OSDL_LAUNCH(4)
+        OSDL_LAUNCH(8)
+        OSDL_LAUNCH(16)
+    }
+#undef OSDL_LAUNCH
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+// rank of a large code: one elimination of the zero syndrome on the device (the host routine is O(m^2 n / 64))
+int probe_rank_large(bposd_handle* h, int* rank) {
+    DevBuf tmp;
+    const size_t n = h->n, m = h->m;
+    const size_t off_llr = 0, off_synd = off_llr + sizeof(double) * n, off_out = off_synd + ((m + 255) & ~(size_t)255),
+                 off_cnt = off_out + ((n + 255) & ~(size_t)255), total = off_cnt + 64;
+    int rc = ensure(h, tmp, total);
+    if (rc) return rc;
+    unsigned char* b = (unsigned char*)tmp.p;
+    HIP_TRY(h, hipMemsetAsync(b, 0, total, h->stream));
+    const int cnt[8] = {0, 1, 0, 0, /*osd_list*/ 0, /*rank_out*/ -1, 0, 0};
+    HIP_TRY(h, hipMemcpyAsync(b + off_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, h->stream));
+    OsdParams P{};
+    P.m = h->m; P.n = h->n; P.rank = std::min(h->m, h->n);
+    P.osd_method = BPOSD_OSD_0; P.osd_order = 0; P.tie_policy = 0;
+    P.synd = b + off_synd; P.rp = h->d_rp; P.ci = h->d_ci; P.llr_ws = (const double*)(b + off_llr);
+    P.osd_list = (const int*)(b + off_cnt) + 4; P.counters = (int*)(b + off_cnt);
+    P.out_osd0 = nullptr; P.out_osdw = b + off_out;
+    rc = launch_osd_large(h, P, 1, (int*)(b + off_cnt) + 5);
+    if (!rc) {
+        int got[8];
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipMemcpy(got, b + off_cnt, sizeof(got), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(h, BPOSD_ERR_HIP, "rank probe failed: %s", hipGetErrorString(e));
+        else if (got[5] < 0 || got[5] > std::min(h->m, h->n)) rc = fail(h, BPOSD_ERR_HIP, "rank probe returned %d", got[5]);
+        else *rank = got[5];
+    }
+    release(tmp);
+    return rc;
 }
 
 int num_candidates(const bposd_handle* h) {
@@ -514,7 +673,7 @@ void bposd_destroy(bposd_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->io_sel, &h->osd_rows_ws, &h->llr_ws, &h->osd_list, &h->io_synd, &h->io_osdw, &h->io_osd0, &h->io_bp,
+    for (DevBuf* b : {&h->bpl_msg, &h->bpl_llr, &h->osdl_ws, &h->io_sel, &h->osd_rows_ws, &h->llr_ws, &h->osd_list, &h->io_synd, &h->io_osdw, &h->io_osd0, &h->io_bp,
                       &h->io_conv, &h->io_iters, &h->io_llr})
         release(*b);
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
@@ -623,17 +782,27 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
         bposd_destroy(h);
         return BPOSD_ERR_UNSUPPORTED;
     }
-    if (!pick_shape(h) || bp_lds_bytes(pair.dc, shape_threads(h, pick_shape(h)) * pick_shape(h)) > h->lds_per_cu) {
-        fail(nullptr, BPOSD_ERR_UNSUPPORTED,
-             "code too large for the LDS-resident BP kernel (m=%d n=%d needs %zu B of LDS): large-code path not built yet",
-             m, n, bp_lds_bytes(pair.dc, ((m + 63) / 64) * 64));
-        bposd_destroy(h);
-        return BPOSD_ERR_UNSUPPORTED;
+    // small path: messages in LDS, OSD rows in registers.  Anything beyond goes to the HBM-resident kernels.
+    h->large = (m > 1024) || (osd_words(n) == 0) || !pick_shape(h) ||
+               bp_lds_bytes(pair.dc, shape_threads(h, pick_shape(h)) * pick_shape(h)) > h->lds_per_cu;
+    if (h->large) {
+        if (n > 32767 || m > 16384 || bp_large_lds_bytes(m, n) > h->lds_per_cu) {
+            fail(nullptr, BPOSD_ERR_UNSUPPORTED, "code too large even for the HBM-resident kernels (m=%d n=%d; limits 16384 / 32767)", m, n);
+            bposd_destroy(h);
+            return BPOSD_ERR_UNSUPPORTED;
+        }
+        if (cfg->osd_method >= BPOSD_OSD_E && cfg->osd_order > OSDL_MAXSPAN) {
+            fail(nullptr, BPOSD_ERR_UNSUPPORTED,
+                 "osd order %d > %d is not supported by the HBM-resident OSD kernel (m=%d n=%d)", cfg->osd_order,
+                 OSDL_MAXSPAN, m, n);
+            bposd_destroy(h);
+            return BPOSD_ERR_UNSUPPORTED;
+        }
     }
 
-    h->rank = gf2_rank_host(m, n, h->rp, h->ci);
+    h->rank = h->large ? std::min(m, n) : gf2_rank_host(m, n, h->rp, h->ci);  // large: probed on the device below
     h->kprime = n - h->rank;
-    if (cfg->osd_method != BPOSD_OSD_OFF) {
+    if (cfg->osd_method != BPOSD_OSD_OFF && !h->large) {
         if (m > 1024 || osd_words(n) == 0) {
             fail(nullptr, BPOSD_ERR_UNSUPPORTED,
                  "code too large for the register-resident OSD kernel (m=%d > 1024 or n=%d > 2047): large-code path not built yet",
@@ -675,9 +844,20 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(hipMalloc((void**)&h->d_iter_total, sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counters, sizeof(int) * 4));
     CREATE_TRY(hipHostMalloc((void**)&h->h_iter_total, sizeof(unsigned long long)));
-    CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, pick_shape(h)) * pick_shape(h),
-                           shape_threads(h, pick_shape(h)), 2 * pick_shape(h)));
+    if (h->large) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
+    else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, pick_shape(h)) * pick_shape(h),
+                                shape_threads(h, pick_shape(h)), 2 * pick_shape(h)));
     CREATE_RC(upload_priors(h));
+    if (h->large) {
+        CREATE_RC(probe_rank_large(h, &h->rank));
+        h->kprime = n - h->rank;
+        if (cfg->osd_method >= BPOSD_OSD_E && cfg->osd_order > h->kprime) {
+            fail(h, BPOSD_ERR_INVALID, "osd_order %d exceeds the number of non-pivot columns n - rank = %d",
+                 cfg->osd_order, h->kprime);
+            CREATE_RC(BPOSD_ERR_INVALID);
+        }
+        h->ncand = num_candidates(h);
+    }
     *out = h;
     return BPOSD_OK;
 #undef CREATE_TRY
@@ -787,7 +967,17 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.iter_total = h->d_iter_total;
 
     HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
-    if ((rc = launch_bp(h, P))) return rc;
+    if (h->large) {
+        BpLargeParams L{};
+        L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling;
+        L.osd_enabled = P.osd_enabled; L.mp = h->tab_mp;
+        L.synd = P.synd; L.llr0 = P.llr0; L.sel = P.sel; L.llr0_alt = P.llr0_alt;
+        L.chk_deg = h->d_chk_deg; L.var_deg = h->d_var_deg; L.var_pos = h->d_var_pos;
+        L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv;
+        L.out_iters = P.out_iters; L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list;
+        L.counters = P.counters; L.iter_total = P.iter_total;
+        if ((rc = launch_bp_large(h, L))) return rc;
+    } else if ((rc = launch_bp(h, P))) return rc;
     HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
     h->ran_osd = false;
     if (osd_on) {
@@ -816,7 +1006,13 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             HIP_TRY(h, hipMemsetAsync(h->d_osd_dbg, 0, 2048 * sizeof(long long), h->stream));
             Q.dbg = h->d_osd_dbg;
         }
-        if ((rc = launch_osd(h, Q, B))) return rc;
+        if (h->large) {
+            if (Q.cost && Q.osd_method >= BPOSD_OSD_E)
+                return fail(h, BPOSD_ERR_UNSUPPORTED,
+                            "the HBM-resident OSD kernel ranks candidates by Hamming weight only: a non-uniform channel with "
+                            "weight_fn=0 needs osd_0 or weight_fn=1 for codes beyond m=1024 / n=2047");
+            if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
+        } else if ((rc = launch_osd(h, Q, B))) return rc;
         h->ran_osd = true;
         if (Q.dbg) {
             static long long st[2048];

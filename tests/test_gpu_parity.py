@@ -490,3 +490,74 @@ def test_random_irregular_codes_vs_oracle(gpu_ready):
         _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
         done += 1
     assert done >= 40
+
+
+@pytest.fixture(scope="module")
+def hgp4050():
+    """[[4050, 18]]-type HGP of the 45x45 circulant 1 + x^2 + x^5: hx, hz are 2025 x 4050 -- beyond the
+    LDS/register-resident kernels (m > 1024), so it runs on the HBM-resident large-code path."""
+    from bp_osd_amd.codes import circulant, hgp
+
+    return hgp(circulant(45, (0, 2, 5)), compute_logicals=False)
+
+
+def test_large_code_bp_vs_oracle(gpu_ready, hgp4050):
+    """Large-code BP kernel (messages in HBM): bit-exact decisions, iteration counts and LLRs."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = hgp4050.hz
+    assert H.shape == (2025, 4050)
+    for q, max_iter, ms in ((0.04, 30, 0.0), (0.07, 12, 0.625)):
+        _, syn = _syndromes(H, q, 600, 3)
+        kw = dict(error_rate=q, max_iter=max_iter, bp_method="ms", ms_scaling_factor=ms, osd_method="osd_off")
+        g = BpOsdDecoder(H, **kw)
+        r = _gpu_decode(g, syn)
+        ref = OracleDecoder(H, **kw).decode_batch(syn)
+        _compare_exact(r, ref)
+    # zero syndromes and the per-syndrome channel also go through the large kernel
+    out = g.decode_batch(np.zeros((3, 2025), dtype=np.uint8))
+    assert not out.any() and g.batch_converge.all()
+
+
+@pytest.mark.parametrize(
+    "method,order,tie",
+    [("osd_0", 0, 0), ("osd_cs", 7, 0), ("osd_e", 5, 0), ("osd_cs", 16, 1), ("osd_e", 10, 0)],
+)
+def test_large_code_osd_vs_oracle(gpu_ready, hgp4050, method, order, tie):
+    """HBM-resident OSD kernel (m = 2025 > 1024): OSD-0 / OSD-CS / OSD-E bit-exact against the oracle,
+    on syndromes BP does not converge on (q = 0.07, 8 iterations) plus a few it does."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = hgp4050.hz
+    _, hard = _syndromes(H, 0.07, 20, 11)
+    _, easy = _syndromes(H, 0.01, 6, 12)
+    syn = np.concatenate([hard, easy, np.zeros((1, H.shape[0]), dtype=np.uint8)])
+    kw = dict(error_rate=0.07, max_iter=8, bp_method="ms", ms_scaling_factor=0.625, osd_method=method,
+              osd_order=order, sort_tie_policy=tie)
+    g = BpOsdDecoder(H, **kw)
+    assert g.rank == 2025
+    r = _gpu_decode(g, syn)
+    ref = OracleDecoder(H, **kw).decode_batch(syn)
+    assert (~r["converged"]).sum() >= 15
+    _compare_exact(r, ref)
+    assert ((H @ r["osdw"].T) % 2 == syn.T).all()
+
+
+def test_large_code_rank_deficient_osd(gpu_ready):
+    """HGP of the 62x62 circulant 1 + x^2 + x^5 (rank 57): hz is 3844 x 7688 with rank < m, which makes the
+    elimination walk every column and exercises the 4-rows-per-thread instantiation."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import circulant, hgp
+    from oracle import OracleDecoder
+
+    H = hgp(circulant(62, (0, 2, 5)), compute_logicals=False).hz
+    assert H.shape == (3844, 7688)
+    _, syn = _syndromes(H, 0.06, 5, 21)
+    kw = dict(error_rate=0.06, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=4)
+    g = BpOsdDecoder(H, **kw)
+    o = OracleDecoder(H, **kw)
+    assert g.rank == o.rank and g.rank < 3844
+    r = _gpu_decode(g, syn)
+    _compare_exact(r, o.decode_batch(syn))
