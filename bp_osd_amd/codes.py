@@ -32,6 +32,7 @@ __all__ = [
     "h1922",
     "surface13",
     "regular_ldpc_seed",
+    "l29k",
 ]
 
 
@@ -296,3 +297,10 @@ def h1922(compute_logicals: bool = True) -> HgpCode:
     """[[1922,50]] HGP of the 31x31 circulant 1 + x^2 + x^5 (SURVEY.md §7 'config
     ambiguities', §8d): hx, hz are 961 x 1922, row weight 6, column weight 3."""
     return hgp(circulant(31, (0, 2, 5)), compute_logicals=compute_logicals)
+
+
+def l29k(seed: int = 0) -> HgpCode:
+    """The large configuration of SURVEY.md §8d: HGP of a seeded (5,6)-regular 110 x 132 matrix --
+    hx, hz are 14520 x 29524, check weight 11, bit weight 5 or 6, 159 720 non-zeros.  No logicals (the
+    throughput benchmark needs none and the dense GF(2) routines above are too slow at this size)."""
+    return hgp(regular_ldpc_seed(110, 132, 5, 6, seed=seed), compute_logicals=False)

@@ -550,28 +550,30 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     while (Q.nsort < h->n) Q.nsort <<= 1;
     Q.mrl = OSDL_NT * RPT;
     Q.synd = P.synd; Q.rp = P.rp; Q.ci = P.ci; Q.llr_ws = P.llr_ws; Q.osd_list = P.osd_list; Q.counters = P.counters;
-    Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.rank_out = d_rank_out;
+    Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.rank_out = d_rank_out; Q.dbg = P.dbg;
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
     auto a256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // every sub-array is [grid][count], laid out back to back in one allocation
     const size_t g = (size_t)grid;
-    const size_t sizes[8] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
+    const size_t sizes[10] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
                              g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
                              g * sizeof(int) * (size_t)Q.nsort,                    // kidx
                              g * sizeof(int) * (size_t)h->n,                       // inv
                              g * sizeof(int) * (size_t)64 * Q.W,                   // pivrow
                              g * sizeof(int) * (size_t)Q.mrl,                      // rowpos
                              g * sizeof(int) * (size_t)64 * Q.W,                   // wt
-                             g * (size_t)h->n};                                    // xout
+                             g * (size_t)h->n,                                     // xout
+                             g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.mrl,        // tmo
+                             g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.W * 64};    // pro
     size_t total = 0;
     for (size_t b : sizes) total += a256(b);
     int rc = ensure(h, h->osdl_ws, total);
     if (rc) return rc;
-    unsigned char* ptrs[8];
+    unsigned char* ptrs[10];
     {
         unsigned char* base = (unsigned char*)h->osdl_ws.p;
-        for (int i = 0; i < 8; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
+        for (int i = 0; i < 10; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
     }
     Q.mat = (unsigned long long*)ptrs[0];
     Q.keys = (unsigned long long*)ptrs[1];
@@ -581,6 +583,8 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     Q.rowpos = (int*)ptrs[5];
     Q.wt = (int*)ptrs[6];
     Q.xout = (uint8_t*)ptrs[7];
+    Q.tmo = (unsigned long long*)ptrs[8];
+    Q.pro = (unsigned long long*)ptrs[9];
     const size_t lds = osd_large_lds_bytes(Q.W, RPT);
     if (lds > h->lds_per_cu) return fail(h, BPOSD_ERR_UNSUPPORTED, "large OSD kernel needs %zu bytes of LDS", lds);
 #define OSDL_LAUNCH(R)                                                                                      \
@@ -1012,6 +1016,14 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
                             "the HBM-resident OSD kernel ranks candidates by Hamming weight only: a non-uniform channel with "
                             "weight_fn=0 needs osd_0 or weight_fn=1 for codes beyond m=1024 / n=2047");
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
+            if (Q.dbg) {
+                long long st[10];
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                HIP_TRY(h, hipMemcpy(st, h->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[bposd large osd, s_memtime ticks, list slot 0] sort %lld  build %lld  E1 %lld  E2 %lld  E3 %lld  apply %lld  "
+                        "sweep %lld | words %lld groups %lld applies %lld\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9]);
+                Q.dbg = nullptr;
+            }
         } else if ((rc = launch_osd(h, Q, B))) return rc;
         h->ran_osd = true;
         if (Q.dbg) {

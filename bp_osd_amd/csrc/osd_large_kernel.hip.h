@@ -5,12 +5,24 @@
 // HBM-bound regime.  One 1024-thread workgroup post-processes one syndrome at a time; thread t owns rows
 // t, t + 1024, ... (RPT of them).  The permuted packed matrix lives in a per-workgroup global workspace
 // M[word][row] (word-major: the rows of one 64-column word are contiguous -> every access by "my rows"
-// is coalesced).  Per 64-column panel:
-//   (i)  panel phase in registers: the thread's panel words and 64-bit combination masks; one barrier
-//        per pivot, lowest proposed column wins (identical to the small kernel);
-//   (ii) trailing phase streamed in chunks of 16 words: the <= 64 pivot rows' words of the chunk are
-//        published to LDS, 4-bit "four Russians" tables are built, every row read-modify-writes its
-//        chunk words in HBM.  Traffic per syndrome ~ sum over panels of the remaining matrix (r + w).
+// is coalesced).
+//
+// Elimination = right-looking blocked Gauss-Jordan with LAZY trailing updates.  A "group" is the set of
+// (<= 64) pivots found in one 64-column word; its effect on a row r is  row_r ^= XOR_{q in t_g(r)} P_g[q]
+// with t_g(r) a 64-bit mask and P_g[q] the pivot rows as they were when the group started.  Instead of
+// sweeping the whole remaining matrix after every word (2 * (W - w) * m * 8 bytes per word: 28 GB per
+// syndrome at 14520 x 29524), up to OSDL_K groups stay OPEN: their masks (TmO) and pivot rows (PRO) are
+// parked in HBM, and
+//   E1  the next word is brought up to date on the fly (16-entry "four Russians" tables, one per nibble
+//       of the mask, built from PRO; conflict-free in LDS because one table is 128 contiguous bytes);
+//   E2  the panel phase runs in registers exactly as in the small kernel: one barrier per pivot, the
+//       lowest proposed column wins;
+//   E3  the new group's pivot rows are materialised for all later words (each wave owns a word and a
+//       private table, no block barriers);
+//   AP  when OSDL_K groups are open, ONE pass over the remaining matrix applies all of them
+//       (tables for OSDL_CW words at a time) -> HBM traffic / OSDL_K (+ the masks re-read per chunk).
+// Earlier words never change: a row that becomes a pivot later has zeros in every earlier non-pivot
+// column, so the reduced columns the sweep reads are final as soon as their word is stored.
 // Sort: bitonic network over a global key array (n up to 32767).  Sweep: per-wave ballots over the
 // finished words re-read from M; singles' weights accumulate in a global int array.
 // Limits: m <= 16384, n <= 32767, osd_cs / osd_e order <= 16, uniform channel (Hamming weights).
@@ -24,7 +36,8 @@ namespace bposd {
 
 constexpr int OSDL_NT = 1024;
 constexpr int OSDL_NW = OSDL_NT / 64;  // waves
-constexpr int OSDL_CW = 16;            // chunk width (words) of the trailing update
+constexpr int OSDL_CW = 8;             // chunk width (words) of the apply pass
+constexpr int OSDL_K = 4;              // open (lazily applied) pivot groups
 constexpr int OSDL_MAXSPAN = 16;       // max osd order
 
 struct OsdLargeParams {
@@ -49,47 +62,64 @@ struct OsdLargeParams {
     int* __restrict__ pivrow;               // [grid][64 * W]  sorted position -> pivot row, -1 non-pivot
     int* __restrict__ rowpos;               // [grid][mrl]     pivot position of a row, -1 if unused
     int* __restrict__ wt;                   // [grid][64 * W]  weights of the single candidates
+    unsigned long long* __restrict__ tmo;   // [grid][OSDL_K * mrl]     masks of the open groups
+    unsigned long long* __restrict__ pro;   // [grid][OSDL_K * W * 64]  pivot rows of the open groups, [g][word][q]
     uint8_t* __restrict__ xout;             // [grid][n]
+    long long* __restrict__ dbg;            // nullable: phase clocks of list slot 0 (s_memtime ticks)
     int* __restrict__ rank_out;             // nullable: [0] = pivots found for list slot 0 (ctor-time rank probe)
 };
+
+__host__ __device__ inline size_t osd_large_union_bytes(int W, int RPT) {
+    size_t e3 = (size_t)OSDL_NW * (OSDL_K - 1) * 256 * 8;   // wave-private tables of E3
+    size_t ap = (size_t)OSDL_K * 16 * OSDL_CW * 16 * 8;     // apply-pass tables (covers E1's OSDL_K * 256 entries)
+    size_t sw = (size_t)OSDL_MAXSPAN * RPT * OSDL_NW * 8 + (size_t)RPT * OSDL_NW * 8 + (size_t)W * 8 + 64 * 4;
+    size_t b = e3 > ap ? e3 : ap;
+    return b > sw ? b : sw;
+}
 
 __host__ __device__ inline size_t osd_large_lds_bytes(int W, int RPT) {
     size_t b = 0;
     b += (size_t)2 * OSDL_NW * 2 * 8;            // pbuf
     b += (size_t)2 * OSDL_NW * 4;                // pcol
-    b += (size_t)64 * 4;                         // qrow
-    b += (size_t)64 * OSDL_CW * 8;               // prow chunk
-    b += (size_t)16 * OSDL_CW * 16 * 8;          // tab
-    b += (size_t)OSDL_MAXSPAN * RPT * OSDL_NW * 8;  // colvec
-    b += (size_t)RPT * OSDL_NW * 8;              // yvec
-    b += (size_t)W * 8;                          // npmask
-    b += (size_t)64 * 4;                         // tpos
+    b += (size_t)OSDL_K * 64 * 4 + OSDL_K * 4;   // grow, gnp
     b += 2 * 8 + 16 * 4;                         // best64, misc
+    b += osd_large_union_bytes(W, RPT);
     return b + 64;
 }
+
+// Row-word access as  uniform base (SGPR pair) + opaque 32-bit byte offset.  Without the opaque step the
+// compiler hoists one 64-bit address per owned row and per base out of every loop and spills them.
+__device__ __forceinline__ unsigned int osdl_opaque(unsigned int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+#define OSDL_AT(type, base, byteoff) (*(type*)((char*)(base) + (size_t)(unsigned int)(byteoff)))
 
 template <int RPT>
 __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n, W = P.W, NS = P.nsort, MRL = P.mrl;
     constexpr int NT = OSDL_NT;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    int tid = threadIdx.x;  // re-laundered per phase (OSDL_FRESH_TID) so that per-row addresses and predicates
+                            // derived from it are recomputed where they are used instead of being hoisted + spilled
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     constexpr int NCV = RPT * OSDL_NW;
+#define OSDL_FRESH_TID() asm volatile("" : "+v"(tid))
 
     unsigned char* p = smem;
     unsigned long long* pbuf = (unsigned long long*)p; p += (size_t)2 * OSDL_NW * 2 * 8;
-    unsigned long long* prow = (unsigned long long*)p; p += (size_t)64 * OSDL_CW * 8;
-    unsigned long long* tab = (unsigned long long*)p; p += (size_t)16 * OSDL_CW * 16 * 8;
-    unsigned long long* colvec = (unsigned long long*)p; p += (size_t)OSDL_MAXSPAN * NCV * 8;
-    unsigned long long* yvec = (unsigned long long*)p; p += (size_t)NCV * 8;
-    unsigned long long* npmask = (unsigned long long*)p; p += (size_t)W * 8;
     unsigned long long* best64 = (unsigned long long*)p; p += 2 * 8;
+    unsigned long long* U = (unsigned long long*)p; p += osd_large_union_bytes(W, RPT);  // phase-dependent (see header)
     unsigned int* pcol = (unsigned int*)p; p += (size_t)2 * OSDL_NW * 4;
-    int* qrow = (int*)p; p += 64 * 4;
-    int* tpos = (int*)p; p += 64 * 4;
+    int* grow = (int*)p; p += OSDL_K * 64 * 4;
+    int* gnp = (int*)p; p += OSDL_K * 4;
     int* misc = (int*)p;
+    // sweep-phase view of U
+    unsigned long long* colvec = U;
+    unsigned long long* yvec = colvec + (size_t)OSDL_MAXSPAN * NCV;
+    unsigned long long* npmask = yvec + NCV;
+    int* tpos = (int*)(npmask + W);
 
     unsigned long long* M = P.mat + (size_t)blockIdx.x * W * MRL;
     unsigned long long* keys = P.keys + (size_t)blockIdx.x * NS;
@@ -99,8 +129,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
     int* rowpos = P.rowpos + (size_t)blockIdx.x * MRL;
     int* wt = P.wt + (size_t)blockIdx.x * 64 * W;
     uint8_t* xout = P.xout + (size_t)blockIdx.x * n;
+    unsigned long long* TmO = P.tmo + (size_t)blockIdx.x * OSDL_K * MRL;
+    unsigned long long* PRO = P.pro + (size_t)blockIdx.x * OSDL_K * W * 64;
 
     for (;;) {
+        OSDL_FRESH_TID();
         if (tid == 0) misc[0] = atomicAdd(&P.counters[2], 1);
         __syncthreads();
         const int slot_id = misc[0];
@@ -109,6 +142,20 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         const long long s = P.osd_list[slot_id];
         const double* llr = P.llr_ws + (size_t)slot_id * n;
 
+#ifdef BPOSD_OSD_DIAG
+        long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies
+        long long t0 = (long long)__builtin_amdgcn_s_memtime();
+#define OSDL_TICK(i)                                                     \
+    do {                                                                 \
+        const long long t1_ = (long long)__builtin_amdgcn_s_memtime();   \
+        tk[i] += t1_ - t0;                                               \
+        t0 = t1_;                                                        \
+    } while (0)
+#define OSDL_COUNT(i) tk[i] += 1
+#else
+#define OSDL_TICK(i) do { } while (0)
+#define OSDL_COUNT(i) do { } while (0)
+#endif
         // ------------------------------------------------------------------ a8: sort (global bitonic)
         for (int i = tid; i < NS; i += NT) {
             if (i < n) {
@@ -145,10 +192,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             __syncthreads();
         }
         for (int j = tid; j < n; j += NT) inv[kidx[j]] = j;
+        OSDL_TICK(0);
+        OSDL_FRESH_TID();
         // ------------------------------------------- build my rows (zero, then set the <= DC bits)
-        for (int x = 0; x < W; ++x)
+        for (int x = 0; x < W; ++x) {
+            const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) M[(size_t)x * MRL + tid + k * NT] = 0ull;
+            for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, M + (size_t)x * MRL, ro + k * NT * 8) = 0ull;
+        }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -165,16 +216,113 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         if (tid < 2 * OSDL_NW) pcol[tid] = 64u;
         __syncthreads();
 
-        // ------------------------------------------------------- a9: blocked Gauss-Jordan
+        OSDL_TICK(1);
+        // ------------------------------------------------------- a9: blocked Gauss-Jordan, lazy groups
         unsigned int usedmask = 0u;  // bit k: my k-th row is a pivot row
         int nrank = 0;
         int par = 0;
+        int ng = 0;                  // open groups
+        int wlast = W - 1;           // last word whose panel phase ran
         bool done = false;
+
+        // AP: apply the ng open groups to words [xlo, W) of every row
+        auto apply_open = [&](int xlo) {
+            for (int x0 = xlo; x0 < W; x0 += OSDL_CW) {
+                OSDL_FRESH_TID();
+                const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
+                __syncthreads();  // the previous tables are no longer read
+                for (int e = tid; e < ng * 16 * OSDL_CW * 16; e += NT) {
+                    const int idx = e & 15, xx = (e >> 4) & (OSDL_CW - 1), grp = (e >> 7) & 15, g = e >> 11;
+                    static_assert(OSDL_CW == 8, "table index decode assumes 8-word chunks");
+                    unsigned long long v = 0ull;
+                    if (xx < cw && 4 * grp < gnp[g]) {
+                        const unsigned long long* pr = PRO + ((size_t)g * W + x0 + xx) * 64 + 4 * grp;
+                        const int np = gnp[g] - 4 * grp;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            if (((idx >> kk) & 1) && kk < np) v ^= pr[kk];
+                    }
+                    U[e] = v;
+                }
+                __syncthreads();
+#pragma clang loop unroll(disable)
+                for (int k = 0; k < RPT; ++k) {
+                    const unsigned int ro = osdl_opaque((unsigned int)(tid + k * NT) * 8u);
+                    unsigned long long v[OSDL_CW];
+#pragma unroll
+                    for (int xx = 0; xx < OSDL_CW; ++xx)
+                        v[xx] = (xx < cw) ? OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) : 0ull;
+#pragma clang loop unroll(disable)
+                    for (int g = 0; g < ng; ++g) {
+                        const unsigned long long mk = OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro);
+                        const unsigned int lo = (unsigned int)mk, hi = (unsigned int)(mk >> 32);
+                        const int ngrp = (gnp[g] + 3) >> 2;  // uniform
+                        const unsigned long long* tb = U + (size_t)g * 16 * OSDL_CW * 16;
+#pragma unroll
+                        for (int qb = 0; qb < 4; ++qb) {
+                            if (qb * 4 < ngrp) {  // tables of the nibbles beyond the group's pivots are zero
+#pragma unroll
+                                for (int gg = 0; gg < 4; ++gg) {
+                                    const int grp = qb * 4 + gg;
+                                    const unsigned int nib = grp < 8 ? ((lo >> (4 * grp)) & 15u) : ((hi >> (4 * (grp - 8))) & 15u);
+                                    const unsigned long long* e = tb + (size_t)grp * OSDL_CW * 16 + nib;
+#pragma unroll
+                                    for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] ^= e[xx * 16];
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int xx = 0; xx < OSDL_CW; ++xx)
+                        if (xx < cw) OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) = v[xx];
+                }
+            }
+            __syncthreads();
+            ng = 0;
+        };
+
 #pragma clang loop unroll(disable)
         for (int w = 0; w < W && !done; ++w) {
+            wlast = w;
+            OSDL_FRESH_TID();
             unsigned long long pw[RPT], t[RPT];
+            {
+                const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) { pw[k] = M[(size_t)w * MRL + tid + k * NT]; t[k] = 0ull; }
+                for (int k = 0; k < RPT; ++k) { pw[k] = OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8); t[k] = 0ull; }
+            }
+            // ---------------- E1: bring word w up to date with the open groups
+            if (ng > 0) {
+                for (int e = tid; e < ng * 256; e += NT) {
+                    const int idx = e & 15, grp = (e >> 4) & 15, g = e >> 8;
+                    unsigned long long v = 0ull;
+                    const int np = gnp[g] - 4 * grp;
+                    if (np > 0) {
+                        const unsigned long long* pr = PRO + ((size_t)g * W + w) * 64 + 4 * grp;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            if (((idx >> kk) & 1) && kk < np) v ^= pr[kk];
+                    }
+                    U[e] = v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < OSDL_K; ++g) {
+                    if (g < ng) {
+                        const int ngrp = (gnp[g] + 3) >> 2;
+                        const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
+#pragma unroll
+                        for (int k = 0; k < RPT; ++k) {
+                            const unsigned long long mk = OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + k * NT * 8);
+                            for (int grp = 0; grp < ngrp; ++grp)
+                                pw[k] ^= U[(g * 16 + grp) * 16 + (int)((mk >> (4 * grp)) & 15ull)];
+                        }
+                    }
+                }
+            }
+            OSDL_TICK(2);
+            OSDL_FRESH_TID();
+            // ---------------- E2: panel phase in registers
             int npiv = 0;
             const int nb = n - w * 64;
             const unsigned long long vmask = nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
@@ -227,7 +375,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         const int r = tid + k * NT;
                         pivrow[j] = r;
                         rowpos[r] = j;
-                        qrow[npiv] = r;
+                        grow[ng * 64 + npiv] = r;
                     } else if (pw[k] & bmask) {
                         pw[k] ^= pw_p;
                         t[k] ^= t_p ^ qbit;
@@ -237,54 +385,84 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 ++nrank;
                 par ^= 1;
             }
+            OSDL_FRESH_TID();
             // word w is final
+            {
+                const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) M[(size_t)w * MRL + tid + k * NT] = pw[k];
-            // ---------------- trailing phase, chunks of OSDL_CW words
+                for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8) = pw[k];
+            }
+            OSDL_TICK(3);
+            OSDL_COUNT(7);
             if (npiv > 0) {
-                const int ngroups = (npiv + 3) >> 2;
-                for (int x0 = w + 1; x0 < W; x0 += OSDL_CW) {
-                    const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
-                    __syncthreads();  // previous chunk's tables are no longer read; qrow[] is published
-                    for (int idx = tid; idx < npiv * cw; idx += NT) {
-                        const int q = idx / cw, xx = idx - q * cw;
-                        prow[q * OSDL_CW + xx] = M[(size_t)(x0 + xx) * MRL + qrow[q]];
-                    }
-                    __syncthreads();
-                    for (int e = tid; e < ngroups * 16 * cw; e += NT) {
-                        const int g = e / (16 * cw);
-                        const int rem = e - g * (16 * cw);
-                        const int xx = rem >> 4, idx = rem & 15;
-                        unsigned long long v = 0ull;
+                OSDL_COUNT(8);
+                {
+                    const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            if (((idx >> kk) & 1) && (4 * g + kk) < npiv) v ^= prow[(4 * g + kk) * OSDL_CW + xx];
-                        tab[(g * OSDL_CW + xx) * 16 + idx] = v;
-                    }
-                    __syncthreads();
+                    for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = t[k];
+                }
+                if (tid == 0) gnp[ng] = npiv;
+                __syncthreads();  // grow / gnp / TmO of the new group are visible
+                // ------------ E3: pivot rows of the new group at its start state, for every later word.
+                // One wave per word, wave-private tables (a wave's LDS operations complete in order).
+                if (w + 1 < W) {
+                    volatile unsigned long long* tw = U + (size_t)wave * (OSDL_K - 1) * 256;
+                    const int row = (lane < npiv) ? grow[ng * 64 + lane] : 0;
+                    unsigned long long mrow[OSDL_K - 1];
 #pragma unroll
-                    for (int k = 0; k < RPT; ++k) {
-                        if (t[k] != 0ull) {
-                            for (int xx = 0; xx < cw; ++xx) {
-                                unsigned long long v = 0ull;
-                                for (int g = 0; g < ngroups; ++g)
-                                    v ^= tab[(g * OSDL_CW + xx) * 16 + (int)((t[k] >> (4 * g)) & 15ull)];
-                                M[(size_t)(x0 + xx) * MRL + tid + k * NT] ^= v;
+                    for (int g = 0; g < OSDL_K - 1; ++g) mrow[g] = (g < ng && lane < npiv) ? TmO[(size_t)g * MRL + row] : 0ull;
+                    for (int x = w + 1 + wave; x < W; x += OSDL_NW) {
+                        for (int e = lane; e < ng * 256; e += 64) {
+                            const int idx = e & 15, grp = (e >> 4) & 15, g = e >> 8;
+                            unsigned long long v = 0ull;
+                            const int np = gnp[g] - 4 * grp;
+                            if (np > 0) {
+                                const unsigned long long* pr = PRO + ((size_t)g * W + x) * 64 + 4 * grp;
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk)
+                                    if (((idx >> kk) & 1) && kk < np) v ^= pr[kk];
+                            }
+                            tw[e] = v;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        unsigned long long v = (lane < npiv) ? M[(size_t)x * MRL + row] : 0ull;
+#pragma unroll
+                        for (int g = 0; g < OSDL_K - 1; ++g) {
+                            if (g < ng) {
+                                const int ngrp = (gnp[g] + 3) >> 2;
+                                for (int grp = 0; grp < ngrp; ++grp)
+                                    v ^= tw[(g * 16 + grp) * 16 + (int)((mrow[g] >> (4 * grp)) & 15ull)];
                             }
                         }
+                        PRO[((size_t)ng * W + x) * 64 + lane] = v;
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
+                ++ng;
+                __syncthreads();  // PRO of the new group is visible
+                OSDL_TICK(4);
+                if (ng == OSDL_K) {
+                    apply_open(w + 1);
+                    OSDL_COUNT(9);
+                    OSDL_TICK(5);
+                }
             }
-            __syncthreads();  // all row updates of this panel are visible before the next panel loads
+            __syncthreads();
         }
+        // pending groups (rank reached before the last word): the sweep reads the syndrome column and the
+        // non-pivot columns to the right of the last panel in their final state
+        if (ng > 0 && wlast + 1 < W) apply_open(wlast + 1);
+        OSDL_TICK(5);
         __syncthreads();
         if (P.rank_out && slot_id == 0 && tid == 0) P.rank_out[0] = nrank;
 
+        OSDL_FRESH_TID();
         // --------------------------------------------------------------- OSD-0 solution
         bool y[RPT];
+        const unsigned int ro_y = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            y[k] = ((M[(size_t)(W - 1) * MRL + tid + k * NT] >> 63) & 1ull) != 0ull;
+            y[k] = ((OSDL_AT(unsigned long long, M + (size_t)(W - 1) * MRL, ro_y + k * NT * 8) >> 63) & 1ull) != 0ull;
             const bool usedk = (usedmask >> k) & 1u;
             const unsigned long long yb = __ballot(usedk && y[k]);
             if (lane == 0) yvec[k * OSDL_NW + wave] = yb;
@@ -312,10 +490,12 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 npm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(npm >> 32)) << 32) |
                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)npm);
                 if (!npm) continue;
-                if (P.osd_method != 3 && tcount >= wspan) break;  // osd_e only needs the first wspan columns
+                if (P.osd_method != 3 && tcount >= wspan) break;
+                OSDL_FRESH_TID();  // osd_e only needs the first wspan columns
                 unsigned long long rw[RPT];
+                const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) rw[k] = M[(size_t)w * MRL + tid + k * NT];
+                for (int k = 0; k < RPT; ++k) rw[k] = OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8);
                 int acc = 0;
                 while (npm) {
                     const int b = __ffsll((long long)npm) - 1;
@@ -384,6 +564,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             }
         }
 
+        OSDL_FRESH_TID();
         // ------------------------------------------------- write the OSD-W solution
         if (sel_a == -1) {
             for (int i = tid; i < n; i += NT) P.out_osdw[(size_t)s * n + i] = xout[i];
@@ -395,16 +576,17 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             for (int k = 0; k < RPT; ++k) {
                 bool xs = y[k];
                 const size_t rr = (size_t)tid + (size_t)k * NT;
+                const unsigned int ro = osdl_opaque((unsigned int)tid * 8u) + k * NT * 8;
                 if (sel_a >= 0) {
-                    xs ^= ((M[(size_t)(sel_a >> 6) * MRL + rr] >> (sel_a & 63)) & 1ull) != 0ull;
-                    if (sel_b >= 0) xs ^= ((M[(size_t)(sel_b >> 6) * MRL + rr] >> (sel_b & 63)) & 1ull) != 0ull;
+                    xs ^= ((OSDL_AT(unsigned long long, M + (size_t)(sel_a >> 6) * MRL, ro) >> (sel_a & 63)) & 1ull) != 0ull;
+                    if (sel_b >= 0) xs ^= ((OSDL_AT(unsigned long long, M + (size_t)(sel_b >> 6) * MRL, ro) >> (sel_b & 63)) & 1ull) != 0ull;
                 } else {
                     unsigned int pp = (unsigned int)sel_b;
                     while (pp) {
                         const int bq = __ffs((int)pp) - 1;
                         pp &= pp - 1;
                         const int pos = tpos[bq];
-                        xs ^= ((M[(size_t)(pos >> 6) * MRL + rr] >> (pos & 63)) & 1ull) != 0ull;
+                        xs ^= ((OSDL_AT(unsigned long long, M + (size_t)(pos >> 6) * MRL, ro) >> (pos & 63)) & 1ull) != 0ull;
                     }
                 }
                 if (((usedmask >> k) & 1u) && xs) xout[kidx[rowpos[rr]]] = 1;
@@ -426,6 +608,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             for (int i = tid; i < n; i += NT) P.out_osdw[(size_t)s * n + i] = xout[i];
         }
         __syncthreads();
+        OSDL_TICK(6);
+#ifdef BPOSD_OSD_DIAG
+        if (P.dbg && slot_id == 0 && tid == 0)
+            for (int i = 0; i < 10; ++i) P.dbg[i] = tk[i];
+#endif
+#undef OSDL_TICK
+#undef OSDL_COUNT
+#undef OSDL_FRESH_TID
     }
 }
 
