@@ -93,6 +93,11 @@ __device__ __forceinline__ unsigned int osdl_opaque(unsigned int v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+#ifndef BPOSD_LDS_MERGED
+typedef const volatile __attribute__((address_space(3))) unsigned long long* osdl_lds_ptr;
+#else
+typedef const unsigned long long* osdl_lds_ptr;
+#endif
 #define OSDL_AT(type, base, byteoff) (*(type*)((char*)(base) + (size_t)(unsigned int)(byteoff)))
 
 template <int RPT>
@@ -143,7 +148,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         const double* llr = P.llr_ws + (size_t)slot_id * n;
 
 #ifdef BPOSD_OSD_DIAG
-        long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies
+        long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
+                                                               // apply look-ups per thread, apply row-words per thread
         long long t0 = (long long)__builtin_amdgcn_s_memtime();
 #define OSDL_TICK(i)                                                     \
     do {                                                                 \
@@ -152,9 +158,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         t0 = t1_;                                                        \
     } while (0)
 #define OSDL_COUNT(i) tk[i] += 1
+#define OSDL_ADD(i, v) tk[i] += (v)
 #else
 #define OSDL_TICK(i) do { } while (0)
 #define OSDL_COUNT(i) do { } while (0)
+#define OSDL_ADD(i, v) do { } while (0)
 #endif
         // ------------------------------------------------------------------ a8: sort (global bitonic)
         for (int i = tid; i < NS; i += NT) {
@@ -231,6 +239,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 OSDL_FRESH_TID();
                 const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
                 __syncthreads();  // the previous tables are no longer read
+#ifdef BPOSD_OSD_DIAG
+                for (int g = 0; g < ng; ++g) OSDL_ADD(10, (long long)RPT * cw * 4 * ((((gnp[g] + 3) >> 2) + 3) >> 2));
+                OSDL_ADD(11, (long long)RPT * cw);
+#endif
                 for (int e = tid; e < ng * 16 * OSDL_CW * 16; e += NT) {
                     const int idx = e & 15, xx = (e >> 4) & (OSDL_CW - 1), grp = (e >> 7) & 15, g = e >> 11;
                     static_assert(OSDL_CW == 8, "table index decode assumes 8-word chunks");
@@ -257,7 +269,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         const unsigned long long mk = OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro);
                         const unsigned int lo = (unsigned int)mk, hi = (unsigned int)(mk >> 32);
                         const int ngrp = (gnp[g] + 3) >> 2;  // uniform
-                        const unsigned long long* tb = U + (size_t)g * 16 * OSDL_CW * 16;
+                        // volatile LDS pointer: keeps the look-ups as single ds_read_b64 (hipcc would pair them
+                        // into ds_read2_b64, which issues at half rate on gfx950 -- same finding as bp_kernel.hip.h;
+                        // measured here: 855 -> 677 ms per 254 L29k eliminations)
+                        osdl_lds_ptr tb = (osdl_lds_ptr)(U + (size_t)g * 16 * OSDL_CW * 16);
 #pragma unroll
                         for (int qb = 0; qb < 4; ++qb) {
                             if (qb * 4 < ngrp) {  // tables of the nibbles beyond the group's pivots are zero
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                 for (int gg = 0; gg < 4; ++gg) {
                                     const int grp = qb * 4 + gg;
                                     const unsigned int nib = grp < 8 ? ((lo >> (4 * grp)) & 15u) : ((hi >> (4 * (grp - 8))) & 15u);
-                                    const unsigned long long* e = tb + (size_t)grp * OSDL_CW * 16 + nib;
+                                    osdl_lds_ptr e = tb + grp * OSDL_CW * 16 + nib;
 #pragma unroll
                                     for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] ^= e[xx * 16];
                                 }
@@ -611,10 +626,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         OSDL_TICK(6);
 #ifdef BPOSD_OSD_DIAG
         if (P.dbg && slot_id == 0 && tid == 0)
-            for (int i = 0; i < 10; ++i) P.dbg[i] = tk[i];
+            for (int i = 0; i < 12; ++i) P.dbg[i] = tk[i];
 #endif
 #undef OSDL_TICK
 #undef OSDL_COUNT
+#undef OSDL_ADD
 #undef OSDL_FRESH_TID
     }
 }

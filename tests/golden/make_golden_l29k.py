@@ -1,0 +1,51 @@
+"""Golden vectors for the large configuration (L29k: 14520 x 29524 HGP code), from the CPU oracle.
+
+Same provenance as make_golden.py (this repository's oracle; no reference code).  Kept separate because the
+oracle needs minutes here: the elimination of one 14520 x 29524 matrix takes ~4.5 s and every OSD-W candidate
+another ~7 ms, so the orders are kept small (osd_e 10 -> 1023 candidates; osd_cs 3 -> 15004 + 3).
+
+    python tests/golden/make_golden_l29k.py
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from bp_osd_amd.codes import l29k  # noqa: E402
+from oracle import OracleDecoder  # noqa: E402
+
+
+def pack(a):
+    return np.packbits(np.asarray(a, dtype=np.uint8), axis=1)
+
+
+def main():
+    H = l29k().hz
+    digest = hashlib.sha256(H.indptr.tobytes() + H.indices.tobytes()).hexdigest()
+    q = 0.06
+    rng = np.random.default_rng(29524)
+    err = (rng.random((4, H.shape[1])) < q).astype(np.uint8)
+    syn = np.ascontiguousarray((H.astype(np.int32) @ err.T.astype(np.int32) % 2).T.astype(np.uint8))
+    # one easy shot so that the BP-converged branch is in the fixture as well
+    easy = (rng.random((1, H.shape[1])) < 0.01).astype(np.uint8)
+    syn = np.concatenate([syn, (H.astype(np.int32) @ easy.T.astype(np.int32) % 2).T.astype(np.uint8)])
+    for name, nshots, cfg in (
+        ("e10", 5, dict(error_rate=q, max_iter=10, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=10)),
+        ("cs3", 2, dict(error_rate=q, max_iter=10, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_cs", osd_order=3)),
+    ):
+        t0 = time.time()
+        sub = np.ascontiguousarray(syn[-nshots:])
+        r = OracleDecoder(H, **cfg).decode_batch(sub)
+        print(name, "%.1fs" % (time.time() - t0), "converged", r["converged"], "weights", r["osdw"].sum(1), flush=True)
+        np.savez_compressed(os.path.join(HERE, f"l29k_golden_{name}.npz"), cfg=repr(cfg), code_sha256=digest,
+                            syn=pack(sub), osdw=pack(r["osdw"]), osd0=pack(r["osd0"]), bp=pack(r["bp"]),
+                            converged=r["converged"], iters=r["iters"])
+
+
+if __name__ == "__main__":
+    main()

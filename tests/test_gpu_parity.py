@@ -561,3 +561,32 @@ def test_large_code_rank_deficient_osd(gpu_ready):
     assert g.rank == o.rank and g.rank < 3844
     r = _gpu_decode(g, syn)
     _compare_exact(r, o.decode_batch(syn))
+
+
+@pytest.mark.parametrize("name", ["e10", "cs3"])
+def test_l29k_golden(gpu_ready, name):
+    """BASELINE configs[4]'s code (14520 x 29524, 16 rows per thread in the OSD kernel) against oracle vectors
+    frozen in tests/golden/l29k_golden_*.npz (tests/golden/make_golden_l29k.py; the oracle needs minutes there)."""
+    import ast
+    import hashlib
+    import os
+
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import l29k
+
+    path = os.path.join(os.path.dirname(__file__), "golden", f"l29k_golden_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip("l29k_golden fixture not generated")
+    g = np.load(path, allow_pickle=False)
+    H = l29k().hz
+    assert hashlib.sha256(H.indptr.tobytes() + H.indices.tobytes()).hexdigest() == str(g["code_sha256"])
+    m, n = H.shape
+    syn = np.unpackbits(g["syn"], axis=1)[:, :m]
+    dec = BpOsdDecoder(H, **ast.literal_eval(str(g["cfg"])))
+    assert dec.rank == 14520
+    out = dec.decode_batch(syn, want_osd0=True, want_bp=True)
+    assert (dec.batch_converge == g["converged"].astype(bool)).all()
+    assert (dec.batch_iter == g["iters"]).all()
+    assert (dec.batch_bp == np.unpackbits(g["bp"], axis=1)[:, :n]).all()
+    assert (dec.batch_osd0 == np.unpackbits(g["osd0"], axis=1)[:, :n]).all()
+    assert (out == np.unpackbits(g["osdw"], axis=1)[:, :n]).all()
