@@ -267,8 +267,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #pragma clang loop unroll(disable)
                     for (int g = 0; g < ng; ++g) {
                         const unsigned long long mk = OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro);
-                        const unsigned int lo = (unsigned int)mk, hi = (unsigned int)(mk >> 32);
                         const int ngrp = (gnp[g] + 3) >> 2;  // uniform
+                        // Half-wave skew: lanes 32-63 walk the nibbles in the order grp ^ 8, so the two halves of a
+                        // wave read different 128-byte tables in the same instruction (tools/microbench/lds_probe:
+                        // 3.45 -> 2.95 cycles per wave-level read).  Only when every batch of four nibbles is live.
+                        const bool skew = (ngrp > 12) && ((lane >> 5) & 1);
+                        const unsigned int lo = skew ? (unsigned int)(mk >> 32) : (unsigned int)mk;
+                        const unsigned int hi = skew ? (unsigned int)mk : (unsigned int)(mk >> 32);
+                        const int hq = skew ? 8 * OSDL_CW * 16 : 0;  // table-index distance between grp and grp ^ 8
                         // volatile LDS pointer: keeps the look-ups as single ds_read_b64 (hipcc would pair them
                         // into ds_read2_b64, which issues at half rate on gfx950 -- same finding as bp_kernel.hip.h;
                         // measured here: 855 -> 677 ms per 254 L29k eliminations)
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                 for (int gg = 0; gg < 4; ++gg) {
                                     const int grp = qb * 4 + gg;
                                     const unsigned int nib = grp < 8 ? ((lo >> (4 * grp)) & 15u) : ((hi >> (4 * (grp - 8))) & 15u);
-                                    osdl_lds_ptr e = tb + grp * OSDL_CW * 16 + nib;
+                                    osdl_lds_ptr e = tb + grp * OSDL_CW * 16 + (int)nib + (grp < 8 ? hq : -hq);
 #pragma unroll
                                     for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] ^= e[xx * 16];
                                 }
