@@ -213,13 +213,15 @@ def main():
         avg_iters = iters_tot / steps
         algo_bytes = avg_iters * bytes_per_iter + B * (m + n)
         achieved = algo_bytes / (avg_bp_ms * 1e-3) / 1e9 if avg_bp_ms > 0 else 0.0
-        traffic = None
+        traffic = osd_traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(args.config, {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                osd_traffic = rec.get("osd_hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic = osd_traffic = None
 
         # LER of this rank's shard (osdw), definitions of css_decode_sim.py:257-280 for one sector
         ler = None
@@ -306,7 +308,7 @@ def main():
             out["roofline_osd"] = {
                 "kernel": "osd_large_kernel (sort + blocked GF(2) elimination + OSD-E sweep, matrix in HBM)",
                 "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": osd_bytes, "avg_launch_ms": avg_osd_ms,
+                "traffic": osd_traffic, "algorithmic_bytes_per_launch": osd_bytes, "avg_launch_ms": avg_osd_ms,
                 "note": "the single-pass figure of SURVEY.md §8(d); a blocked elimination revisits the trailing matrix once "
                         "per group of pivot panels and its inner loop is bound by LDS table look-ups (DESIGN.md §4.5)",
             }
