@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import sys
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -175,15 +177,18 @@ class BpOsdDecoder:
         s = np.asarray(syndromes)
         if s.ndim != 2 or s.shape[1] != self.m:
             raise ValueError(f"The syndromes must have shape (B, {self.m}). Not {s.shape}.")
+        # uint8 input goes to the device as it is (the kernels look at bit 0 only); other dtypes are reduced mod 2
         s8 = np.ascontiguousarray(s.astype(np.int64) & 1, dtype=np.uint8) if s.dtype != np.uint8 \
-            else np.ascontiguousarray(s & 1)
+            else np.ascontiguousarray(s)
         B = s8.shape[0]
-        osdw = np.empty((B, self.n), np.uint8)
-        osd0 = np.empty((B, self.n), np.uint8) if want_osd0 else None
-        bp = np.empty((B, self.n), np.uint8) if want_bp else None
+        # drop last call's arrays first: their buffers can then be reused (unless the caller kept them)
+        self.batch_osd0 = self.batch_bp = self.batch_llr = None
+        osdw = self._out_array((B, self.n), np.uint8)
+        osd0 = self._out_array((B, self.n), np.uint8) if want_osd0 else None
+        bp = self._out_array((B, self.n), np.uint8) if want_bp else None
         conv = np.empty(B, np.uint8)
         iters = np.empty(B, np.int32)
-        llr = np.empty((B, self.n), np.float64) if want_llr else None
+        llr = self._out_array((B, self.n), np.float64) if want_llr else None
         ptr = lambda a: a.ctypes.data if a is not None else None
         if prior_select is not None:
             sel = np.ascontiguousarray(np.asarray(prior_select) != 0, dtype=np.uint8)
@@ -207,6 +212,39 @@ class BpOsdDecoder:
         self.batch_iter = iters
         self.batch_osd0, self.batch_bp, self.batch_llr = osd0, bp, llr
         return osdw
+
+    # ------------------------------------------------------------------ recycled output buffers
+    _POOL_MIN_BYTES = 1 << 20   # below this a fresh numpy array costs nothing
+    _POOL_MAX_BYTES = 4 << 30   # host memory kept for reuse per decoder
+
+    def _out_array(self, shape, dtype):
+        """Output array for decode_batch.  A fresh 250 MB numpy array costs ~25 ms of page faults while the
+        device-to-host copy lands in it (measured, tools/pin_probe.py), so large result buffers are recycled:
+        a buffer returns to this decoder's pool as soon as no array refers to it any more (reference count),
+        i.e. results the caller keeps are never overwritten.  Page-locked buffers were measured too and gain
+        nothing over warm pageable memory on this platform."""
+        count = int(np.prod(shape))
+        nbytes = count * np.dtype(dtype).itemsize
+        if nbytes < self._POOL_MIN_BYTES:
+            return np.empty(shape, dtype)
+        pool = self.__dict__.setdefault("_out_pool", [])
+        best = -1
+        for k in range(len(pool)):
+            # references to a free buffer: the pool list and getrefcount's argument
+            if pool[k].nbytes >= nbytes and sys.getrefcount(pool[k]) == 2:
+                if best < 0 or pool[k].nbytes < pool[best].nbytes:
+                    best = k
+        if best < 0:
+            pool.append(np.empty(nbytes, np.uint8))
+            best = len(pool) - 1
+            k = 0
+            while sum(b.nbytes for b in pool) > self._POOL_MAX_BYTES and k < len(pool) - 1:
+                if sys.getrefcount(pool[k]) == 2:
+                    del pool[k]
+                    best -= 1
+                else:
+                    k += 1
+        return pool[best][:nbytes].view(dtype).reshape(shape)
 
     def decode(self, syndrome):
         """Decode one syndrome; returns the correction with the syndrome's dtype

@@ -17,6 +17,7 @@
 #ifndef BPOSD_MI355X_H
 #define BPOSD_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

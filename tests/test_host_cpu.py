@@ -89,3 +89,30 @@ def test_create_rejects_bad_csr_via_c_abi(lib):
     rc = lib.bposd_create(ctypes.byref(cfg), indptr.ctypes.data, indices.ctypes.data, 1, 3, probs.ctypes.data,
                           ctypes.byref(h))
     assert rc == _lib.BPOSD_ERR_INVALID
+
+
+def test_output_buffer_pool_never_hands_out_live_memory():
+    """decode_batch recycles large result buffers; a buffer is reused only when no array refers to it."""
+    import types
+
+    from bp_osd_amd.decoder import BpOsdDecoder
+
+    fake = types.SimpleNamespace(_POOL_MIN_BYTES=1 << 10, _POOL_MAX_BYTES=3 << 12)
+    alloc = lambda shape, dt=np.uint8: BpOsdDecoder._out_array(fake, shape, dt)
+    small = alloc((4, 8))
+    assert "_out_pool" not in fake.__dict__ and small.shape == (4, 8)          # below the threshold: plain array
+    a = alloc((64, 64))
+    a[:] = 7
+    b = alloc((64, 64))
+    assert not np.shares_memory(a, b) and len(fake._out_pool) == 2               # a is alive -> new buffer
+    addr_a = a.ctypes.data
+    view = a[3:5]                                                                # a view keeps the buffer busy
+    del a
+    c = alloc((64, 64))
+    assert c.ctypes.data != addr_a and (view == 7).all() and len(fake._out_pool) == 3
+    del view
+    d = alloc((32, 64), np.float64)                                              # 16 KB > 4 KB buffers: new one
+    e = alloc((64, 64))
+    assert e.ctypes.data == addr_a                                               # the freed buffer is reused
+    assert d.dtype == np.float64 and d.shape == (32, 64)
+    assert sum(x.nbytes for x in fake._out_pool) <= max(3 << 12, d.nbytes + 2 * 4096) + 4096
