@@ -198,8 +198,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- one more decode of batch 0 for verification / LER (outside the timed region)
-    dec.decode_batch_device(d_syn[0].data_ptr(), B, d_osdw.data_ptr(), None, None, d_conv.data_ptr(),
+    # ---- one more decode of batch 0 for verification / LER (outside the timed region), with the OSD-0 and BP-only
+    # outputs as well (css_decode_sim.py:294-295,338-339 report those error rates next to OSD-W's)
+    d_osd0 = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    d_bp = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    dec.decode_batch_device(d_syn[0].data_ptr(), B, d_osdw.data_ptr(), d_osd0.data_ptr(), d_bp.data_ptr(), d_conv.data_ptr(),
                             d_iters.data_ptr(), None)
     dec.synchronize()
     t_last = dec.last_timing()
@@ -224,15 +227,19 @@ def main():
                 traffic = osd_traffic = None
 
         # LER of this rank's shard (osdw), definitions of css_decode_sim.py:257-280 for one sector
-        ler = None
+        ler = ler0 = ler_bp = None
         if code.lz is not None:
             err0 = torch.from_numpy(batches[0][0]).to(dev)
             lz = torch.from_numpy(code.lz.astype(np.float32)).to(dev)
-            fails = 0
+            fails = fails0 = fails_bp = 0
             for lo in range(0, B, 16384):
-                resid = (d_osdw[lo:lo + 16384] ^ err0[lo:lo + 16384]).to(torch.float32)
-                fails += int((((resid @ lz.T) % 2).sum(dim=1) > 0).sum().item())
-            ler = fails / B
+                sl = slice(lo, lo + 16384)
+                logical = lambda x: (((x[sl] ^ err0[sl]).to(torch.float32) @ lz.T) % 2).sum(dim=1) > 0
+                fails += int(logical(d_osdw).sum().item())
+                fails0 += int(logical(d_osd0).sum().item())
+                # BP-only succeeds when it converged and left no logical error (css_decode_sim.py:331-349, one sector)
+                fails_bp += int((logical(d_bp) | (d_conv[sl] == 0)).sum().item())
+            ler, ler0, ler_bp = fails / B, fails0 / B, fails_bp / B
         # every correction must reproduce its syndrome (checked on the device for the whole batch)
         Hd = torch.sparse_csr_tensor(torch.from_numpy(H.indptr.astype(np.int64)), torch.from_numpy(H.indices.astype(np.int64)),
                                      torch.ones(H.nnz, dtype=torch.float32), size=H.shape).to(dev)
@@ -271,6 +278,10 @@ def main():
             },
             "logical_error_rate": ler,
             "logical_error_rate_eb": None if ler is None else float(np.sqrt(ler * (1 - ler) / B)),
+            "osd0_logical_error_rate": ler0,
+            "osd0_logical_error_rate_eb": None if ler0 is None else float(np.sqrt(ler0 * (1 - ler0) / B)),
+            "bp_logical_error_rate": ler_bp,
+            "bp_logical_error_rate_eb": None if ler_bp is None else float(np.sqrt(ler_bp * (1 - ler_bp) / B)),
             "corrections_reproduce_syndromes": synd_ok,
             "bp_converged_fraction": conv_frac,
             "bp_iterations_mean": float(it_cpu.mean()),

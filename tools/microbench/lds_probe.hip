@@ -46,6 +46,43 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long* out, long long
     if (tid == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
+// write probes: MODE 0 = b64 linear, 1 = b128 linear, 2 = b32 linear, 3 = b64 at stride 16 B (2-way), 4 = 2 x b32 split of a b64
+template <int MODE>
+__global__ __launch_bounds__(1024) void wprobe(unsigned long long* out, long long* ticks, int nrep) {
+    extern __shared__ unsigned long long lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    typedef volatile __attribute__((address_space(3))) unsigned long long* w64;
+    typedef volatile __attribute__((address_space(3))) unsigned int* w32;
+    typedef volatile __attribute__((address_space(3))) ulonglong2* w128;
+    char* base = (char*)lds + (tid >> 6) * 4096;  // 4 KB per wave
+    unsigned long long v = tid;
+    __syncthreads();
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    for (int i = 0; i < nrep; ++i) {
+        v += i;
+        if (MODE == 0) {
+            w64 p = (w64)(base + lane * 8);
+            p[0] = v; p[64] = v; p[128] = v; p[192] = v; p[256] = v; p[320] = v; p[384] = v; p[448] = v;
+        } else if (MODE == 1) {
+            w128 p = (w128)(base + lane * 16);
+            ulonglong2 x; x.x = v; x.y = v;
+            p[0].x = x.x; p[0].y = x.y; p[64].x = x.x; p[64].y = x.y; p[128].x = x.x; p[128].y = x.y; p[192].x = x.x; p[192].y = x.y;
+        } else if (MODE == 2) {
+            w32 p = (w32)(base + lane * 4);
+            p[0] = (unsigned)v; p[64] = (unsigned)v; p[128] = (unsigned)v; p[192] = (unsigned)v;
+            p[256] = (unsigned)v; p[320] = (unsigned)v; p[384] = (unsigned)v; p[448] = (unsigned)v;
+        } else if (MODE == 3) {
+            w64 p = (w64)(base + (lane & 31) * 16 + (lane >> 5) * 8);
+            p[0] = v; p[64] = v; p[128] = v; p[192] = v; p[256] = v; p[320] = v; p[384] = v; p[448] = v;
+        }
+    }
+    __syncthreads();
+    const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 1024 + tid] = lds[tid] + v;
+    if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 int main() {
     int ncu = 256;
     const int nrep = 4096;
@@ -71,5 +108,18 @@ int main() {
         printf("%-52s %.2f ticks per wave-level read (CU-wide, 16 waves)\n", names[M], per);          \
     }
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
+    const char* wnames[4] = {"write b64 linear", "write b128 linear (asm may split)", "write b32 linear", "write b64 interleaved halves"};
+#define WRUN(M, NW, BYTES)                                                                             \
+    {                                                                                                  \
+        hipLaunchKernelGGL(wprobe<M>, dim3(ncu), dim3(1024), 65536, 0, out, ticks, nrep);              \
+        hipDeviceSynchronize();                                                                        \
+        hipLaunchKernelGGL(wprobe<M>, dim3(ncu), dim3(1024), 65536, 0, out, ticks, nrep);              \
+        hipDeviceSynchronize();                                                                        \
+        hipMemcpy(t.data(), ticks, ncu * 8, hipMemcpyDeviceToHost);                                    \
+        double s = 0; for (auto v : t) s += v;                                                         \
+        const double per = s / ncu / ((double)nrep * NW * 16);                                         \
+        printf("%-52s %.2f ticks per wave-level write of %d B (CU-wide, 16 waves)\n", wnames[M], per, BYTES); \
+    }
+    WRUN(0, 8, 512) WRUN(1, 4, 1024) WRUN(2, 8, 256) WRUN(3, 8, 512)
     return 0;
 }
