@@ -38,6 +38,7 @@ constexpr int OSDL_NT = 1024;
 constexpr int OSDL_NW = OSDL_NT / 64;  // waves
 constexpr int OSDL_CW = 8;             // chunk width (words) of the apply pass
 constexpr int OSDL_K = 4;              // open (lazily applied) pivot groups
+constexpr int OSDL_G5 = 13;            // 5-bit fields of a 64-bit pivot mask in the apply pass (12 x 5 + 4)
 constexpr int OSDL_MAXSPAN = 16;       // max osd order
 
 struct OsdLargeParams {
@@ -71,7 +72,7 @@ struct OsdLargeParams {
 
 __host__ __device__ inline size_t osd_large_union_bytes(int W, int RPT) {
     size_t e3 = (size_t)OSDL_NW * (OSDL_K - 1) * 256 * 8;   // wave-private tables of E3
-    size_t ap = (size_t)OSDL_K * 16 * OSDL_CW * 16 * 8;     // apply-pass tables (covers E1's OSDL_K * 256 entries)
+    size_t ap = (size_t)OSDL_K * OSDL_G5 * OSDL_CW * 32 * 8;  // apply-pass tables (5-bit; covers E1's OSDL_K * 256 entries)
     size_t sw = (size_t)OSDL_MAXSPAN * RPT * OSDL_NW * 8 + (size_t)RPT * OSDL_NW * 8 + (size_t)W * 8 + 64 * 4;
     size_t b = e3 > ap ? e3 : ap;
     return b > sw ? b : sw;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         const double* llr = P.llr_ws + (size_t)slot_id * n;
 
 #ifdef BPOSD_OSD_DIAG
-        long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
+        long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
                                                                // apply look-ups per thread, apply row-words per thread
         long long t0 = (long long)__builtin_amdgcn_s_memtime();
 #define OSDL_TICK(i)                                                     \
@@ -239,56 +240,104 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 OSDL_FRESH_TID();
                 const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
                 __syncthreads();  // the previous tables are no longer read
+                OSDL_TICK(5);
 #ifdef BPOSD_OSD_DIAG
-                for (int g = 0; g < ng; ++g) OSDL_ADD(10, (long long)RPT * cw * 4 * ((((gnp[g] + 3) >> 2) + 3) >> 2));
+                for (int g = 0; g < ng; ++g) OSDL_ADD(10, (long long)RPT * cw * ((gnp[g] + 4) / 5 > 8 ? 13 : ((gnp[g] + 4) / 5 > 4 ? 8 : 4)));
                 OSDL_ADD(11, (long long)RPT * cw);
 #endif
-                for (int e = tid; e < ng * 16 * OSDL_CW * 16; e += NT) {
-                    const int idx = e & 15, xx = (e >> 4) & (OSDL_CW - 1), grp = (e >> 7) & 15, g = e >> 11;
+                // 32-entry tables, one per 5 pivots (a 256-byte table is as fast to look up as a 128-byte one --
+                // tools/microbench/lds_probe -- and needs 13 instead of 16 look-ups per 64 pivots).  One thread
+                // builds one table: 5 pivot-row words in registers, then a Gray-code walk (one XOR + one LDS
+                // store per entry).  The walk starts at entry (lane & 31) so that the 32 lanes of a store
+                // instruction hit 32 different entries = all 64 banks once.
+                for (int tt = tid; tt < ng * OSDL_G5 * OSDL_CW; tt += NT) {
+                    const int xx = tt & (OSDL_CW - 1), gg = tt >> 3;
                     static_assert(OSDL_CW == 8, "table index decode assumes 8-word chunks");
-                    unsigned long long v = 0ull;
-                    if (xx < cw && 4 * grp < gnp[g]) {
-                        const unsigned long long* pr = PRO + ((size_t)g * W + x0 + xx) * 64 + 4 * grp;
-                        const int np = gnp[g] - 4 * grp;
+                    const int g = gg / OSDL_G5, grp = gg - g * OSDL_G5;
+                    const int np = gnp[g] - 5 * grp;
+                    unsigned long long pr[5];
+                    // unconditional (clamped) loads so that the five requests are in flight together
+                    const unsigned long long* src = PRO + ((size_t)g * W + (xx < cw ? x0 + xx : W - 1)) * 64;
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            if (((idx >> kk) & 1) && kk < np) v ^= pr[kk];
+                    for (int kk = 0; kk < 5; ++kk) {
+                        const int q = 5 * grp + kk;
+                        const unsigned long long val = src[q < 63 ? q : 63];
+                        pr[kk] = (xx < cw && kk < np) ? val : 0ull;
                     }
-                    U[e] = v;
+                    unsigned int idx = osdl_opaque((unsigned int)lane & 31u);  // (laundered: else all 32 indices are hoisted + spilled)
+                    unsigned long long v = 0ull;
+#pragma unroll
+                    for (int kk = 0; kk < 5; ++kk)
+                        if ((idx >> kk) & 1u) v ^= pr[kk];
+                    unsigned long long* tabp = U + (size_t)tt * 32;
+                    tabp[idx] = v;
+#pragma unroll
+                    for (int i = 1; i < 32; ++i) {
+                        const int bit = (i & 1) ? 0 : ((i & 2) ? 1 : ((i & 4) ? 2 : ((i & 8) ? 3 : 4)));  // ctz(i)
+                        idx ^= 1u << bit;
+                        v ^= pr[bit];
+                        tabp[idx] = v;
+                    }
                 }
                 __syncthreads();
+                OSDL_TICK(12);
+                // Software-pipelined over the thread's rows: the words and masks of row k + 1 are requested before
+                // the look-ups of row k start (one wave keeps 2 x 4.5 KB in flight), otherwise the pass is bound by
+                // the latency of its own global loads rather than by the LDS.
+                unsigned long long vn[OSDL_CW], mkn[OSDL_K];
+                {
+                    const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
+#pragma unroll
+                    for (int xx = 0; xx < OSDL_CW; ++xx)
+                        vn[xx] = (xx < cw) ? OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) : 0ull;
+#pragma unroll
+                    for (int g = 0; g < OSDL_K; ++g)
+                        mkn[g] = (g < ng) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro) : 0ull;
+                }
 #pragma clang loop unroll(disable)
                 for (int k = 0; k < RPT; ++k) {
                     const unsigned int ro = osdl_opaque((unsigned int)(tid + k * NT) * 8u);
-                    unsigned long long v[OSDL_CW];
+                    unsigned long long v[OSDL_CW], mks[OSDL_K];
 #pragma unroll
-                    for (int xx = 0; xx < OSDL_CW; ++xx)
-                        v[xx] = (xx < cw) ? OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) : 0ull;
-#pragma clang loop unroll(disable)
-                    for (int g = 0; g < ng; ++g) {
-                        const unsigned long long mk = OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro);
-                        const int ngrp = (gnp[g] + 3) >> 2;  // uniform
-                        // Half-wave skew: lanes 32-63 walk the nibbles in the order grp ^ 8, so the two halves of a
-                        // wave read different 128-byte tables in the same instruction (tools/microbench/lds_probe:
-                        // 3.45 -> 2.95 cycles per wave-level read).  Only when every batch of four nibbles is live.
-                        const bool skew = (ngrp > 12) && ((lane >> 5) & 1);
-                        const unsigned int lo = skew ? (unsigned int)(mk >> 32) : (unsigned int)mk;
-                        const unsigned int hi = skew ? (unsigned int)mk : (unsigned int)(mk >> 32);
-                        const int hq = skew ? 8 * OSDL_CW * 16 : 0;  // table-index distance between grp and grp ^ 8
+                    for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] = vn[xx];
+#pragma unroll
+                    for (int g = 0; g < OSDL_K; ++g) mks[g] = mkn[g];
+                    if (k + 1 < RPT) {
+                        const unsigned int rn = ro + NT * 8;
+#pragma unroll
+                        for (int xx = 0; xx < OSDL_CW; ++xx)
+                            vn[xx] = (xx < cw) ? OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, rn) : 0ull;
+#pragma unroll
+                        for (int g = 0; g < OSDL_K; ++g)
+                            mkn[g] = (g < ng) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, rn) : 0ull;
+                    }
+#pragma unroll
+                    for (int g = 0; g < OSDL_K; ++g) {
+                        if (g >= ng) break;  // uniform
+                        const unsigned long long mk = mks[g];
+                        const int ngrp = (gnp[g] + 4) / 5;  // uniform: live 5-bit fields
+                        // Half-wave skew: lanes 32-63 walk the fields in the rotated order (grp + 6) mod 13, so the two
+                        // halves of a wave read different tables in the same instruction (lds_probe: 3.45 -> 2.95
+                        // cycles per wave-level read).  Only when all 13 fields are live.
+                        const bool skew = (ngrp == OSDL_G5) && ((lane >> 5) & 1);
+                        constexpr int TS = OSDL_CW * 32;  // table stride (elements) between consecutive fields
+                        const int up = skew ? 6 * TS : 0, down = skew ? 7 * TS : 0;
                         // volatile LDS pointer: keeps the look-ups as single ds_read_b64 (hipcc would pair them
                         // into ds_read2_b64, which issues at half rate on gfx950 -- same finding as bp_kernel.hip.h;
                         // measured here: 855 -> 677 ms per 254 L29k eliminations)
-                        osdl_lds_ptr tb = (osdl_lds_ptr)(U + (size_t)g * 16 * OSDL_CW * 16);
+                        osdl_lds_ptr tb = (osdl_lds_ptr)(U + (size_t)g * OSDL_G5 * TS);
 #pragma unroll
-                        for (int qb = 0; qb < 4; ++qb) {
-                            if (qb * 4 < ngrp) {  // tables of the nibbles beyond the group's pivots are zero
+                        for (int qb = 0; qb < 3; ++qb) {
+                            if (qb * 4 < ngrp) {  // tables of the fields beyond the group's pivots are zero
 #pragma unroll
-                                for (int gg = 0; gg < 4; ++gg) {
-                                    const int grp = qb * 4 + gg;
-                                    const unsigned int nib = grp < 8 ? ((lo >> (4 * grp)) & 15u) : ((hi >> (4 * (grp - 8))) & 15u);
-                                    osdl_lds_ptr e = tb + grp * OSDL_CW * 16 + (int)nib + (grp < 8 ? hq : -hq);
+                                for (int grp = qb * 4; grp < (qb == 2 ? OSDL_G5 : qb * 4 + 4); ++grp) {
+                                    const int grp2 = grp < 7 ? grp + 6 : grp - 7;  // the skewed lanes' field
+                                    const unsigned int f1 = (unsigned int)(mk >> (5 * grp)) & 31u;
+                                    const unsigned int f2 = (unsigned int)(mk >> (5 * grp2)) & 31u;
+                                    const unsigned int nib = skew ? f2 : f1;
+                                    osdl_lds_ptr e = tb + grp * TS + (int)nib + (grp < 7 ? up : -down);
 #pragma unroll
-                                    for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] ^= e[xx * 16];
+                                    for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] ^= e[xx * 32];
                                 }
                             }
                         }
@@ -427,26 +476,56 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 // ------------ E3: pivot rows of the new group at its start state, for every later word.
                 // One wave per word, wave-private tables (a wave's LDS operations complete in order).
                 if (w + 1 < W) {
-                    volatile unsigned long long* tw = U + (size_t)wave * (OSDL_K - 1) * 256;
+                    typedef volatile __attribute__((address_space(3))) unsigned long long* lds_rw;
+                    lds_rw tw = (lds_rw)(U + (size_t)wave * (OSDL_K - 1) * 256);
                     const int row = (lane < npiv) ? grow[ng * 64 + lane] : 0;
                     unsigned long long mrow[OSDL_K - 1];
 #pragma unroll
                     for (int g = 0; g < OSDL_K - 1; ++g) mrow[g] = (g < ng && lane < npiv) ? TmO[(size_t)g * MRL + row] : 0ull;
-                    for (int x = w + 1 + wave; x < W; x += OSDL_NW) {
-                        for (int e = lane; e < ng * 256; e += 64) {
-                            const int idx = e & 15, grp = (e >> 4) & 15, g = e >> 8;
-                            unsigned long long v = 0ull;
-                            const int np = gnp[g] - 4 * grp;
-                            if (np > 0) {
-                                const unsigned long long* pr = PRO + ((size_t)g * W + x) * 64 + 4 * grp;
+                    // lane L < 16 * ng builds the 16-entry table of (group L >> 4, nibble L & 15) by a Gray-code walk
+                    // from its 4 pivot-row words; the inputs of the next word are requested before this word is
+                    // processed (the loop is otherwise bound by the latency of its own loads)
+                    const int tg = lane >> 4, tgrp = lane & 15;
+                    const bool builder = tg < ng;
+                    const int tnp = builder ? gnp[tg] - 4 * tgrp : 0;
+                    const int q0 = 4 * tgrp;
+                    unsigned long long prn[4], mvn;
+                    int x = w + 1 + wave;
+                    if (x < W) {
+                        const unsigned long long* src = PRO + ((size_t)(builder ? tg : 0) * W + x) * 64 + q0;
 #pragma unroll
-                                for (int kk = 0; kk < 4; ++kk)
-                                    if (((idx >> kk) & 1) && kk < np) v ^= pr[kk];
+                        for (int kk = 0; kk < 4; ++kk) prn[kk] = src[kk];
+                        mvn = M[(size_t)x * MRL + row];
+                    }
+                    for (; x < W; x += OSDL_NW) {
+                        unsigned long long pr[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) pr[kk] = (builder && kk < tnp) ? prn[kk] : 0ull;
+                        unsigned long long v = (lane < npiv) ? mvn : 0ull;
+                        const int xn = x + OSDL_NW;
+                        if (xn < W) {
+                            const unsigned long long* src = PRO + ((size_t)(builder ? tg : 0) * W + xn) * 64 + q0;
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) prn[kk] = src[kk];
+                            mvn = M[(size_t)xn * MRL + row];
+                        }
+                        if (builder) {
+                            unsigned int idx = osdl_opaque(((unsigned int)lane >> 1) & 15u);  // conflict-free start entries
+                            unsigned long long tv = 0ull;
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk)
+                                if ((idx >> kk) & 1u) tv ^= pr[kk];
+                            lds_rw tp = tw + lane * 16;
+                            tp[idx] = tv;
+#pragma unroll
+                            for (int i = 1; i < 16; ++i) {
+                                const int bit = (i & 1) ? 0 : ((i & 2) ? 1 : ((i & 4) ? 2 : 3));  // ctz(i)
+                                idx ^= 1u << bit;
+                                tv ^= pr[bit];
+                                tp[idx] = tv;
                             }
-                            tw[e] = v;
                         }
                         __builtin_amdgcn_wave_barrier();
-                        unsigned long long v = (lane < npiv) ? M[(size_t)x * MRL + row] : 0ull;
 #pragma unroll
                         for (int g = 0; g < OSDL_K - 1; ++g) {
                             if (g < ng) {
@@ -632,7 +711,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         OSDL_TICK(6);
 #ifdef BPOSD_OSD_DIAG
         if (P.dbg && slot_id == 0 && tid == 0)
-            for (int i = 0; i < 12; ++i) P.dbg[i] = tk[i];
+            for (int i = 0; i < 13; ++i) P.dbg[i] = tk[i];
 #endif
 #undef OSDL_TICK
 #undef OSDL_COUNT
