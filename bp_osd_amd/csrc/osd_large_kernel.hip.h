@@ -400,13 +400,15 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #pragma clang loop unroll(disable)
             for (;;) {
                 if (nrank >= P.rank) { done = true; break; }
-                int lb = 64, kb = 0;
+                // candidate columns of this lane = OR of its unused rows' panel words; lowest one is proposed
+                unsigned long long cand = 0ull;
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) {
-                    const unsigned long long cw = ((usedmask >> k) & 1u) ? 0ull : (pw[k] & vmask);
-                    const int l = cw ? (__ffsll((long long)cw) - 1) : 64;
-                    if (l < lb) { lb = l; kb = k; }
+                    const unsigned int um = (unsigned int)__builtin_amdgcn_sbfe((int)usedmask, k, 1);  // -1 if used
+                    cand |= pw[k] & ~(((unsigned long long)um << 32) | um);
                 }
+                cand &= vmask;
+                const int lb = cand ? (__ffsll((long long)cand) - 1) : 64;
                 unsigned long long act = ~0ull;
                 int col = 0;
 #pragma unroll
@@ -415,6 +417,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     if (z) act = z; else col |= (1 << bitp);
                 }
                 const int first = __ffsll((long long)act) - 1;
+                // the proposing lane's row: any unused row of its with a one in column lb (the pivot set does not
+                // depend on which row is taken)
+                int kb = 0;
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const bool hit = (((pw[k] >> (lb & 63)) & 1ull) != 0ull) && (((usedmask >> k) & 1u) == 0u);
+                    kb = hit ? k : kb;
+                }
                 if (lane == first) {
                     unsigned long long a = 0ull, c = 0ull;
 #pragma unroll
@@ -434,22 +444,25 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 if (mincol >= 64) { par ^= 1; break; }
                 const unsigned long long pw_p = pbuf[(size_t)(par * OSDL_NW + wv) * 2 + 0];
                 const unsigned long long t_p = pbuf[(size_t)(par * OSDL_NW + wv) * 2 + 1];
-                const unsigned long long bmask = 1ull << mincol;
-                const unsigned long long qbit = 1ull << npiv;
+                const unsigned long long tq = t_p ^ (1ull << npiv);
                 const int j = w * 64 + mincol;
+                // every row with a one in the pivot column adds the pivot row (branch-free: mask = -bit); the pivot
+                // row itself is put back afterwards by the one lane that owns it
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) {
-                    const bool is_pivot = (wave == wv) && (lane == first) && (k == kb) && (col == mincol);
-                    if (is_pivot) {
-                        usedmask |= 1u << k;
-                        const int r = tid + k * NT;
-                        pivrow[j] = r;
-                        rowpos[r] = j;
-                        grow[ng * 64 + npiv] = r;
-                    } else if (pw[k] & bmask) {
-                        pw[k] ^= pw_p;
-                        t[k] ^= t_p ^ qbit;
-                    }
+                    const unsigned long long mm = (unsigned long long)((long long)(pw[k] << (63 - mincol)) >> 63);
+                    pw[k] ^= pw_p & mm;
+                    t[k] ^= tq & mm;
+                }
+                if (wave == wv && lane == first) {
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k)
+                        if (k == kb) { pw[k] = pw_p; t[k] = t_p; }
+                    usedmask |= 1u << kb;
+                    const int r = tid + kb * NT;
+                    pivrow[j] = r;
+                    rowpos[r] = j;
+                    grow[ng * 64 + npiv] = r;
                 }
                 ++npiv;
                 ++nrank;
