@@ -590,3 +590,29 @@ def test_l29k_golden(gpu_ready, name):
     assert (dec.batch_bp == np.unpackbits(g["bp"], axis=1)[:, :n]).all()
     assert (dec.batch_osd0 == np.unpackbits(g["osd0"], axis=1)[:, :n]).all()
     assert (out == np.unpackbits(g["osdw"], axis=1)[:, :n]).all()
+
+
+def test_large_code_limits_and_nonuniform_channel(gpu_ready, hgp4050):
+    """What the HBM-resident path refuses (loudly) and what it still does with a non-uniform channel."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = hgp4050.hz
+    n = H.shape[1]
+    with pytest.raises(ValueError):
+        BpOsdDecoder(H, error_rate=0.05, max_iter=4, bp_method="ms", osd_method="osd_cs", osd_order=17)
+    rng = np.random.default_rng(7)
+    probs = rng.uniform(0.03, 0.09, n)
+    _, syn = _syndromes(H, 0.07, 6, 31)
+    # OSD-0 needs no candidate weights: a per-bit channel is fine and exact (priors drive BP and the column order)
+    kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_0", osd_order=0)
+    g = BpOsdDecoder(H, **kw)
+    _compare_exact(_gpu_decode(g, syn), OracleDecoder(H, **kw).decode_batch(syn))
+    # OSD-E with fp64 index-order weights is not built for this path: refused at decode time, never approximated
+    g = BpOsdDecoder(H, channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=4)
+    with pytest.raises(ValueError):
+        g.decode_batch(syn)
+    # ... unless the caller asks for Hamming weights, which is what this path computes
+    kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=4, weight_fn=1)
+    g = BpOsdDecoder(H, **kw)
+    _compare_exact(_gpu_decode(g, syn), OracleDecoder(H, **kw).decode_batch(syn))
