@@ -1,0 +1,328 @@
+// bp_local_kernel.hip.h -- min-sum BP for (3,6)-regular codes with one third of the messages kept in registers.
+//
+// bp_kernel.hip.h moves every message through LDS twice per iteration (check -> bit, bit -> check) and is
+// bound by LDS bandwidth (ds_write_b64 6.1 cycles, ds_read_b64 2.95 cycles per wave -- tools/microbench).
+// For a code with check degree 6, bit degree 3 and n = 2m the host finds an assignment "every check OWNS two
+// of its six neighbouring bits, every bit is owned by exactly one check" (a perfect b-matching; it exists for
+// every (3,6)-biregular graph).  The thread that runs a check also runs its two owned bits, so the message on
+// the edge (check, owned bit) never leaves that thread's registers: 2 of a check's 6 edges and 1 of a bit's 3
+// edges are LOCAL; LDS carries 4m instead of 6m messages (32 instead of 48 bytes per check and direction).
+//
+// Exactness.  The min-sum check update is order-independent (exact minima of the other five magnitudes, sign
+// parity), so a check may list its two local edges last.  The bit update is NOT (fp64 sums: prefix from the
+// top of the column including the prior, suffix from the bottom -- SURVEY.md Appendix A.3), so the local
+// message has to enter the sums at the position dl in {0,1,2} its check has among the bit's three checks in
+// ascending order.  The host therefore sorts checks into 64-position groups (a wave = one group per owned
+// check) whose slot-b bits share one dl wherever it can; the kernel switches on the wave-uniform code
+// (0, 1, 2: straight-line code, instruction for instruction the arithmetic of bp_kernel; 3: a mixed group, the
+// operands are routed by per-lane selects).  The position count MP is a compile-time power of two, as in
+// bp_kernel, so LDS offsets are instruction immediates.
+//
+// Everything else -- persistent workgroups on an atomic queue, in-place messages, incremental convergence
+// bitmap with a speculative check pass, outputs, OSD hand-off -- is the scheme of bp_kernel.hip.h (rows a3-a7).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bp_kernel.hip.h"
+
+namespace bposd {
+
+struct BpLocalParams {
+    int m, n;
+    long long B;
+    int max_iter;
+    double ms_scaling;
+    int osd_enabled;
+    int mp;                               // positions = blockDim.x * CPT (multiple of 64)
+    const uint8_t* __restrict__ synd;     // [B, m]
+    const double* __restrict__ llr0;      // [n]
+    const uint8_t* __restrict__ sel;      // [B, n] nullable
+    const double* __restrict__ llr0_alt;  // [n]
+    const int* __restrict__ pos_chk;      // [mp]      check at position p, -1 = padding
+    const int* __restrict__ pos_bit;      // [2 * mp]  entry b*mp + p: b-th owned bit of position p, -1 = padding
+    const int* __restrict__ pos_alo;      // [2 * mp]  LDS slot (k * mp + p') of the bit's non-local edge to its lower check
+    const int* __restrict__ pos_ahi;      // [2 * mp]  ... to its higher check
+    const int* __restrict__ pos_dl;       // [2 * mp]  position dl of the owner among the bit's three checks
+    const int* __restrict__ grp_dl;       // [2 * mp / 64]  entry b*(mp/64) + g: dl if the whole group shares it, else 3
+    uint8_t* __restrict__ out_bp;
+    uint8_t* __restrict__ out_osd0;
+    uint8_t* __restrict__ out_osdw;
+    uint8_t* __restrict__ out_conv;
+    int* __restrict__ out_iters;
+    double* __restrict__ out_llr;
+    double* __restrict__ llr_ws;
+    int* __restrict__ osd_list;
+    int* __restrict__ counters;
+    unsigned long long* __restrict__ iter_total;
+};
+
+__host__ __device__ inline size_t bp_local_lds_bytes(int mp) {
+    // 4 LDS edges per position (+ dummy slot) + mismatch bitmap + control words
+    return ((size_t)4 * mp + 2) * 8 + (size_t)(mp / 32 + 2) * 4 + 8 * 4;
+}
+
+// the three orders in which the register-resident message R and the two LDS messages X (lower check), Y (higher
+// check) enter a bit's sums
+template <int DL>
+__device__ __forceinline__ void bit_update(double l0, double R, double X, double Y, double& llr, double& oR, double& oX,
+                                           double& oY) {
+    const double c0 = DL == 0 ? R : X;
+    const double c1 = DL == 0 ? X : (DL == 1 ? R : Y);
+    const double c2 = DL == 2 ? R : Y;
+    double t = l0;
+    const double pre0 = t;  // prefix from the top of the column (prior included)
+    t += c0;
+    const double pre1 = t;
+    t += c1;
+    const double pre2 = t;
+    t += c2;
+    llr = t;
+    double suf = 0.0;  // suffix from the bottom of the column
+    const double o2 = pre2 + suf;
+    suf += c2;
+    const double o1 = pre1 + suf;
+    suf += c1;
+    const double o0 = pre0 + suf;
+    oR = DL == 0 ? o0 : (DL == 1 ? o1 : o2);
+    oX = DL == 0 ? o1 : o0;
+    oY = DL == 2 ? o1 : o2;
+}
+
+// mixed group: the same sums with the operands routed per lane
+__device__ __forceinline__ void bit_update_mixed(int dlv, double l0, double R, double X, double Y, double& llr, double& oR,
+                                                 double& oX, double& oY) {
+    const bool d0 = dlv == 0, d1 = dlv == 1, d2 = dlv == 2;
+    const double c0 = d0 ? R : X;
+    const double c1 = d0 ? X : (d1 ? R : Y);
+    const double c2 = d2 ? R : Y;
+    double t = l0;
+    const double pre0 = t;
+    t += c0;
+    const double pre1 = t;
+    t += c1;
+    const double pre2 = t;
+    t += c2;
+    llr = t;
+    double suf = 0.0;
+    const double o2 = pre2 + suf;
+    suf += c2;
+    const double o1 = pre1 + suf;
+    suf += c1;
+    const double o0 = pre0 + suf;
+    oR = d0 ? o0 : (d1 ? o1 : o2);
+    oX = d0 ? o1 : o0;
+    oY = d2 ? o1 : o2;
+}
+
+// CPT: checks per thread (each with its two owned bits); MPT: positions (power of two) = blockDim.x * CPT
+template <int CPT, int MPT, int MINW>
+__global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocalParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m = P.m, n = P.n;
+    constexpr int NT = MPT / CPT;
+    constexpr int MP = MPT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    constexpr int NB = 2 * CPT;  // owned bits per thread
+
+    double* msg_plain = reinterpret_cast<double*>(smem);
+    msg_ptr msg = (msg_ptr)msg_plain;
+    unsigned int* diffw = reinterpret_cast<unsigned int*>(msg_plain + (size_t)4 * MP + 2);
+    int* sh = reinterpret_cast<int*>(diffw + (MP / 32 + 2));
+
+    // ---- per-thread graph tables
+    int alo[NB], ahi[NB], dl[NB];
+    unsigned int dlpack = 0u;  // 2 bits per owned bit: its dl (needed per lane only in mixed groups)
+    bool bvalid[NB];
+    double l0[NB];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int p = tid + j * NT;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r = 2 * j + b;
+            const int bit = P.pos_bit[b * MP + p];
+            bvalid[r] = bit >= 0;
+            l0[r] = bvalid[r] ? P.llr0[bit] : 1.0;
+            alo[r] = P.pos_alo[b * MP + p];  // padding points at the dummy slot 4 * MP
+            ahi[r] = P.pos_ahi[b * MP + p];
+            dl[r] = __builtin_amdgcn_readfirstlane(P.grp_dl[b * (MP >> 6) + (p >> 6)]);  // uniform per wave
+            dlpack |= (unsigned int)P.pos_dl[b * MP + p] << (2 * r);
+        }
+    }
+
+    for (;;) {
+        if (tid == 0) {
+            sh[0] = 0;
+            sh[1] = 0;
+            sh[2] = atomicAdd(&P.counters[0], 1);
+        }
+        __syncthreads();
+        const long long s = sh[2];
+        if (s >= P.B) break;
+
+        // ---- syndrome bits of my checks; the mismatch bitmap (indexed by position) starts as the syndrome
+        bool sbit[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int p = tid + j * NT;
+            const int c = P.pos_chk[p];
+            sbit[j] = (c >= 0) ? ((P.synd[(size_t)s * m + c] & 1) != 0) : false;
+            const unsigned long long bal = __ballot(sbit[j]);
+            if (lane == 0) {
+                const int w0 = (p >> 5);  // p is a multiple of 64 for lane 0
+                diffw[w0] = (unsigned int)bal;
+                diffw[w0 + 1] = (unsigned int)(bal >> 32);
+                if (bal) sh[0] = 1;
+            }
+        }
+        if (P.sel) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int i = P.pos_bit[b * MP + tid + j * NT];
+                    if (i >= 0) l0[2 * j + b] = P.sel[(size_t)s * n + i] ? P.llr0_alt[i] : P.llr0[i];
+                }
+        }
+        // ---- a3: every edge's bit->check message starts at the prior (two in LDS, one in a register)
+        double llr[NB], loc[NB];
+        unsigned int decmask = 0u;  // bit r: hard decision of my r-th bit
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            llr[r] = l0[r];
+            loc[r] = l0[r];
+            msg[alo[r]] = l0[r];
+            msg[ahi[r]] = l0[r];
+        }
+        __syncthreads();
+
+        int it_done = 0;
+        bool conv = (sh[0] == 0);
+        if (!conv) {
+#pragma clang loop unroll(disable)
+            for (int it = 1;; ++it) {
+                const int fi = it & 1;
+                {
+                    bool mis = false;
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j) {
+                        const int p = tid + j * NT;
+                        mis |= ((diffw[p >> 5] >> (p & 31)) & 1u) != 0;
+                    }
+                    const unsigned long long anym = __ballot(mis);
+                    if (lane == 0 && anym) sh[fi] = 1;
+                }
+                if (it > P.max_iter) {
+                    __syncthreads();
+                    conv = (sh[fi] == 0);
+                    it_done = P.max_iter;
+                    break;
+                }
+                // =================== check -> bit pass (a4), speculative for it >= 2 ===========
+                const double alpha = alpha_for_iteration(P.ms_scaling, it);
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    msg_ptr mc = msg + (tid + j * NT);
+                    double v[6];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = mc[k * MP];
+                    v[4] = loc[2 * j];
+                    v[5] = loc[2 * j + 1];
+                    bool neg[6];
+                    bool par = sbit[j];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        neg[k] = (v[k] <= 0.0);
+                        par ^= neg[k];
+                    }
+                    double pre[6], suf[6];
+                    pre[0] = __DBL_MAX__;
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) pre[k] = min_abs(pre[k - 1], v[k - 1]);
+                    suf[5] = __DBL_MAX__;
+#pragma unroll
+                    for (int k = 4; k >= 0; --k) suf[k] = min_abs(suf[k + 1], v[k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const double mag = (k == 0) ? suf[0] : (k == 5 ? pre[5] : min_pos(pre[k], suf[k]));
+                        const double o = flip_sign(mag * alpha, par ^ neg[k]);
+                        if (k < 4) mc[k * MP] = o;
+                        else loc[2 * j + (k - 4)] = o;
+                    }
+                }
+                __syncthreads();
+                if (sh[fi] == 0) {
+                    conv = true;
+                    it_done = it - 1;
+                    break;
+                }
+                if (tid == 0) sh[fi ^ 1] = 0;
+                // ============ bit pass: posterior, decision, bit -> check (a6 / a7) ============
+                double X[NB], Y[NB];
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    X[r] = msg[alo[r]];
+                    Y[r] = msg[ahi[r]];
+                }
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    double oR, oX, oY;
+                    if (dl[r] == 0) bit_update<0>(l0[r], loc[r], X[r], Y[r], llr[r], oR, oX, oY);
+                    else if (dl[r] == 1) bit_update<1>(l0[r], loc[r], X[r], Y[r], llr[r], oR, oX, oY);
+                    else if (dl[r] == 2) bit_update<2>(l0[r], loc[r], X[r], Y[r], llr[r], oR, oX, oY);
+                    else bit_update_mixed((int)((dlpack >> (2 * r)) & 3u), l0[r], loc[r], X[r], Y[r], llr[r], oR, oX, oY);
+                    loc[r] = oR;
+                    msg[alo[r]] = oX;
+                    msg[ahi[r]] = oY;
+                    const unsigned int dnew = (llr[r] <= 0.0) ? 1u : 0u;
+                    if (bvalid[r] && dnew != ((decmask >> r) & 1u)) {
+                        decmask ^= 1u << r;
+                        int pa = alo[r], pb = ahi[r];
+                        asm volatile("" : "+v"(pa), "+v"(pb));  // keep the rare path's address arithmetic in the branch
+                        const int ca = pa & (MP - 1), cb = pb & (MP - 1), co = tid + (r >> 1) * NT;  // slot = k * MP + position
+                        atomicXor(&diffw[ca >> 5], 1u << (ca & 31));
+                        atomicXor(&diffw[cb >> 5], 1u << (cb & 31));
+                        atomicXor(&diffw[co >> 5], 1u << (co & 31));
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- results
+        const bool to_osd = (!conv) && P.osd_enabled;
+        if (tid == 0) {
+            if (to_osd) {
+                const int slot = atomicAdd(&P.counters[1], 1);
+                P.osd_list[slot] = (int)s;
+                sh[3] = slot;
+            }
+            if (P.out_conv) P.out_conv[s] = conv ? 1 : 0;
+            if (P.out_iters) P.out_iters[s] = it_done;
+            if (it_done) atomicAdd(P.iter_total, (unsigned long long)it_done);
+        }
+        __syncthreads();
+        const int slot = to_osd ? sh[3] : 0;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            const int i = P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT];
+            if (i >= 0) {
+                const size_t o = (size_t)s * n + i;
+                const uint8_t b = (uint8_t)((decmask >> r) & 1u);
+                if (P.out_bp) P.out_bp[o] = b;
+                if (!to_osd) {
+                    P.out_osdw[o] = b;
+                    if (P.out_osd0) P.out_osd0[o] = b;
+                } else {
+                    P.llr_ws[(size_t)slot * n + i] = llr[r];
+                }
+                if (P.out_llr) P.out_llr[o] = llr[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace bposd

@@ -18,10 +18,12 @@
 #include <climits>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "bp_kernel.hip.h"
 #include "bp_large_kernel.hip.h"
+#include "bp_local_kernel.hip.h"
 #include "osd_large_kernel.hip.h"
 #include "osd_kernel.hip.h"
 
@@ -48,6 +50,11 @@ struct bposd_handle {
     int m = 0, n = 0, E = 0;
     int dc_max = 0, dv_max = 0;
     bool regular = false;
+    // local-edge BP kernel (bp_local_kernel.hip.h): available for (3,6)-regular codes with n = 2m, min-sum
+    bool local_ok = false;
+    int local_mp = 0, local_nt = 0;
+    long long local_cost0 = 0, local_cost = 0;  // simulated LDS passes of the bit pass before / after the layout search
+    int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
     bool large = false;  // beyond the LDS-resident kernels: HBM-resident messages / matrix
     DevBuf bpl_msg, bpl_llr;  // large BP workspaces
     DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
@@ -437,6 +444,252 @@ int launch_bp(bposd_handle* h, BpParams& P) {
     return fail(h, BPOSD_ERR_UNSUPPORTED, "no BP kernel for check degree %d / bit degree %d", h->dc_max, h->dv_max);
 }
 
+// ------------------------------------------------------------------ local-edge BP kernel: tables + launch
+// Every check owns two of its six bits (perfect b-matching, Kuhn's augmenting paths with capacity 2); checks are
+// grouped into 64-position groups whose slot-b bits share the position dl of the owner among the bit's checks.
+int build_tables_local(bposd_handle* h) {
+    h->local_ok = false;
+    const int m = h->m, n = h->n;
+    if (!(h->regular && h->dc_max == 6 && h->dv_max == 3 && n == 2 * m)) return 0;
+    // column lists (ascending check index: rows are visited in order)
+    std::vector<int> cols(3 * (size_t)n);
+    {
+        std::vector<int> fill(n, 0);
+        for (int c = 0; c < m; ++c)
+            for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
+                const int i = h->ci[e];
+                cols[3 * (size_t)i + fill[i]++] = c;
+            }
+    }
+    std::vector<int> owner(n, -1), load(2 * (size_t)m, -1);  // load[2c + s] = bit in slot s of check c
+    auto cnt = [&](int c) { return (load[2 * c] >= 0) + (load[2 * c + 1] >= 0); };
+    auto put = [&](int c, int i) { (load[2 * c] < 0 ? load[2 * c] : load[2 * c + 1]) = i; owner[i] = c; };
+    auto drop = [&](int c, int i) { if (load[2 * c] == i) load[2 * c] = -1; else load[2 * c + 1] = -1; };
+    std::vector<int> seen(m, -1);
+    // iterative DFS over alternating paths: place(i) tries the checks of bit i, evicting a current owner's bit
+    std::function<bool(int, int)> place = [&](int i, int stamp) -> bool {
+        for (int d = 0; d < 3; ++d) {
+            const int c = cols[3 * (size_t)i + d];
+            if (seen[c] == stamp) continue;
+            seen[c] = stamp;
+            if (cnt(c) < 2) { put(c, i); return true; }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int j = load[2 * c + s2];
+                // move j elsewhere
+                drop(c, j);
+                owner[j] = -1;
+                if (place(j, stamp)) { put(c, i); return true; }
+                load[2 * c + s2] = j;
+                owner[j] = c;
+            }
+        }
+        return false;
+    };
+    for (int i = 0; i < n; ++i)
+        if (!place(i, i)) return 0;  // no perfect assignment: the generic kernel is used
+    for (int c = 0; c < m; ++c)
+        if (cnt(c) != 2) return 0;
+    auto dl_of = [&](int i) { const int c = owner[i]; return cols[3 * (size_t)i] == c ? 0 : (cols[3 * (size_t)i + 1] == c ? 1 : 2); };
+    // canonical slot order per check: (dl0 <= dl1); classes = ordered pairs.  Full groups of 64 checks of one class
+    // are uniform (code dl); what is left over of every class shares mixed groups (code 3), sorted by (dl0, dl1) so
+    // that a slot of a mixed group is still uniform where possible.
+    std::vector<std::vector<int>> cls(9);
+    for (int c = 0; c < m; ++c) {
+        int a = load[2 * c], b = load[2 * c + 1];
+        if (dl_of(a) > dl_of(b)) { std::swap(a, b); load[2 * c] = a; load[2 * c + 1] = b; }
+        cls[dl_of(a) * 3 + dl_of(b)].push_back(c);
+    }
+    const int MP = 1024;  // the kernels are compiled for 1024 positions (H1922: 961 checks)
+    if (m > MP) return 0;
+    const int G = MP / 64;
+    std::vector<int> order;  // checks in position order
+    order.reserve(m);
+    std::vector<int> rest;
+    for (int k = 0; k < 9; ++k) {
+        const size_t full = cls[k].size() / 64 * 64;
+        order.insert(order.end(), cls[k].begin(), cls[k].begin() + full);
+        rest.insert(rest.end(), cls[k].begin() + full, cls[k].end());  // already ordered by class
+    }
+    order.insert(order.end(), rest.begin(), rest.end());
+    std::vector<int> pos_chk(MP, -1), pos_of(m, -1), grp_dl(2 * (size_t)G, 0);
+    for (int p = 0; p < m; ++p) {
+        pos_chk[p] = order[p];
+        pos_of[order[p]] = p;
+    }
+    // ---- bank-conflict hill climbing.  The bit pass gathers / scatters the two non-local messages of every owned
+    // bit at slot k * MP + position(other check): bank pair = position mod 32, and a half-wave (32 consecutive
+    // positions) is served in max-multiplicity passes.  Swapping two checks of one class between uniform groups,
+    // or any two checks inside one group / inside the mixed region, keeps the group codes; accept what does not
+    // raise the simulated pass count (random layout ~3.1 passes per access, after the search ~1.9; ideal 1).
+    {
+        auto key = [&](int c) { return dl_of(load[2 * c]) * 3 + dl_of(load[2 * c + 1]); };
+        const int nfull = (int)(order.size() - rest.size());  // positions [0, nfull) are uniform groups
+        std::vector<int> tgt(4 * (size_t)m);                  // [c][b][s]: the other two checks of owned bit b
+        std::vector<std::vector<int>> users(m);               // checks whose accesses land on c, encoded 4*c' + 2*b + s
+        for (int c = 0; c < m; ++c)
+            for (int b = 0; b < 2; ++b) {
+                const int i = load[2 * c + b];
+                int no = 0;
+                for (int d = 0; d < 3; ++d) {
+                    const int o = cols[3 * (size_t)i + d];
+                    if (o == c) continue;
+                    tgt[4 * (size_t)c + 2 * b + no] = o;
+                    users[o].push_back(4 * c + 2 * b + no);
+                    ++no;
+                }
+            }
+        auto hw_cost = [&](int hw, int bs) {
+            int cnt[32] = {0}, mx = 1;
+            for (int p = 32 * hw; p < 32 * hw + 32; ++p) {
+                const int c = pos_chk[p];
+                if (c < 0) continue;
+                const int r = pos_of[tgt[4 * (size_t)c + bs]] & 31;
+                if (++cnt[r] > mx) mx = cnt[r];
+            }
+            return mx;
+        };
+        std::vector<int> touched;
+        auto collect = [&](int c) {
+            const int hw = pos_of[c] >> 5;
+            for (int bs = 0; bs < 4; ++bs) touched.push_back(hw * 4 + bs);
+            for (int u : users[c]) touched.push_back((pos_of[u >> 2] >> 5) * 4 + (u & 3));
+        };
+        auto cost_of = [&]() {
+            std::sort(touched.begin(), touched.end());
+            touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+            int t = 0;
+            for (int e : touched) t += hw_cost(e >> 2, e & 3);
+            return t;
+        };
+        unsigned long long rs = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&](int mod) {
+            rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+            return (int)((rs >> 11) % (unsigned long long)mod);
+        };
+        long long total = 0;
+        for (int hw = 0; hw < MP / 32; ++hw)
+            for (int bs = 0; bs < 4; ++bs) total += hw_cost(hw, bs);
+        const long long start_cost = total;
+        const int iters = 400000;
+        for (int it = 0; it < iters; ++it) {
+            const int c1 = pos_chk[rnd(m)];
+            int c2;
+            const int p1 = pos_of[c1];
+            if (p1 < nfull) {
+                if (rnd(4) == 0) {
+                    c2 = pos_chk[(p1 & ~63) + rnd(64)];  // same group
+                } else {
+                    c2 = pos_chk[rnd(nfull)];             // another uniform position: must be the same class
+                    if (key(c2) != key(c1)) continue;
+                }
+            } else {
+                c2 = pos_chk[nfull + rnd(m - nfull)];     // mixed region: anything goes (codes are recomputed below)
+            }
+            if (c2 < 0 || c2 == c1) continue;
+            touched.clear();
+            collect(c1);
+            collect(c2);
+            const int p2 = pos_of[c2];
+            // the streams touched after the swap are the same set with the two positions exchanged
+            for (int bs = 0; bs < 4; ++bs) { touched.push_back((p1 >> 5) * 4 + bs); touched.push_back((p2 >> 5) * 4 + bs); }
+            const int before = cost_of();
+            pos_of[c1] = p2; pos_of[c2] = p1; pos_chk[p1] = c2; pos_chk[p2] = c1;
+            const int after = cost_of();
+            if (after > before) { pos_of[c1] = p1; pos_of[c2] = p2; pos_chk[p1] = c1; pos_chk[p2] = c2; }
+            else total += after - before;
+        }
+        h->local_cost0 = start_cost;
+        h->local_cost = total;
+        if (getenv("BPOSD_DEBUG_OCC"))
+            fprintf(stderr, "[bposd] local-edge layout: simulated LDS passes %lld -> %lld (ideal %d)\n", start_cost, total, 4 * (MP / 32));
+    }
+    for (int g = 0; g < G; ++g)
+        for (int b = 0; b < 2; ++b) {
+            int code = -1;
+            for (int p = 64 * g; p < 64 * g + 64 && p < m; ++p) {
+                const int d = dl_of(load[2 * pos_chk[p] + b]);
+                code = (code < 0 || code == d) ? d : 3;
+            }
+            grp_dl[(size_t)b * G + g] = code < 0 ? 0 : code;
+        }
+    const int NT = 512;
+    // LDS slot of (check c, bit i) for the check's four non-local edges, ascending column order
+    auto slot_of = [&](int c, int i) {
+        int k = 0;
+        for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
+            const int j = h->ci[e];
+            if (owner[j] == c) continue;
+            if (j == i) return k * MP + pos_of[c];
+            ++k;
+        }
+        return -1;
+    };
+    std::vector<int> pos_bit(2 * (size_t)MP, -1), pos_alo(2 * (size_t)MP, 4 * MP), pos_ahi(2 * (size_t)MP, 4 * MP), pos_dl(2 * (size_t)MP, 0);
+    for (int c = 0; c < m; ++c) {
+        const int p = pos_of[c];
+        for (int b = 0; b < 2; ++b) {
+            const int i = load[2 * c + b];
+            int other[2], no = 0;
+            for (int d = 0; d < 3; ++d)
+                if (cols[3 * (size_t)i + d] != c) other[no++] = cols[3 * (size_t)i + d];
+            const int lo = slot_of(other[0], i), hi = slot_of(other[1], i);
+            if (no != 2 || lo < 0 || hi < 0) return 0;
+            pos_dl[(size_t)b * MP + p] = dl_of(i);
+            pos_bit[(size_t)b * MP + p] = i;
+            pos_alo[(size_t)b * MP + p] = lo;
+            pos_ahi[(size_t)b * MP + p] = hi;
+        }
+    }
+    auto up = [&](int** dst, const std::vector<int>& v) -> int {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        HIP_TRY(h, hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1)));
+        HIP_TRY(h, hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc;
+    if ((rc = up(&h->d_lpos_chk, pos_chk))) return rc;
+    if ((rc = up(&h->d_lpos_bit, pos_bit))) return rc;
+    if ((rc = up(&h->d_lpos_alo, pos_alo))) return rc;
+    if ((rc = up(&h->d_lpos_ahi, pos_ahi))) return rc;
+    if ((rc = up(&h->d_lgrp_dl, grp_dl))) return rc;
+    if ((rc = up(&h->d_lpos_dl, pos_dl))) return rc;
+    h->local_mp = MP;
+    h->local_nt = NT;
+    h->local_ok = true;
+    return 0;
+}
+
+template <int CPT, int MINW>
+int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
+    auto k = bp_local_kernel<CPT, 1024, MINW>;
+    const int nt = 1024 / CPT;
+    const size_t lds = bp_local_lds_bytes(L.mp);
+    HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int wg_per_cu = 1;
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void*)k, nt, lds));
+    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] local-edge BP kernel: %d threads, %zu B LDS, %d workgroups per CU\n", nt, lds, wg_per_cu);
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
+    long long grid = std::min<long long>(L.B, (long long)h->num_cu * wg_per_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->stream, L);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_bp_local(bposd_handle* h, const BpParams& P) {
+    BpLocalParams L{};
+    L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling; L.osd_enabled = P.osd_enabled;
+    L.mp = h->local_mp;
+    L.synd = P.synd; L.llr0 = P.llr0; L.sel = P.sel; L.llr0_alt = P.llr0_alt;
+    L.pos_chk = h->d_lpos_chk; L.pos_bit = h->d_lpos_bit; L.pos_alo = h->d_lpos_alo; L.pos_ahi = h->d_lpos_ahi;
+    L.grp_dl = h->d_lgrp_dl; L.pos_dl = h->d_lpos_dl;
+    L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv; L.out_iters = P.out_iters;
+    L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list; L.counters = P.counters; L.iter_total = P.iter_total;
+    if (h->bp_variant == 17) return launch_bp_local_t<2, 8>(h, L);   // 512 threads, <= 64 VGPRs: 4 workgroups per CU
+    if (h->bp_variant == 18) return launch_bp_local_t<1, 8>(h, L);   // 1024 threads, <= 64 VGPRs: 2 workgroups per CU
+    return launch_bp_local_t<2, 6>(h, L);                            // 512 threads, <= 80 VGPRs: 3 workgroups per CU
+}
+
 // ------------------------------------------------------------------------ large-code BP launch
 int build_tables_large(bposd_handle* h, int DV, int MP) {
     const int m = h->m, n = h->n;
@@ -682,7 +935,8 @@ void bposd_destroy(bposd_handle* h) {
         release(*b);
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
                     (void*)h->d_var_pos, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt, (void*)h->d_counters,
-                    (void*)h->d_iter_total, (void*)h->d_osd_dbg})
+                    (void*)h->d_iter_total, (void*)h->d_osd_dbg, (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
+                    (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl})
         if (p) (void)hipFree(p);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->h_iter_total) (void)hipHostFree(h->h_iter_total);
@@ -851,6 +1105,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     if (h->large) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
     else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, pick_shape(h)) * pick_shape(h),
                                 shape_threads(h, pick_shape(h)), 2 * pick_shape(h)));
+    if (!h->large && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
     CREATE_RC(upload_priors(h));
     if (h->large) {
         CREATE_RC(probe_rank_large(h, &h->rank));
@@ -881,8 +1136,10 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4)
-        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0, 1, 2 or 4");
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 16 && variant != 17 && variant != 18)
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes) or 16, 17, 18 (local-edge kernel)");
+    if (variant >= 16 && !(h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM))
+        return fail(h, BPOSD_ERR_UNSUPPORTED, "the local-edge BP kernel needs a (3,6)-regular code with n = 2m and min-sum");
     h->bp_variant = variant;
     return BPOSD_OK;
 }
@@ -981,6 +1238,8 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         L.out_iters = P.out_iters; L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list;
         L.counters = P.counters; L.iter_total = P.iter_total;
         if ((rc = launch_bp_large(h, L))) return rc;
+    } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || h->bp_variant >= 16)) {
+        if ((rc = launch_bp_local(h, P))) return rc;
     } else if ((rc = launch_bp(h, P))) return rc;
     HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
     h->ran_osd = false;

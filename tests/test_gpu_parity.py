@@ -616,3 +616,35 @@ def test_large_code_limits_and_nonuniform_channel(gpu_ready, hgp4050):
     kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=4, weight_fn=1)
     g = BpOsdDecoder(H, **kw)
     _compare_exact(_gpu_decode(g, syn), OracleDecoder(H, **kw).decode_batch(syn))
+
+
+@pytest.mark.parametrize("side", ["hz", "hx"])
+def test_local_edge_kernel_equals_lds_kernel(gpu_ready, h1922, side):
+    """The (3,6)-regular codes run by default on the local-edge BP kernel (one message in three stays in registers);
+    it must reproduce the LDS kernel (variant 2) and the oracle bit for bit, LLRs included, also with per-shot priors."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = getattr(h1922, side)
+    q = 0.06
+    _, syn = _syndromes(H, q, 3000, 77)
+    kw = dict(error_rate=q, max_iter=25, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_cs", osd_order=5)
+    a = BpOsdDecoder(H, **kw)            # auto: local-edge kernel
+    b = BpOsdDecoder(H, **kw)
+    b.set_bp_variant(2)                  # LDS kernel, 512 threads
+    c = BpOsdDecoder(H, **kw)
+    c.set_bp_variant(18)                 # local-edge kernel, one check per thread
+    ra, rb, rc = _gpu_decode(a, syn), _gpu_decode(b, syn), _gpu_decode(c, syn)
+    for r in (rb, rc):
+        for k in ("osdw", "osd0", "bp", "converged", "iters"):
+            assert (ra[k] == r[k]).all(), k
+        assert (ra["llr"].view(np.uint64) == r["llr"].view(np.uint64)).all()
+    _compare_exact({k: v[:400] for k, v in ra.items()}, OracleDecoder(H, **kw).decode_batch(syn[:400]))
+    # per-shot two-valued channel through the same kernel
+    rng = np.random.default_rng(5)
+    sel = (rng.random((256, H.shape[1])) < 0.3).astype(np.uint8)
+    alt = np.full(H.shape[1], 0.11)
+    oa = a.decode_batch(syn[:256], prior_select=sel, alt_channel_probs=alt, want_llr=True)
+    la = a.batch_llr.copy()
+    ob = b.decode_batch(syn[:256], prior_select=sel, alt_channel_probs=alt, want_llr=True)
+    assert (oa == ob).all() and (la.view(np.uint64) == b.batch_llr.view(np.uint64)).all()
