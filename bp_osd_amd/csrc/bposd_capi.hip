@@ -489,6 +489,87 @@ int build_tables_local(bposd_handle* h) {
         if (!place(i, i)) return 0;  // no perfect assignment: the generic kernel is used
     for (int c = 0; c < m; ++c)
         if (cnt(c) != 2) return 0;
+    // ---- candidate assignments.  Which perfect assignment is taken decides how many checks share a class (uniform
+    // groups) and how regular the bit pass's LDS accesses are.  For two-block codes (hypergraph products: every check
+    // has three bits in each half of the bit range) also try "each check owns one bit per block, a bit prefers its
+    // rank-d check" for the nine (d1, d2): two-phase augmenting paths, preferred edges first.  Candidates are ranked
+    // by the collision count of the sorted start layout (it tracks the result of the search below).
+    auto score = [&](const std::vector<int>& own, const std::vector<int>& ld) -> long long {
+        auto dlo = [&](int i) { const int c = own[i]; return cols[3 * (size_t)i] == c ? 0 : (cols[3 * (size_t)i + 1] == c ? 1 : 2); };
+        std::vector<std::vector<int>> cl(9);
+        std::vector<int> l2 = ld;
+        for (int c = 0; c < m; ++c) {
+            if (dlo(l2[2 * c]) > dlo(l2[2 * c + 1])) std::swap(l2[2 * c], l2[2 * c + 1]);
+            cl[dlo(l2[2 * c]) * 3 + dlo(l2[2 * c + 1])].push_back(c);
+        }
+        std::vector<int> ord, rst;
+        for (int k = 0; k < 9; ++k) {
+            const size_t full = cl[k].size() / 64 * 64;
+            ord.insert(ord.end(), cl[k].begin(), cl[k].begin() + full);
+            rst.insert(rst.end(), cl[k].begin() + full, cl[k].end());
+        }
+        ord.insert(ord.end(), rst.begin(), rst.end());
+        std::vector<int> pof(m);
+        for (int p = 0; p < m; ++p) pof[ord[p]] = p;
+        long long t = 0;
+        for (int hw = 0; hw < (m + 31) / 32; ++hw)
+            for (int bs = 0; bs < 4; ++bs) {
+                int cntb[32] = {0};
+                for (int p = 32 * hw; p < 32 * hw + 32 && p < m; ++p) {
+                    const int c = ord[p], i = l2[2 * c + (bs >> 1)];
+                    int no = 0, o = -1;
+                    for (int d = 0; d < 3; ++d) {
+                        if (cols[3 * (size_t)i + d] == c) continue;
+                        if (no++ == (bs & 1)) o = cols[3 * (size_t)i + d];
+                    }
+                    t += 2 * cntb[pof[o] & 31]++ + 1;
+                }
+            }
+        return t - 64LL * (long long)(ord.size() - rst.size());  // reward uniform groups
+    };
+    {
+        std::vector<int> best_owner = owner, best_load = load;
+        long long best = score(owner, load);
+        bool two_block = true;
+        for (int c = 0; c < m && two_block; ++c) {
+            int lo = 0;
+            for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) lo += h->ci[e] < n / 2;
+            two_block = (lo == 3);
+        }
+        if (two_block) {
+            std::vector<int> own2(n), slot(2 * (size_t)m), seen2(m);
+            for (int p1 = 0; p1 < 3; ++p1)
+                for (int p2 = 0; p2 < 3; ++p2) {
+                    std::fill(own2.begin(), own2.end(), -1);
+                    std::fill(slot.begin(), slot.end(), -1);
+                    std::fill(seen2.begin(), seen2.end(), -1);
+                    bool pref_only = true;
+                    std::function<bool(int, int, int)> aug = [&](int i, int stamp, int blk) -> bool {
+                        const int pr = blk == 0 ? p1 : p2;
+                        for (int dd = 0; dd < (pref_only ? 1 : 3); ++dd) {
+                            const int c = cols[3 * (size_t)i + (pr + dd) % 3];
+                            if (seen2[c] == stamp) continue;
+                            seen2[c] = stamp;
+                            const int j = slot[2 * c + blk];
+                            if (j < 0 || aug(j, stamp, blk)) { slot[2 * c + blk] = i; own2[i] = c; return true; }
+                        }
+                        return false;
+                    };
+                    int stamp = 0;
+                    for (int i = 0; i < n; ++i) (void)aug(i, ++stamp, i < n / 2 ? 0 : 1);
+                    pref_only = false;
+                    bool ok = true;
+                    for (int i = 0; i < n && ok; ++i)
+                        if (own2[i] < 0) ok = aug(i, ++stamp, i < n / 2 ? 0 : 1);
+                    for (int c = 0; c < m && ok; ++c) ok = slot[2 * c] >= 0 && slot[2 * c + 1] >= 0;
+                    if (!ok) continue;
+                    const long long sc = score(own2, slot);
+                    if (sc < best) { best = sc; best_owner = own2; best_load = slot; }
+                }
+        }
+        owner = best_owner;
+        load = best_load;
+    }
     auto dl_of = [&](int i) { const int c = owner[i]; return cols[3 * (size_t)i] == c ? 0 : (cols[3 * (size_t)i + 1] == c ? 1 : 2); };
     // canonical slot order per check: (dl0 <= dl1); classes = ordered pairs.  Full groups of 64 checks of one class
     // are uniform (code dl); what is left over of every class shares mixed groups (code 3), sorted by (dl0, dl1) so
@@ -538,15 +619,18 @@ int build_tables_local(bposd_handle* h) {
                     ++no;
                 }
             }
+        bool smooth = false;
         auto hw_cost = [&](int hw, int bs) {
-            int cnt[32] = {0}, mx = 1;
+            // smooth == true: collision pairs + 8 * passes (gives the search a gradient); false: passes
+            int cnt[32] = {0}, mx = 1, sq = 0;
             for (int p = 32 * hw; p < 32 * hw + 32; ++p) {
                 const int c = pos_chk[p];
                 if (c < 0) continue;
                 const int r = pos_of[tgt[4 * (size_t)c + bs]] & 31;
+                sq += 2 * cnt[r] + 1;
                 if (++cnt[r] > mx) mx = cnt[r];
             }
-            return mx;
+            return smooth ? sq + 8 * mx : mx;
         };
         std::vector<int> touched;
         auto collect = [&](int c) {
@@ -570,6 +654,7 @@ int build_tables_local(bposd_handle* h) {
         for (int hw = 0; hw < MP / 32; ++hw)
             for (int bs = 0; bs < 4; ++bs) total += hw_cost(hw, bs);
         const long long start_cost = total;
+        smooth = true;
         const int iters = 400000;
         for (int it = 0; it < iters; ++it) {
             const int c1 = pos_chk[rnd(m)];
@@ -598,6 +683,10 @@ int build_tables_local(bposd_handle* h) {
             if (after > before) { pos_of[c1] = p1; pos_of[c2] = p2; pos_chk[p1] = c1; pos_chk[p2] = c2; }
             else total += after - before;
         }
+        smooth = false;
+        total = 0;
+        for (int hw = 0; hw < MP / 32; ++hw)
+            for (int bs = 0; bs < 4; ++bs) total += hw_cost(hw, bs);
         h->local_cost0 = start_cost;
         h->local_cost = total;
         if (getenv("BPOSD_DEBUG_OCC"))
