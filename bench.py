@@ -292,7 +292,7 @@ def main():
             "kernel_only_syndromes_per_s_per_gpu": B / ((avg_bp_ms + float(np.mean(osd_ms))) * 1e-3),
             "roofline": {
                 "kernel": "bp_large_kernel (BP message passing, messages in HBM)" if large else
-                          "bp_kernel (BP message passing, LDS-resident)",
+                          "bp_local_kernel / bp_kernel (BP message passing, LDS- and register-resident messages)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
