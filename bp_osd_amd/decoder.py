@@ -292,6 +292,7 @@ class BpOsdDecoder:
         return {"natural": a.value, "chosen": b.value, "ideal": c.value}
 
     def set_bp_variant(self, variant: int):
+        """Tuning / test knob: 0 auto; 1, 2, 4 LDS kernel shapes; 16, 17, 18 local-edge kernel (see the C header)."""
         _lib.check(self._lib, self._h, self._lib.bposd_set_bp_variant(self._h, int(variant)))
 
     # ------------------------------------------------------------------ mutators / attributes

@@ -154,8 +154,11 @@ int bposd_info(bposd_handle *h, int32_t *rank, int32_t *num_candidates, int32_t 
  * order the library chose, and the conflict-free ideal.  Any pointer may be NULL. */
 int bposd_layout_info(bposd_handle *h, int64_t *natural_cycles, int64_t *chosen_cycles, int64_t *ideal_cycles);
 
-/* Tuning knob (not part of the reference surface): BP workgroup shape variant
- * 0 = auto, 1 = 1 check/thread, 2 = 2 checks/thread, 4 = 4 checks/thread. */
+/* Tuning knob (not part of the reference surface): which BP kernel / workgroup shape runs.
+ * 0 = auto; 1, 2, 4 = LDS kernel with 1 / 2 / 4 checks per thread; 16, 17, 18 = local-edge kernel (a third of the
+ * messages in registers; (3,6)-regular codes with n = 2m and min-sum only, BPOSD_ERR_UNSUPPORTED otherwise):
+ * 2 checks per thread at <= 80 / <= 64 VGPRs, 1 check per thread.  Auto picks 16 where it applies.  All variants
+ * return identical results. */
 int bposd_set_bp_variant(bposd_handle *h, int32_t variant);
 
 /* Message for the last error on this handle (h == NULL: last create() failure). */
