@@ -157,21 +157,30 @@ def main():
     d_osdw = torch.empty((B, n), dtype=torch.uint8, device=dev)
     d_conv = torch.empty(B, dtype=torch.uint8, device=dev)
     d_iters = torch.empty(B, dtype=torch.int32, device=dev)
-    # the one exchange step: corrections are bit-packed on the device (8x fewer xGMI bytes), then gathered
+    # the one exchange step: corrections are bit-packed on the device (8x fewer xGMI bytes), then gathered.  The
+    # gather runs on torch's stream and may still be reading while the next step decodes on the library's stream,
+    # so the packed rows are double-buffered and a buffer is reused only after its gather has completed.
     wpr = (n + 63) // 64
-    d_packed = torch.empty((B, wpr), dtype=torch.int64, device=dev)
+    d_packed = [torch.empty((B, wpr), dtype=torch.int64, device=dev) for _ in range(2)]
+    gather_done = [None, None]
     gather_list = None
     if world > 1 and not args.no_gather and rank == 0:
-        gather_list = [torch.empty((B, wpr), dtype=torch.int64, device=dev) for _ in range(world)]
+        gather_list = [[torch.empty((B, wpr), dtype=torch.int64, device=dev) for _ in range(world)] for _ in range(2)]
 
     def step(k):
         dec.decode_batch_device(d_syn[k % nbatch].data_ptr(), B, d_osdw.data_ptr(), None, None,
                                 d_conv.data_ptr(), d_iters.data_ptr(), None)
         if world > 1 and not args.no_gather:
-            dec.pack_rows_device(d_osdw.data_ptr(), B, n, d_packed.data_ptr())
+            buf = k & 1
+            if gather_done[buf] is not None:
+                gather_done[buf].synchronize()
+            dec.pack_rows_device(d_osdw.data_ptr(), B, n, d_packed[buf].data_ptr())
         dec.synchronize()  # the library runs on its own stream
         if world > 1 and not args.no_gather:
-            dist.gather(d_packed, gather_list, dst=0)
+            dist.gather(d_packed[buf], gather_list[buf] if rank == 0 else None, dst=0)
+            ev = torch.cuda.Event()
+            ev.record()
+            gather_done[buf] = ev
 
     def fence():
         if world > 1:
