@@ -41,8 +41,8 @@ struct BpLocalParams {
     const double* __restrict__ llr0_alt;  // [n]
     const int* __restrict__ pos_chk;      // [mp]      check at position p, -1 = padding
     const int* __restrict__ pos_bit;      // [2 * mp]  entry b*mp + p: b-th owned bit of position p, -1 = padding
-    const int* __restrict__ pos_alo;      // [2 * mp]  LDS slot (k * mp + p') of the bit's non-local edge to its lower check
-    const int* __restrict__ pos_ahi;      // [2 * mp]  ... to its higher check
+    const int* __restrict__ pos_alo;      // [2 * mp]  LDS slot (k * mp + p') of the bit's edge to the check after its owner (cyclically)
+    const int* __restrict__ pos_ahi;      // [2 * mp]  ... to the check after that one
     const int* __restrict__ pos_dl;       // [2 * mp]  position dl of the owner among the bit's three checks
     const int* __restrict__ grp_dl;       // [2 * mp / 64]  entry b*(mp/64) + g: dl if the whole group shares it, else 3
     uint8_t* __restrict__ out_bp;
@@ -62,14 +62,16 @@ __host__ __device__ inline size_t bp_local_lds_bytes(int mp) {
     return ((size_t)4 * mp + 2) * 8 + (size_t)(mp / 32 + 2) * 4 + 8 * 4;
 }
 
-// the three orders in which the register-resident message R and the two LDS messages X (lower check), Y (higher
-// check) enter a bit's sums
+// A bit's three checks in ascending index order have ranks 0, 1, 2; its owner has rank DL.  X is the message of the
+// check that follows the owner cyclically (rank DL+1 mod 3), Y the one after (rank DL+2 mod 3): the roles are tied to
+// the owner, not to the index order, which keeps the LDS access pattern of structured codes regular across the
+// wrap-around of their circulants.  The sums run in rank order.
 template <int DL>
 __device__ __forceinline__ void bit_update(double l0, double R, double X, double Y, double& llr, double& oR, double& oX,
                                            double& oY) {
-    const double c0 = DL == 0 ? R : X;
+    const double c0 = DL == 0 ? R : (DL == 1 ? Y : X);
     const double c1 = DL == 0 ? X : (DL == 1 ? R : Y);
-    const double c2 = DL == 2 ? R : Y;
+    const double c2 = DL == 0 ? Y : (DL == 1 ? X : R);
     double t = l0;
     const double pre0 = t;  // prefix from the top of the column (prior included)
     t += c0;
@@ -85,17 +87,17 @@ __device__ __forceinline__ void bit_update(double l0, double R, double X, double
     suf += c1;
     const double o0 = pre0 + suf;
     oR = DL == 0 ? o0 : (DL == 1 ? o1 : o2);
-    oX = DL == 0 ? o1 : o0;
-    oY = DL == 2 ? o1 : o2;
+    oX = DL == 0 ? o1 : (DL == 1 ? o2 : o0);
+    oY = DL == 0 ? o2 : (DL == 1 ? o0 : o1);
 }
 
 // mixed group: the same sums with the operands routed per lane
 __device__ __forceinline__ void bit_update_mixed(int dlv, double l0, double R, double X, double Y, double& llr, double& oR,
                                                  double& oX, double& oY) {
-    const bool d0 = dlv == 0, d1 = dlv == 1, d2 = dlv == 2;
-    const double c0 = d0 ? R : X;
+    const bool d0 = dlv == 0, d1 = dlv == 1;
+    const double c0 = d0 ? R : (d1 ? Y : X);
     const double c1 = d0 ? X : (d1 ? R : Y);
-    const double c2 = d2 ? R : Y;
+    const double c2 = d0 ? Y : (d1 ? X : R);
     double t = l0;
     const double pre0 = t;
     t += c0;
@@ -111,8 +113,8 @@ __device__ __forceinline__ void bit_update_mixed(int dlv, double l0, double R, d
     suf += c1;
     const double o0 = pre0 + suf;
     oR = d0 ? o0 : (d1 ? o1 : o2);
-    oX = d0 ? o1 : o0;
-    oY = d2 ? o1 : o2;
+    oX = d0 ? o1 : (d1 ? o2 : o0);
+    oY = d0 ? o2 : (d1 ? o0 : o1);
 }
 
 // CPT: checks per thread (each with its two owned bits); MPT: positions (power of two) = blockDim.x * CPT

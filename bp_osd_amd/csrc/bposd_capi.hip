@@ -447,261 +447,277 @@ int launch_bp(bposd_handle* h, BpParams& P) {
 // ------------------------------------------------------------------ local-edge BP kernel: tables + launch
 // Every check owns two of its six bits (perfect b-matching, Kuhn's augmenting paths with capacity 2); checks are
 // grouped into 64-position groups whose slot-b bits share the position dl of the owner among the bit's checks.
+namespace local_layout {
+
+// An assignment (every check owns two bits) plus a position for every check.
+struct Layout {
+    std::vector<int> owner;    // [n]  owning check of a bit
+    std::vector<int> load;     // [2m] load[2c + b] = b-th owned bit of check c
+    std::vector<int> pos_of;   // [m]  position of a check
+    std::vector<int> pos_chk;  // [MP] check at a position, -1 = empty
+    int nfull = 0;             // positions [0, nfull) are class-uniform groups that the search must keep uniform
+    double cost = 1e30;        // simulated passes + 5 * mixed (group, slot) pairs (measured exchange rate)
+    long long passes = 0;
+};
+
+struct Graph {
+    int m, n, MP;
+    std::vector<int> cols;  // [3n] checks of a bit, ascending
+    int rank_of(int i, int c) const { return cols[3 * (size_t)i] == c ? 0 : (cols[3 * (size_t)i + 1] == c ? 1 : 2); }
+    // the two non-local checks of bit i owned by c, in cyclic order after the owner (roles X, Y of the kernel)
+    void others(int i, int c, int* o) const {
+        const int d = rank_of(i, c);
+        o[0] = cols[3 * (size_t)i + (d + 1) % 3];
+        o[1] = cols[3 * (size_t)i + (d + 2) % 3];
+    }
+};
+
+// bank-conflict search: swaps that do not raise (collision pairs + 8 * passes); see build_tables_local
+void search(const Graph& g, Layout& L, bool constrained, int iters) {
+    const int m = g.m, MP = g.MP;
+    auto key = [&](int c) { return g.rank_of(L.load[2 * c], c) * 3 + g.rank_of(L.load[2 * c + 1], c); };
+    std::vector<int> tgt(4 * (size_t)m);
+    std::vector<std::vector<int>> users(m);
+    for (int c = 0; c < m; ++c)
+        for (int b = 0; b < 2; ++b) {
+            int o[2];
+            g.others(L.load[2 * c + b], c, o);
+            for (int s = 0; s < 2; ++s) {
+                tgt[4 * (size_t)c + 2 * b + s] = o[s];
+                users[o[s]].push_back(4 * c + 2 * b + s);
+            }
+        }
+    bool smooth = true;
+    auto hw_cost = [&](int hw, int bs) {
+        int cnt[32] = {0}, mx = 1, sq = 0;
+        for (int p = 32 * hw; p < 32 * hw + 32; ++p) {
+            const int c = L.pos_chk[p];
+            if (c < 0) continue;
+            const int r = L.pos_of[tgt[4 * (size_t)c + bs]] & 31;
+            sq += 2 * cnt[r] + 1;
+            if (++cnt[r] > mx) mx = cnt[r];
+        }
+        return smooth ? sq + 8 * mx : mx;
+    };
+    std::vector<int> touched;
+    auto collect = [&](int c) {
+        const int hw = L.pos_of[c] >> 5;
+        for (int bs = 0; bs < 4; ++bs) touched.push_back(hw * 4 + bs);
+        for (int u : users[c]) touched.push_back((L.pos_of[u >> 2] >> 5) * 4 + (u & 3));
+    };
+    auto cost_of = [&]() {
+        std::sort(touched.begin(), touched.end());
+        touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+        int t = 0;
+        for (int e : touched) t += hw_cost(e >> 2, e & 3);
+        return t;
+    };
+    unsigned long long rs = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&](int mod) {
+        rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+        return (int)((rs >> 11) % (unsigned long long)mod);
+    };
+    for (int it = 0; it < iters; ++it) {
+        const int c1 = rnd(m);
+        const int p1 = L.pos_of[c1];
+        int p2;
+        if (!constrained) p2 = rnd(MP);
+        else if (p1 < L.nfull) {
+            if (rnd(4) == 0) p2 = (p1 & ~63) + rnd(64);  // same group
+            else {
+                p2 = rnd(L.nfull);                        // another uniform position: must be the same class
+                if (L.pos_chk[p2] < 0 || key(L.pos_chk[p2]) != key(c1)) continue;
+            }
+        } else p2 = L.nfull + rnd(MP - L.nfull);           // mixed region (with its empty positions)
+        const int c2 = L.pos_chk[p2];
+        if (c2 == c1) continue;
+        touched.clear();
+        collect(c1);
+        if (c2 >= 0) collect(c2);
+        for (int bs = 0; bs < 4; ++bs) { touched.push_back((p1 >> 5) * 4 + bs); touched.push_back((p2 >> 5) * 4 + bs); }
+        const int before = cost_of();
+        L.pos_of[c1] = p2; L.pos_chk[p2] = c1; L.pos_chk[p1] = c2;
+        if (c2 >= 0) L.pos_of[c2] = p1;
+        const int after = cost_of();
+        if (after > before) {
+            L.pos_of[c1] = p1; L.pos_chk[p1] = c1; L.pos_chk[p2] = c2;
+            if (c2 >= 0) L.pos_of[c2] = p2;
+        }
+    }
+    smooth = false;
+    L.passes = 0;
+    for (int hw = 0; hw < MP / 32; ++hw)
+        for (int bs = 0; bs < 4; ++bs) L.passes += hw_cost(hw, bs);
+    int mixed = 0;
+    for (int gq = 0; gq < MP / 64; ++gq)
+        for (int b = 0; b < 2; ++b) {
+            int code = -1;
+            for (int p = 64 * gq; p < 64 * gq + 64; ++p) {
+                const int c = L.pos_chk[p];
+                if (c < 0) continue;
+                const int d = g.rank_of(L.load[2 * c + b], c);
+                code = (code < 0 || code == d) ? d : 3;
+            }
+            mixed += code == 3;
+        }
+    L.cost = (double)L.passes + 5.0 * mixed;
+}
+
+// class-sorted start layout: full groups of one class first (uniform), the leftovers behind them
+void class_sorted(const Graph& g, Layout& L) {
+    const int m = g.m;
+    std::vector<std::vector<int>> cls(9);
+    for (int c = 0; c < m; ++c) {
+        if (g.rank_of(L.load[2 * c], c) > g.rank_of(L.load[2 * c + 1], c)) std::swap(L.load[2 * c], L.load[2 * c + 1]);
+        cls[g.rank_of(L.load[2 * c], c) * 3 + g.rank_of(L.load[2 * c + 1], c)].push_back(c);
+    }
+    std::vector<int> order, rest;
+    for (int k = 0; k < 9; ++k) {
+        const size_t full = cls[k].size() / 64 * 64;
+        order.insert(order.end(), cls[k].begin(), cls[k].begin() + full);
+        rest.insert(rest.end(), cls[k].begin() + full, cls[k].end());
+    }
+    L.nfull = (int)order.size();
+    order.insert(order.end(), rest.begin(), rest.end());
+    L.pos_chk.assign(g.MP, -1);
+    L.pos_of.assign(m, -1);
+    for (int p = 0; p < m; ++p) { L.pos_chk[p] = order[p]; L.pos_of[order[p]] = p; }
+}
+
+}  // namespace local_layout
+
+// Every check owns two of its six bits; positions are chosen so that (a) as many 64-position groups as possible
+// share the owner's rank per slot (select-free code) and (b) the bit pass's LDS accesses collide as little as
+// possible.  Candidates: Kuhn's augmenting paths and, for two-block codes (hypergraph products), the nine "a bit
+// prefers its rank-d check" block matchings; each is class-sorted (full groups of one class first), the cheapest start
+// layout (simulated passes + 5 * mixed (group, slot) pairs) is then searched under the uniformity constraint.
+// (A row layout of the circulant grid is conflict-free -- 128 passes for 128 accesses -- but the wrap-around makes
+// every group mixed, and measured on the GPU a mixed pair costs as much as five extra passes: 36.3 ms against 29.8.)
 int build_tables_local(bposd_handle* h) {
+    using namespace local_layout;
     h->local_ok = false;
     const int m = h->m, n = h->n;
     if (!(h->regular && h->dc_max == 6 && h->dv_max == 3 && n == 2 * m)) return 0;
-    // column lists (ascending check index: rows are visited in order)
-    std::vector<int> cols(3 * (size_t)n);
+    const int MP = 1024;  // the kernels are compiled for 1024 positions (H1922: 961 checks)
+    if (m > MP) return 0;
+    Graph g;
+    g.m = m; g.n = n; g.MP = MP;
+    g.cols.assign(3 * (size_t)n, 0);
     {
         std::vector<int> fill(n, 0);
         for (int c = 0; c < m; ++c)
             for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
                 const int i = h->ci[e];
-                cols[3 * (size_t)i + fill[i]++] = c;
+                g.cols[3 * (size_t)i + fill[i]++] = c;
             }
     }
-    std::vector<int> owner(n, -1), load(2 * (size_t)m, -1);  // load[2c + s] = bit in slot s of check c
-    auto cnt = [&](int c) { return (load[2 * c] >= 0) + (load[2 * c + 1] >= 0); };
-    auto put = [&](int c, int i) { (load[2 * c] < 0 ? load[2 * c] : load[2 * c + 1]) = i; owner[i] = c; };
-    auto drop = [&](int c, int i) { if (load[2 * c] == i) load[2 * c] = -1; else load[2 * c + 1] = -1; };
-    std::vector<int> seen(m, -1);
-    // iterative DFS over alternating paths: place(i) tries the checks of bit i, evicting a current owner's bit
-    std::function<bool(int, int)> place = [&](int i, int stamp) -> bool {
-        for (int d = 0; d < 3; ++d) {
-            const int c = cols[3 * (size_t)i + d];
-            if (seen[c] == stamp) continue;
-            seen[c] = stamp;
-            if (cnt(c) < 2) { put(c, i); return true; }
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int j = load[2 * c + s2];
-                // move j elsewhere
-                drop(c, j);
-                owner[j] = -1;
-                if (place(j, stamp)) { put(c, i); return true; }
-                load[2 * c + s2] = j;
-                owner[j] = c;
-            }
-        }
-        return false;
-    };
-    for (int i = 0; i < n; ++i)
-        if (!place(i, i)) return 0;  // no perfect assignment: the generic kernel is used
-    for (int c = 0; c < m; ++c)
-        if (cnt(c) != 2) return 0;
-    // ---- candidate assignments.  Which perfect assignment is taken decides how many checks share a class (uniform
-    // groups) and how regular the bit pass's LDS accesses are.  For two-block codes (hypergraph products: every check
-    // has three bits in each half of the bit range) also try "each check owns one bit per block, a bit prefers its
-    // rank-d check" for the nine (d1, d2): two-phase augmenting paths, preferred edges first.  Candidates are ranked
-    // by the collision count of the sorted start layout (it tracks the result of the search below).
-    auto score = [&](const std::vector<int>& own, const std::vector<int>& ld) -> long long {
-        auto dlo = [&](int i) { const int c = own[i]; return cols[3 * (size_t)i] == c ? 0 : (cols[3 * (size_t)i + 1] == c ? 1 : 2); };
-        std::vector<std::vector<int>> cl(9);
-        std::vector<int> l2 = ld;
-        for (int c = 0; c < m; ++c) {
-            if (dlo(l2[2 * c]) > dlo(l2[2 * c + 1])) std::swap(l2[2 * c], l2[2 * c + 1]);
-            cl[dlo(l2[2 * c]) * 3 + dlo(l2[2 * c + 1])].push_back(c);
-        }
-        std::vector<int> ord, rst;
-        for (int k = 0; k < 9; ++k) {
-            const size_t full = cl[k].size() / 64 * 64;
-            ord.insert(ord.end(), cl[k].begin(), cl[k].begin() + full);
-            rst.insert(rst.end(), cl[k].begin() + full, cl[k].end());
-        }
-        ord.insert(ord.end(), rst.begin(), rst.end());
-        std::vector<int> pof(m);
-        for (int p = 0; p < m; ++p) pof[ord[p]] = p;
-        long long t = 0;
-        for (int hw = 0; hw < (m + 31) / 32; ++hw)
-            for (int bs = 0; bs < 4; ++bs) {
-                int cntb[32] = {0};
-                for (int p = 32 * hw; p < 32 * hw + 32 && p < m; ++p) {
-                    const int c = ord[p], i = l2[2 * c + (bs >> 1)];
-                    int no = 0, o = -1;
-                    for (int d = 0; d < 3; ++d) {
-                        if (cols[3 * (size_t)i + d] == c) continue;
-                        if (no++ == (bs & 1)) o = cols[3 * (size_t)i + d];
-                    }
-                    t += 2 * cntb[pof[o] & 31]++ + 1;
+    const std::vector<int>& cols = g.cols;
+    std::vector<Layout> cands;
+    // ---- (1) generic perfect assignment
+    {
+        Layout L;
+        L.owner.assign(n, -1);
+        L.load.assign(2 * (size_t)m, -1);
+        auto cnt = [&](int c) { return (L.load[2 * c] >= 0) + (L.load[2 * c + 1] >= 0); };
+        auto put = [&](int c, int i) { (L.load[2 * c] < 0 ? L.load[2 * c] : L.load[2 * c + 1]) = i; L.owner[i] = c; };
+        auto drop = [&](int c, int i) { if (L.load[2 * c] == i) L.load[2 * c] = -1; else L.load[2 * c + 1] = -1; };
+        std::vector<int> seen(m, -1);
+        std::function<bool(int, int)> place = [&](int i, int stamp) -> bool {
+            for (int d = 0; d < 3; ++d) {
+                const int c = cols[3 * (size_t)i + d];
+                if (seen[c] == stamp) continue;
+                seen[c] = stamp;
+                if (cnt(c) < 2) { put(c, i); return true; }
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int j = L.load[2 * c + s2];
+                    drop(c, j);
+                    L.owner[j] = -1;
+                    if (place(j, stamp)) { put(c, i); return true; }
+                    L.load[2 * c + s2] = j;
+                    L.owner[j] = c;
                 }
             }
-        return t - 64LL * (long long)(ord.size() - rst.size());  // reward uniform groups
-    };
-    {
-        std::vector<int> best_owner = owner, best_load = load;
-        long long best = score(owner, load);
-        bool two_block = true;
-        for (int c = 0; c < m && two_block; ++c) {
-            int lo = 0;
-            for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) lo += h->ci[e] < n / 2;
-            two_block = (lo == 3);
-        }
-        if (two_block) {
-            std::vector<int> own2(n), slot(2 * (size_t)m), seen2(m);
-            for (int p1 = 0; p1 < 3; ++p1)
-                for (int p2 = 0; p2 < 3; ++p2) {
-                    std::fill(own2.begin(), own2.end(), -1);
-                    std::fill(slot.begin(), slot.end(), -1);
-                    std::fill(seen2.begin(), seen2.end(), -1);
-                    bool pref_only = true;
-                    std::function<bool(int, int, int)> aug = [&](int i, int stamp, int blk) -> bool {
-                        const int pr = blk == 0 ? p1 : p2;
-                        for (int dd = 0; dd < (pref_only ? 1 : 3); ++dd) {
-                            const int c = cols[3 * (size_t)i + (pr + dd) % 3];
-                            if (seen2[c] == stamp) continue;
-                            seen2[c] = stamp;
-                            const int j = slot[2 * c + blk];
-                            if (j < 0 || aug(j, stamp, blk)) { slot[2 * c + blk] = i; own2[i] = c; return true; }
-                        }
-                        return false;
-                    };
-                    int stamp = 0;
-                    for (int i = 0; i < n; ++i) (void)aug(i, ++stamp, i < n / 2 ? 0 : 1);
-                    pref_only = false;
-                    bool ok = true;
-                    for (int i = 0; i < n && ok; ++i)
-                        if (own2[i] < 0) ok = aug(i, ++stamp, i < n / 2 ? 0 : 1);
-                    for (int c = 0; c < m && ok; ++c) ok = slot[2 * c] >= 0 && slot[2 * c + 1] >= 0;
-                    if (!ok) continue;
-                    const long long sc = score(own2, slot);
-                    if (sc < best) { best = sc; best_owner = own2; best_load = slot; }
-                }
-        }
-        owner = best_owner;
-        load = best_load;
-    }
-    auto dl_of = [&](int i) { const int c = owner[i]; return cols[3 * (size_t)i] == c ? 0 : (cols[3 * (size_t)i + 1] == c ? 1 : 2); };
-    // canonical slot order per check: (dl0 <= dl1); classes = ordered pairs.  Full groups of 64 checks of one class
-    // are uniform (code dl); what is left over of every class shares mixed groups (code 3), sorted by (dl0, dl1) so
-    // that a slot of a mixed group is still uniform where possible.
-    std::vector<std::vector<int>> cls(9);
-    for (int c = 0; c < m; ++c) {
-        int a = load[2 * c], b = load[2 * c + 1];
-        if (dl_of(a) > dl_of(b)) { std::swap(a, b); load[2 * c] = a; load[2 * c + 1] = b; }
-        cls[dl_of(a) * 3 + dl_of(b)].push_back(c);
-    }
-    const int MP = 1024;  // the kernels are compiled for 1024 positions (H1922: 961 checks)
-    if (m > MP) return 0;
-    const int G = MP / 64;
-    std::vector<int> order;  // checks in position order
-    order.reserve(m);
-    std::vector<int> rest;
-    for (int k = 0; k < 9; ++k) {
-        const size_t full = cls[k].size() / 64 * 64;
-        order.insert(order.end(), cls[k].begin(), cls[k].begin() + full);
-        rest.insert(rest.end(), cls[k].begin() + full, cls[k].end());  // already ordered by class
-    }
-    order.insert(order.end(), rest.begin(), rest.end());
-    std::vector<int> pos_chk(MP, -1), pos_of(m, -1), grp_dl(2 * (size_t)G, 0);
-    for (int p = 0; p < m; ++p) {
-        pos_chk[p] = order[p];
-        pos_of[order[p]] = p;
-    }
-    // ---- bank-conflict hill climbing.  The bit pass gathers / scatters the two non-local messages of every owned
-    // bit at slot k * MP + position(other check): bank pair = position mod 32, and a half-wave (32 consecutive
-    // positions) is served in max-multiplicity passes.  Swapping two checks of one class between uniform groups,
-    // or any two checks inside one group / inside the mixed region, keeps the group codes; accept what does not
-    // raise the simulated pass count (random layout ~3.1 passes per access, after the search ~1.9; ideal 1).
-    {
-        auto key = [&](int c) { return dl_of(load[2 * c]) * 3 + dl_of(load[2 * c + 1]); };
-        const int nfull = (int)(order.size() - rest.size());  // positions [0, nfull) are uniform groups
-        std::vector<int> tgt(4 * (size_t)m);                  // [c][b][s]: the other two checks of owned bit b
-        std::vector<std::vector<int>> users(m);               // checks whose accesses land on c, encoded 4*c' + 2*b + s
+            return false;
+        };
+        for (int i = 0; i < n; ++i)
+            if (!place(i, i)) return 0;  // no perfect assignment: the LDS kernel is used
         for (int c = 0; c < m; ++c)
-            for (int b = 0; b < 2; ++b) {
-                const int i = load[2 * c + b];
-                int no = 0;
-                for (int d = 0; d < 3; ++d) {
-                    const int o = cols[3 * (size_t)i + d];
-                    if (o == c) continue;
-                    tgt[4 * (size_t)c + 2 * b + no] = o;
-                    users[o].push_back(4 * c + 2 * b + no);
-                    ++no;
-                }
-            }
-        bool smooth = false;
-        auto hw_cost = [&](int hw, int bs) {
-            // smooth == true: collision pairs + 8 * passes (gives the search a gradient); false: passes
-            int cnt[32] = {0}, mx = 1, sq = 0;
-            for (int p = 32 * hw; p < 32 * hw + 32; ++p) {
-                const int c = pos_chk[p];
-                if (c < 0) continue;
-                const int r = pos_of[tgt[4 * (size_t)c + bs]] & 31;
-                sq += 2 * cnt[r] + 1;
-                if (++cnt[r] > mx) mx = cnt[r];
-            }
-            return smooth ? sq + 8 * mx : mx;
-        };
-        std::vector<int> touched;
-        auto collect = [&](int c) {
-            const int hw = pos_of[c] >> 5;
-            for (int bs = 0; bs < 4; ++bs) touched.push_back(hw * 4 + bs);
-            for (int u : users[c]) touched.push_back((pos_of[u >> 2] >> 5) * 4 + (u & 3));
-        };
-        auto cost_of = [&]() {
-            std::sort(touched.begin(), touched.end());
-            touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-            int t = 0;
-            for (int e : touched) t += hw_cost(e >> 2, e & 3);
-            return t;
-        };
-        unsigned long long rs = 0x9E3779B97F4A7C15ull;
-        auto rnd = [&](int mod) {
-            rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
-            return (int)((rs >> 11) % (unsigned long long)mod);
-        };
-        long long total = 0;
-        for (int hw = 0; hw < MP / 32; ++hw)
-            for (int bs = 0; bs < 4; ++bs) total += hw_cost(hw, bs);
-        const long long start_cost = total;
-        smooth = true;
-        const int iters = 400000;
-        for (int it = 0; it < iters; ++it) {
-            const int c1 = pos_chk[rnd(m)];
-            int c2;
-            const int p1 = pos_of[c1];
-            if (p1 < nfull) {
-                if (rnd(4) == 0) {
-                    c2 = pos_chk[(p1 & ~63) + rnd(64)];  // same group
-                } else {
-                    c2 = pos_chk[rnd(nfull)];             // another uniform position: must be the same class
-                    if (key(c2) != key(c1)) continue;
-                }
-            } else {
-                c2 = pos_chk[nfull + rnd(m - nfull)];     // mixed region: anything goes (codes are recomputed below)
-            }
-            if (c2 < 0 || c2 == c1) continue;
-            touched.clear();
-            collect(c1);
-            collect(c2);
-            const int p2 = pos_of[c2];
-            // the streams touched after the swap are the same set with the two positions exchanged
-            for (int bs = 0; bs < 4; ++bs) { touched.push_back((p1 >> 5) * 4 + bs); touched.push_back((p2 >> 5) * 4 + bs); }
-            const int before = cost_of();
-            pos_of[c1] = p2; pos_of[c2] = p1; pos_chk[p1] = c2; pos_chk[p2] = c1;
-            const int after = cost_of();
-            if (after > before) { pos_of[c1] = p1; pos_of[c2] = p2; pos_chk[p1] = c1; pos_chk[p2] = c2; }
-            else total += after - before;
-        }
-        smooth = false;
-        total = 0;
-        for (int hw = 0; hw < MP / 32; ++hw)
-            for (int bs = 0; bs < 4; ++bs) total += hw_cost(hw, bs);
-        h->local_cost0 = start_cost;
-        h->local_cost = total;
-        if (getenv("BPOSD_DEBUG_OCC"))
-            fprintf(stderr, "[bposd] local-edge layout: simulated LDS passes %lld -> %lld (ideal %d)\n", start_cost, total, 4 * (MP / 32));
+            if (cnt(c) != 2) return 0;
+        cands.push_back(L);
     }
-    for (int g = 0; g < G; ++g)
+    bool two_block = true;
+    for (int c = 0; c < m && two_block; ++c) {
+        int lo = 0;
+        for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) lo += h->ci[e] < n / 2;
+        two_block = (lo == 3);
+    }
+    // ---- (2) rank-preference block matchings
+    if (two_block) {
+        std::vector<int> own2(n), slot(2 * (size_t)m), seen2(m);
+        for (int p1 = 0; p1 < 3; ++p1)
+            for (int p2 = 0; p2 < 3; ++p2) {
+                std::fill(own2.begin(), own2.end(), -1);
+                std::fill(slot.begin(), slot.end(), -1);
+                std::fill(seen2.begin(), seen2.end(), -1);
+                bool pref_only = true;
+                std::function<bool(int, int, int)> aug = [&](int i, int stamp, int blk) -> bool {
+                    const int pr = blk == 0 ? p1 : p2;
+                    for (int dd = 0; dd < (pref_only ? 1 : 3); ++dd) {
+                        const int c = cols[3 * (size_t)i + (pr + dd) % 3];
+                        if (seen2[c] == stamp) continue;
+                        seen2[c] = stamp;
+                        const int j = slot[2 * c + blk];
+                        if (j < 0 || aug(j, stamp, blk)) { slot[2 * c + blk] = i; own2[i] = c; return true; }
+                    }
+                    return false;
+                };
+                int stamp = 0;
+                for (int i = 0; i < n; ++i) (void)aug(i, ++stamp, i < n / 2 ? 0 : 1);
+                pref_only = false;
+                bool ok = true;
+                for (int i = 0; i < n && ok; ++i)
+                    if (own2[i] < 0) ok = aug(i, ++stamp, i < n / 2 ? 0 : 1);
+                for (int c = 0; c < m && ok; ++c) ok = slot[2 * c] >= 0 && slot[2 * c + 1] >= 0;
+                if (!ok) continue;
+                Layout L;
+                L.owner = own2;
+                L.load = slot;
+                cands.push_back(L);
+            }
+    }
+    // class-sorted start for (1) and (2); rank them by a short search and finish the best
+    Layout best;
+    {
+        int bi = -1;
+        for (size_t k = 0; k < cands.size(); ++k) {
+            class_sorted(g, cands[k]);
+            search(g, cands[k], true, 0);  // cost of the start layout
+            if (bi < 0 || cands[k].cost < cands[bi].cost) bi = (int)k;
+        }
+        best = cands[bi];
+        search(g, best, true, 400000);
+    }
+    if (getenv("BPOSD_DEBUG_OCC"))
+        fprintf(stderr, "[bposd] local-edge layout: %lld simulated LDS passes for %d accesses, cost %.1f, %d uniform positions\n",
+                best.passes, 4 * (MP / 32), best.cost, best.nfull);
+    h->local_cost0 = 4LL * (MP / 32);
+    h->local_cost = best.passes;
+
+    // ---- tables
+    const int G = MP / 64;
+    const std::vector<int>&owner = best.owner, &load = best.load, &pos_of = best.pos_of, &pos_chk = best.pos_chk;
+    std::vector<int> grp_dl(2 * (size_t)G, 0);
+    for (int gq = 0; gq < G; ++gq)
         for (int b = 0; b < 2; ++b) {
             int code = -1;
-            for (int p = 64 * g; p < 64 * g + 64 && p < m; ++p) {
-                const int d = dl_of(load[2 * pos_chk[p] + b]);
+            for (int p = 64 * gq; p < 64 * gq + 64; ++p) {
+                const int c = pos_chk[p];
+                if (c < 0) continue;
+                const int d = g.rank_of(load[2 * c + b], c);
                 code = (code < 0 || code == d) ? d : 3;
             }
-            grp_dl[(size_t)b * G + g] = code < 0 ? 0 : code;
+            grp_dl[(size_t)b * G + gq] = code < 0 ? 0 : code;
         }
-    const int NT = 512;
     // LDS slot of (check c, bit i) for the check's four non-local edges, ascending column order
     auto slot_of = [&](int c, int i) {
         int k = 0;
@@ -718,15 +734,14 @@ int build_tables_local(bposd_handle* h) {
         const int p = pos_of[c];
         for (int b = 0; b < 2; ++b) {
             const int i = load[2 * c + b];
-            int other[2], no = 0;
-            for (int d = 0; d < 3; ++d)
-                if (cols[3 * (size_t)i + d] != c) other[no++] = cols[3 * (size_t)i + d];
-            const int lo = slot_of(other[0], i), hi = slot_of(other[1], i);
-            if (no != 2 || lo < 0 || hi < 0) return 0;
-            pos_dl[(size_t)b * MP + p] = dl_of(i);
+            int o[2];
+            g.others(i, c, o);
+            const int sx = slot_of(o[0], i), sy = slot_of(o[1], i);
+            if (sx < 0 || sy < 0) return 0;
+            pos_dl[(size_t)b * MP + p] = g.rank_of(i, c);
             pos_bit[(size_t)b * MP + p] = i;
-            pos_alo[(size_t)b * MP + p] = lo;
-            pos_ahi[(size_t)b * MP + p] = hi;
+            pos_alo[(size_t)b * MP + p] = sx;
+            pos_ahi[(size_t)b * MP + p] = sy;
         }
     }
     auto up = [&](int** dst, const std::vector<int>& v) -> int {
@@ -743,7 +758,7 @@ int build_tables_local(bposd_handle* h) {
     if ((rc = up(&h->d_lgrp_dl, grp_dl))) return rc;
     if ((rc = up(&h->d_lpos_dl, pos_dl))) return rc;
     h->local_mp = MP;
-    h->local_nt = NT;
+    h->local_nt = 512;
     h->local_ok = true;
     return 0;
 }
