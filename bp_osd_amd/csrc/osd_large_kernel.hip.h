@@ -294,15 +294,17 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     for (int g = 0; g < OSDL_K; ++g)
                         mkn[g] = (g < ng) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro) : 0ull;
                 }
+                // rows >= m are padding (all-zero rows with zero masks): a wave whose rows are all padding skips them
+                const int kmax = (m - (int)(threadIdx.x & ~63u) + NT - 1) / NT;  // wave-uniform: rows tid + k * NT < m for some lane
 #pragma clang loop unroll(disable)
-                for (int k = 0; k < RPT; ++k) {
+                for (int k = 0; k < RPT && k < kmax; ++k) {
                     const unsigned int ro = osdl_opaque((unsigned int)(tid + k * NT) * 8u);
                     unsigned long long v[OSDL_CW], mks[OSDL_K];
 #pragma unroll
                     for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] = vn[xx];
 #pragma unroll
                     for (int g = 0; g < OSDL_K; ++g) mks[g] = mkn[g];
-                    if (k + 1 < RPT) {
+                    if (k + 1 < RPT && k + 1 < kmax) {
                         const unsigned int rn = ro + NT * 8;
 #pragma unroll
                         for (int xx = 0; xx < OSDL_CW; ++xx)
