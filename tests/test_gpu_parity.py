@@ -648,3 +648,26 @@ def test_local_edge_kernel_equals_lds_kernel(gpu_ready, h1922, side):
     la = a.batch_llr.copy()
     ob = b.decode_batch(syn[:256], prior_select=sel, alt_channel_probs=alt, want_llr=True)
     assert (oa == ob).all() and (la.view(np.uint64) == b.batch_llr.view(np.uint64)).all()
+
+
+@pytest.mark.parametrize("seed_file,N,K", [("mkmn_20_5_8.txt", 625, 25), ("mkmn_24_6_10.txt", 900, 36)])
+def test_reference_example_codes_625_900(gpu_ready, seed_file, N, K):
+    """The other two hypergraph-product codes the reference ships (examples/codes/classical_seed_codes/*.txt, code
+    parameters from the file names of examples/codes/hgp_codes/): check degree 7, bit degree 3-4, both sectors,
+    OSD-CS and OSD-E, bit-exact against the oracle."""
+    import os
+
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp
+    from oracle import OracleDecoder
+
+    seed = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", seed_file)).astype(np.uint8)
+    code = hgp(seed)
+    assert (code.N, code.K) == (N, K) and code.test()
+    q = 0.06
+    for H, method, order in ((code.hx, "osd_cs", 10), (code.hz, "osd_e", 8)):
+        _, syn = _syndromes(H, q, 400, N)
+        kw = dict(error_rate=q, max_iter=12, bp_method="ms", ms_scaling_factor=0.625, osd_method=method, osd_order=order)
+        r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
+        assert 0.02 < (~r["converged"]).mean() < 0.98  # both branches are exercised
+        _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
