@@ -207,3 +207,27 @@ def test_code_parameters(surface13, h1922):
     assert h1922.test()
     steane = hgp(rep_code(2))  # tiny sanity: hgp of a 1x2 matrix
     assert steane.N == 5 and steane.test()
+
+
+@pytest.mark.parametrize("seed_file,N,K", [("mkmn_16_4_6.txt", 400, 16), ("mkmn_20_5_8.txt", 625, 25), ("mkmn_24_6_10.txt", 900, 36)])
+def test_logicals_span_the_reference_logical_space(seed_file, N, K):
+    """The reference ships lx / lz for its three example codes (examples/codes/hgp_codes/*_{lx,lz}.txt, packed into
+    tests/golden/hgp_reference_logicals_fixture.npz).  Our hgp() of the same seed must give the same code: the
+    reference's logicals commute with our stabilisers, are independent of them, and span the same logical space as
+    ours (css.py:75-95 fixes the space, not the basis)."""
+    import os
+
+    from bp_osd_amd.codes import gf2_rank, hgp
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    code = hgp(np.loadtxt(os.path.join(here, seed_file)).astype(np.uint8))
+    fx = np.load(os.path.join(here, "hgp_reference_logicals_fixture.npz"))
+    lx = np.unpackbits(fx[f"lx_{N}"], axis=1)[:, :N]
+    lz = np.unpackbits(fx[f"lz_{N}"], axis=1)[:, :N]
+    assert (code.N, code.K) == (N, K) and lx.shape == (K, N) and lz.shape == (K, N)
+    hx, hz = code.hx.toarray().astype(np.int64), code.hz.toarray().astype(np.int64)
+    assert not ((hz @ lx.T) % 2).any() and not ((hx @ lz.T) % 2).any()
+    rx, rz = gf2_rank(hx), gf2_rank(hz)
+    assert gf2_rank(np.vstack([hx, lx])) == rx + K and gf2_rank(np.vstack([hz, lz])) == rz + K
+    assert gf2_rank(np.vstack([hx, lx, code.lx])) == rx + K and gf2_rank(np.vstack([hz, lz, code.lz])) == rz + K
+    assert gf2_rank((lx.astype(np.int64) @ code.lz.T.astype(np.int64)) % 2) == K  # their X logicals pair with our Z logicals
