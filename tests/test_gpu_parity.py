@@ -671,3 +671,20 @@ def test_reference_example_codes_625_900(gpu_ready, seed_file, N, K):
         r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
         assert 0.02 < (~r["converged"]).mean() < 0.98  # both branches are exercised
         _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
+
+
+def test_reference_example_script_configuration(gpu_ready, hgp400):
+    """examples/qldpc_decode_example.py, option for option ([[400,16,6]], Z-only noise at 5 %, min-sum with the variable
+    scaling factor, max_iter = 0 -> N, osd_cs order 42, seed 42, 1000 runs): the batched harness on the MI355X decoder
+    ends with the same counters as the same harness on the CPU oracle."""
+    from bp_osd_amd.sim import css_decode_sim
+    from tests.sim_util import OracleAdapter
+
+    opts = dict(error_rate=0.05, target_runs=1000, xyz_error_bias=[0, 0, 1], bp_method="ms", ms_scaling_factor=0,
+                osd_method="osd_cs", osd_order=42, channel_update=None, seed=42, max_iter=0, tqdm_disable=1)
+    gpu = css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, batch_size=500, **opts)
+    cpu = css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, batch_size=250, decoder_factory=OracleAdapter, **opts)
+    for k in ("run_count", "osdw_success_count", "osd0_success_count", "bp_success_count", "bp_converge_count_x",
+              "bp_converge_count_z", "min_logical_weight", "osdw_logical_error_rate"):
+        assert getattr(gpu, k) == getattr(cpu, k), (k, getattr(gpu, k), getattr(cpu, k))
+    assert gpu.run_count == 1000 and gpu.osd_order == 42
