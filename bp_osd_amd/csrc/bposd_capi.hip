@@ -52,8 +52,8 @@ struct bposd_handle {
     bool regular = false;
     // local-edge BP kernel (bp_local_kernel.hip.h): available for (3,6)-regular codes with n = 2m, min-sum
     bool local_ok = false;
-    int local_mp = 0, local_nt = 0;
-    long long local_cost0 = 0, local_cost = 0;  // simulated LDS passes of the bit pass before / after the layout search
+    int local_mp = 0;
+    long long local_passes = 0;  // simulated LDS passes of the bit pass in the chosen layout (ideal: 4 * MP / 32)
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
     bool large = false;  // beyond the LDS-resident kernels: HBM-resident messages / matrix
     DevBuf bpl_msg, bpl_llr;  // large BP workspaces
@@ -700,8 +700,7 @@ int build_tables_local(bposd_handle* h) {
     if (getenv("BPOSD_DEBUG_OCC"))
         fprintf(stderr, "[bposd] local-edge layout: %lld simulated LDS passes for %d accesses, cost %.1f, %d uniform positions\n",
                 best.passes, 4 * (MP / 32), best.cost, best.nfull);
-    h->local_cost0 = 4LL * (MP / 32);
-    h->local_cost = best.passes;
+    h->local_passes = best.passes;
 
     // ---- tables
     const int G = MP / 64;
@@ -758,7 +757,6 @@ int build_tables_local(bposd_handle* h) {
     if ((rc = up(&h->d_lgrp_dl, grp_dl))) return rc;
     if ((rc = up(&h->d_lpos_dl, pos_dl))) return rc;
     h->local_mp = MP;
-    h->local_nt = 512;
     h->local_ok = true;
     return 0;
 }
