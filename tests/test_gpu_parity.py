@@ -688,3 +688,27 @@ def test_reference_example_script_configuration(gpu_ready, hgp400):
               "bp_converge_count_z", "min_logical_weight", "osdw_logical_error_rate"):
         assert getattr(gpu, k) == getattr(cpu, k), (k, getattr(gpu, k), getattr(cpu, k))
     assert gpu.run_count == 1000 and gpu.osd_order == 42
+
+
+def test_local_edge_kernel_on_a_random_regular_product_code(gpu_ready):
+    """A hypergraph product of a RANDOM (3,3)-regular 31 x 31 matrix: check degree 6, bit degree 3, n = 2m, no circulant
+    structure.  The local-edge kernel (auto) must agree with the LDS kernel and the oracle here as well."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp, regular_ldpc_seed
+    from oracle import OracleDecoder
+
+    code = hgp(regular_ldpc_seed(31, 31, 3, 3, seed=3), compute_logicals=False)
+    H = code.hz
+    assert H.shape == (961, 1922) and set(np.diff(H.indptr)) == {6}
+    q = 0.04
+    _, syn = _syndromes(H, q, 1500, 9)
+    kw = dict(error_rate=q, max_iter=20, bp_method="ms", ms_scaling_factor=0.75, osd_method="osd_cs", osd_order=3)
+    a = BpOsdDecoder(H, **kw)
+    b = BpOsdDecoder(H, **kw)
+    b.set_bp_variant(2)
+    a.set_bp_variant(16)  # fails loudly if the local-edge kernel were not available for this code
+    ra, rb = _gpu_decode(a, syn), _gpu_decode(b, syn)
+    for k in ("osdw", "osd0", "bp", "converged", "iters"):
+        assert (ra[k] == rb[k]).all(), k
+    assert (ra["llr"].view(np.uint64) == rb["llr"].view(np.uint64)).all()
+    _compare_exact({k: v[:300] for k, v in ra.items()}, OracleDecoder(H, **kw).decode_batch(syn[:300]))
