@@ -758,3 +758,20 @@ def test_large_path_random_irregular_codes(gpu_ready):
     both = r["converged"] & ref["converged"].astype(bool)
     assert (r["converged"] == ref["converged"].astype(bool)).mean() > 0.9
     assert both.sum() >= 16 and (r["bp"][both] == ref["bp"][both]).mean() > 0.9999
+
+
+def test_large_code_eight_rows_per_thread(gpu_ready):
+    """HGP of the 72 x 72 circulant 1 + x^2 + x^5: hz is 5184 x 10368 -> the 8-rows-per-thread instantiation of the
+    large OSD kernel (4096 < m <= 8192); OSD-E against the oracle on three non-converging shots."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import circulant, hgp
+    from oracle import OracleDecoder
+
+    H = hgp(circulant(72, (0, 2, 5)), compute_logicals=False).hz
+    assert H.shape == (5184, 10368)
+    _, syn = _syndromes(H, 0.07, 3, 5)
+    kw = dict(error_rate=0.07, max_iter=5, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=3)
+    g = BpOsdDecoder(H, **kw)
+    o = OracleDecoder(H, **kw)
+    assert g.rank == o.rank
+    _compare_exact(_gpu_decode(g, syn), o.decode_batch(syn))
