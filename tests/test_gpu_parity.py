@@ -775,3 +775,19 @@ def test_large_code_eight_rows_per_thread(gpu_ready):
     o = OracleDecoder(H, **kw)
     assert g.rank == o.rank
     _compare_exact(_gpu_decode(g, syn), o.decode_batch(syn))
+
+
+def test_osd_off_on_the_small_path(gpu_ready, h1922, hgp400):
+    """osd_method="osd_off": BP only -- a non-converged shot returns BP's last hard decision in all three outputs
+    (local-edge kernel for H1922, LDS kernel for the irregular [[400,16,6]] code); compared with the oracle."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    for H, q in ((h1922.hz, 0.06), (hgp400.hx, 0.06)):
+        _, syn = _syndromes(H, q, 500, 17)
+        kw = dict(error_rate=q, max_iter=20, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_off")
+        g = BpOsdDecoder(H, **kw)
+        r = _gpu_decode(g, syn)
+        assert 0 < r["converged"].sum() < len(syn)  # both branches occur
+        _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
+        assert (r["osdw"] == r["bp"]).all() and (r["osd0"] == r["bp"]).all()
