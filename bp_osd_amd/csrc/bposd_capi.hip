@@ -571,17 +571,35 @@ void class_sorted(const Graph& g, Layout& L) {
         if (g.rank_of(L.load[2 * c], c) > g.rank_of(L.load[2 * c + 1], c)) std::swap(L.load[2 * c], L.load[2 * c + 1]);
         cls[g.rank_of(L.load[2 * c], c) * 3 + g.rank_of(L.load[2 * c + 1], c)].push_back(c);
     }
-    std::vector<int> order, rest;
-    for (int k = 0; k < 9; ++k) {
-        const size_t full = cls[k].size() / 64 * 64;
-        order.insert(order.end(), cls[k].begin(), cls[k].begin() + full);
-        rest.insert(rest.end(), cls[k].begin() + full, cls[k].end());
-    }
-    L.nfull = (int)order.size();
-    order.insert(order.end(), rest.begin(), rest.end());
+    // full groups of one class first; then, while the 64-position groups suffice, the largest leftover classes get a
+    // partly filled group of their own (still uniform, and its empty positions give the search slack); what remains
+    // shares the mixed group(s) at the end
     L.pos_chk.assign(g.MP, -1);
     L.pos_of.assign(m, -1);
-    for (int p = 0; p < m; ++p) { L.pos_chk[p] = order[p]; L.pos_of[order[p]] = p; }
+    int p = 0;
+    std::vector<std::vector<int>> left(9);
+    for (int k = 0; k < 9; ++k) {
+        const size_t full = cls[k].size() / 64 * 64;
+        for (size_t q = 0; q < full; ++q) { L.pos_chk[p] = cls[k][q]; L.pos_of[cls[k][q]] = p; ++p; }
+        left[k].assign(cls[k].begin() + full, cls[k].end());
+    }
+    const int G = g.MP / 64;
+    for (;;) {
+        int nleft = 0, big = -1;
+        for (int k = 0; k < 9; ++k) {
+            nleft += (int)left[k].size();
+            if (!left[k].empty() && (big < 0 || left[k].size() > left[big].size())) big = k;
+        }
+        const int used = p / 64;
+        // peel the largest leftover class off only if the others still fit behind it
+        if (big < 0 || nleft <= 64 || used + 1 + (nleft - (int)left[big].size() + 63) / 64 > G) break;
+        for (int c : left[big]) { L.pos_chk[p] = c; L.pos_of[c] = p; ++p; }
+        left[big].clear();
+        p = (p + 63) / 64 * 64;
+    }
+    L.nfull = p;
+    for (int k = 0; k < 9; ++k)
+        for (int c : left[k]) { L.pos_chk[p] = c; L.pos_of[c] = p; ++p; }
 }
 
 }  // namespace local_layout
