@@ -52,6 +52,8 @@ struct BpLocalParams {
     int* __restrict__ out_iters;
     double* __restrict__ out_llr;
     double* __restrict__ llr_ws;
+    double* __restrict__ llr_tmp;          // [gridDim.x][n] LLRs of the syndrome a workgroup is on, written only when they
+                                           // will be read: in the last iteration, or every iteration if out_llr is set
     int* __restrict__ osd_list;
     int* __restrict__ counters;
     unsigned long long* __restrict__ iter_total;
@@ -189,14 +191,21 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                 }
         }
         // ---- a3: every edge's bit->check message starts at the prior (two in LDS, one in a register)
-        double llr[NB], loc[NB];
+        double loc[NB];
+        double* llrt = P.llr_tmp + (size_t)blockIdx.x * n;
         unsigned int decmask = 0u;  // bit r: hard decision of my r-th bit
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-            llr[r] = l0[r];
             loc[r] = l0[r];
             msg[alo[r]] = l0[r];
             msg[ahi[r]] = l0[r];
+        }
+        if (P.out_llr) {  // a syndrome that needs no iteration reports the priors
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int i = P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT];
+                if (i >= 0) llrt[i] = l0[r];
+            }
         }
         __syncthreads();
 
@@ -262,23 +271,30 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                 }
                 if (tid == 0) sh[fi ^ 1] = 0;
                 // ============ bit pass: posterior, decision, bit -> check (a6 / a7) ============
+                const bool keep_llr = (it == P.max_iter) || (P.out_llr != nullptr);  // uniform
+                // the two LDS messages of every owned bit: all of them up front (latency hidden inside the thread), or,
+                // for the register-capped high-occupancy variant, two bits at a time
+                constexpr int BATCH = (MINW >= 8 && NB > 2) ? 2 : NB;
                 double X[NB], Y[NB];
 #pragma unroll
                 for (int r = 0; r < NB; ++r) {
-                    X[r] = msg[alo[r]];
-                    Y[r] = msg[ahi[r]];
-                }
+                    if (r % BATCH == 0) {
 #pragma unroll
-                for (int r = 0; r < NB; ++r) {
-                    double oR, oX, oY;
-                    if (dl[r] == 0) bit_update<0>(l0[r], loc[r], X[r], Y[r], llr[r], oR, oX, oY);
-                    else if (dl[r] == 1) bit_update<1>(l0[r], loc[r], X[r], Y[r], llr[r], oR, oX, oY);
-                    else if (dl[r] == 2) bit_update<2>(l0[r], loc[r], X[r], Y[r], llr[r], oR, oX, oY);
-                    else bit_update_mixed((int)((dlpack >> (2 * r)) & 3u), l0[r], loc[r], X[r], Y[r], llr[r], oR, oX, oY);
+                        for (int q = r; q < r + BATCH; ++q) {
+                            X[q] = msg[alo[q]];
+                            Y[q] = msg[ahi[q]];
+                        }
+                    }
+                    double oR, oX, oY, t;
+                    if (dl[r] == 0) bit_update<0>(l0[r], loc[r], X[r], Y[r], t, oR, oX, oY);
+                    else if (dl[r] == 1) bit_update<1>(l0[r], loc[r], X[r], Y[r], t, oR, oX, oY);
+                    else if (dl[r] == 2) bit_update<2>(l0[r], loc[r], X[r], Y[r], t, oR, oX, oY);
+                    else bit_update_mixed((int)((dlpack >> (2 * r)) & 3u), l0[r], loc[r], X[r], Y[r], t, oR, oX, oY);
+                    if (keep_llr && bvalid[r]) llrt[P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT]] = t;
                     loc[r] = oR;
                     msg[alo[r]] = oX;
                     msg[ahi[r]] = oY;
-                    const unsigned int dnew = (llr[r] <= 0.0) ? 1u : 0u;
+                    const unsigned int dnew = (t <= 0.0) ? 1u : 0u;
                     if (bvalid[r] && dnew != ((decmask >> r) & 1u)) {
                         decmask ^= 1u << r;
                         int pa = alo[r], pb = ahi[r];
@@ -318,9 +334,9 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                     P.out_osdw[o] = b;
                     if (P.out_osd0) P.out_osd0[o] = b;
                 } else {
-                    P.llr_ws[(size_t)slot * n + i] = llr[r];
+                    P.llr_ws[(size_t)slot * n + i] = llrt[i];
                 }
-                if (P.out_llr) P.out_llr[o] = llr[r];
+                if (P.out_llr) P.out_llr[o] = llrt[i];
             }
         }
         __syncthreads();

@@ -56,7 +56,7 @@ struct bposd_handle {
     long long local_passes = 0;  // simulated LDS passes of the bit pass in the chosen layout (ideal: 4 * MP / 32)
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
     bool large = false;  // beyond the LDS-resident kernels: HBM-resident messages / matrix
-    DevBuf bpl_msg, bpl_llr;  // large BP workspaces
+    DevBuf bpl_msg, bpl_llr;  // large BP workspaces (bpl_llr also serves the local-edge kernel: LLRs of the current syndrome)
     DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
     int max_iter = 0;
     int rank = 0, kprime = 0, ncand = 0;
@@ -791,7 +791,11 @@ int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
     wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
     long long grid = std::min<long long>(L.B, (long long)h->num_cu * wg_per_cu);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->stream, L);
+    int rc = ensure(h, h->bpl_llr, sizeof(double) * (size_t)grid * h->n);
+    if (rc) return rc;
+    BpLocalParams Lq = L;
+    Lq.llr_tmp = (double*)h->bpl_llr.p;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->stream, Lq);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
