@@ -791,3 +791,22 @@ def test_osd_off_on_the_small_path(gpu_ready, h1922, hgp400):
         assert 0 < r["converged"].sum() < len(syn)  # both branches occur
         _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
         assert (r["osdw"] == r["bp"]).all() and (r["osd0"] == r["bp"]).all()
+
+
+def test_large_osd_workgroups_process_several_syndromes(gpu_ready, hgp4050):
+    """More non-converged syndromes than workgroups: every persistent OSD workgroup takes several syndromes from the
+    queue, so its per-workgroup workspaces (matrix, pivot maps, candidate weights, open-group state) are reused."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = hgp4050.hz
+    _, syn = _syndromes(H, 0.06, 640, 41)
+    for method, order, nref in (("osd_0", 0, 640), ("osd_cs", 3, 40)):
+        kw = dict(error_rate=0.06, max_iter=1, bp_method="ms", ms_scaling_factor=0.625, osd_method=method, osd_order=order)
+        g = BpOsdDecoder(H, **kw)
+        r = _gpu_decode(g, syn, want_llr=False)
+        assert (~r["converged"]).sum() > 600  # > 256 CUs: queue depth 2-3 per workgroup
+        ref = OracleDecoder(H, **kw).decode_batch(syn[:nref])
+        _compare_exact({k: (v[:nref] if v is not None else None) for k, v in r.items()}, ref)
+        got = r["osdw"].astype(np.int32)
+        assert (((H.astype(np.int32) @ got.T) % 2).T == syn).all()  # all 640 corrections reproduce their syndromes
