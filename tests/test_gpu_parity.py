@@ -810,3 +810,17 @@ def test_large_osd_workgroups_process_several_syndromes(gpu_ready, hgp4050):
         _compare_exact({k: (v[:nref] if v is not None else None) for k, v in r.items()}, ref)
         got = r["osdw"].astype(np.int32)
         assert (((H.astype(np.int32) @ got.T) % 2).T == syn).all()  # all 640 corrections reproduce their syndromes
+
+
+def test_large_bp_workgroups_process_several_syndromes(gpu_ready, hgp4050):
+    """More syndromes than resident workgroups of the large BP kernel (256 CUs x 4): the per-workgroup message and LLR
+    slices are reused from syndrome to syndrome; decisions, iteration counts and LLR bits against the oracle."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = hgp4050.hz
+    _, syn = _syndromes(H, 0.035, 3000, 77)
+    kw = dict(error_rate=0.035, max_iter=12, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_off")
+    r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
+    assert 0 < r["converged"].sum() < len(syn)
+    _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
