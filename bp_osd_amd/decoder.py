@@ -263,11 +263,22 @@ class BpOsdDecoder:
         return osdw[0].astype(dtype)
 
     def decode_batch_device(self, d_syndromes, B, d_osdw, d_osd0=None, d_bp=None, d_converged=None,
-                            d_iters=None, d_llr=None):
+                            d_iters=None, d_llr=None, d_prior_select=None, alt_channel_probs=None):
         """Asynchronous decode on device pointers (ints, e.g. ``tensor.data_ptr()``) that live on this
-        decoder's device; call :meth:`synchronize` before reading the outputs."""
-        rc = self._lib.bposd_decode_batch_device(self._h, d_syndromes, int(B), d_osdw, d_osd0, d_bp,
-                                                 d_converged, d_iters, d_llr)
+        decoder's device; call :meth:`synchronize` before reading the outputs.  ``d_prior_select`` (device uint8
+        [B, n]) with ``alt_channel_probs`` (host array of n floats) is the per-shot two-valued channel of
+        :meth:`decode_batch`."""
+        if d_prior_select is not None:
+            if alt_channel_probs is None:
+                raise ValueError("alt_channel_probs is required with d_prior_select")
+            alt = np.ascontiguousarray(alt_channel_probs, dtype=np.float64)
+            if alt.shape != (self.n,):
+                raise ValueError(f"alt_channel_probs must have length {self.n}")
+            rc = self._lib.bposd_decode_batch_select_device(self._h, d_syndromes, int(B), d_prior_select, alt.ctypes.data,
+                                                            d_osdw, d_osd0, d_bp, d_converged, d_iters, d_llr)
+        else:
+            rc = self._lib.bposd_decode_batch_device(self._h, d_syndromes, int(B), d_osdw, d_osd0, d_bp,
+                                                     d_converged, d_iters, d_llr)
         _lib.check(self._lib, self._h, rc)
 
     def pack_rows_device(self, d_bytes, B, n, d_words):

@@ -824,3 +824,31 @@ def test_large_bp_workgroups_process_several_syndromes(gpu_ready, hgp4050):
     r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
     assert 0 < r["converged"].sum() < len(syn)
     _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
+
+
+def test_device_pointer_api_with_prior_select(gpu_ready, h1922):
+    """bposd_decode_batch_select_device: per-shot two-valued channel with everything resident on the device equals the
+    host-pointer call."""
+    import torch
+
+    from bp_osd_amd import BpOsdDecoder
+
+    H = h1922.hx
+    n = H.shape[1]
+    _, syn = _syndromes(H, 0.06, 700, 3)
+    rng = np.random.default_rng(8)
+    sel = (rng.random((700, n)) < 0.25).astype(np.uint8)
+    alt = rng.uniform(0.02, 0.2, n)
+    kw = dict(error_rate=0.06, max_iter=15, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=4)
+    a = BpOsdDecoder(H, **kw)
+    want = a.decode_batch(syn, prior_select=sel, alt_channel_probs=alt)
+    b = BpOsdDecoder(H, **kw)
+    d_syn, d_sel = torch.from_numpy(syn).cuda(), torch.from_numpy(sel).cuda()
+    d_out = torch.empty((700, n), dtype=torch.uint8, device="cuda")
+    d_conv = torch.empty(700, dtype=torch.uint8, device="cuda")
+    b.decode_batch_device(d_syn.data_ptr(), 700, d_out.data_ptr(), d_converged=d_conv.data_ptr(),
+                          d_prior_select=d_sel.data_ptr(), alt_channel_probs=alt)
+    b.synchronize()
+    assert (d_out.cpu().numpy() == want).all() and (d_conv.cpu().numpy().astype(bool) == a.batch_converge).all()
+    with pytest.raises(ValueError):
+        b.decode_batch_device(d_syn.data_ptr(), 700, d_out.data_ptr(), d_prior_select=d_sel.data_ptr())
