@@ -224,19 +224,24 @@ class css_decode_sim:
     def _encoded_error_rates(self, error_x, error_z, rx, rz):  # css_decode_sim.py:250-365
         B = len(error_x)
         self.run_count += B
+        self.bp_converge_count_z += int(rz["conv"].sum())
+        self.bp_converge_count_x += int(rx["conv"].sum())
+        both = rz["conv"] & rx["conv"]
+        fx_bp, fz_bp, w_bp = self._logical_fail(error_x, error_z, rx["bp"], rz["bp"])
+        self.bp_success_count += int((both & ~(fx_bp | fz_bp)).sum())
+        # where both decoders converged, osdw = osd0 = bp in both sectors (decode contract, README.md:197-202 /
+        # SURVEY Appendix A.2), so the logical checks of those shots are the BP ones; only the rest is recomputed
+        rest = np.flatnonzero(~both)
         for key in ("osdw", "osd0"):
-            fx, fz, weight = self._logical_fail(error_x, error_z, rx[key], rz[key])
+            fx, fz, weight = fx_bp.copy(), fz_bp.copy(), w_bp.copy()
+            if rest.size:
+                fx[rest], fz[rest], weight[rest] = self._logical_fail(error_x[rest], error_z[rest], rx[key][rest], rz[key][rest])
             failed = fx | fz
             if failed.any():
                 wmin = int(weight[failed].min())
                 if wmin < self.min_logical_weight:
                     self.min_logical_weight = wmin
             setattr(self, f"{key}_success_count", getattr(self, f"{key}_success_count") + int((~failed).sum()))
-        self.bp_converge_count_z += int(rz["conv"].sum())
-        self.bp_converge_count_x += int(rx["conv"].sum())
-        both = rz["conv"] & rx["conv"]
-        fx, fz, _ = self._logical_fail(error_x, error_z, rx["bp"], rz["bp"])
-        self.bp_success_count += int((both & ~(fx | fz)).sum())
         self._update_rates()
 
     def _update_rates(self):
