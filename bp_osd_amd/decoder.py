@@ -124,6 +124,7 @@ class BpOsdDecoder:
         self._lib = lib
         cfg = _lib.BposdConfig()
         cfg.device = int(device)
+        self.device = int(device)
         cfg.bp_method = int(self._bp_method)
         cfg.ms_scaling_factor = self._ms
         cfg.max_iter = max_iter

@@ -11,6 +11,13 @@ after ``np.random.seed(seed)`` (css_decode_sim.py:135-138,471-472); ``np.random.
 same stream in the same order, so with equal decoders this harness sees exactly the reference's errors.
 What is NOT reproduced: tqdm, wall-clock based saving/early-stop points (the error-bar cut-off is checked
 after every batch instead), the hadamard_rotate option's print-outs.
+
+``engine="torch"`` keeps a whole batch on the GPU: errors, syndromes (sparse products), both decoders through their
+device-pointer API (the two handles overlap when there is no channel update) and the logical checks, so that the
+harness runs at the decoders' rate instead of numpy's (34 k runs/s on the [[1922,50]] code).  With ``rng="numpy"`` the
+random numbers still come from numpy's legacy stream (uploaded), which makes the counters identical to the default
+engine's; ``rng="torch"`` draws them on the device (seeded, but a different stream).  torch is plumbing here (device
+buffers, sparse products); every decode runs in the HIP kernels either way.
 """
 from __future__ import annotations
 
@@ -97,7 +104,14 @@ class css_decode_sim:
         ``BpOsdDecoder``); tests inject a CPU-oracle adapter here.
     """
 
-    def __init__(self, hx=None, hz=None, batch_size=4096, decoder_factory=None, **input_dict):
+    def __init__(self, hx=None, hz=None, batch_size=4096, decoder_factory=None, engine="numpy", rng="numpy", **input_dict):
+        if engine not in ("numpy", "torch") or rng not in ("numpy", "torch"):
+            raise ValueError("engine and rng must be 'numpy' or 'torch'")
+        if engine == "torch" and decoder_factory is not None:
+            raise ValueError("engine='torch' drives the MI355X decoders through device pointers; decoder_factory must be None")
+        if engine == "numpy" and rng == "torch":
+            raise ValueError("rng='torch' needs engine='torch'")
+        self._engine, self._rng = engine, rng
         for key, val in input_dict.items():  # css_decode_sim.py:87-91: anything passed overrides
             self.__dict__[key] = val
         for key, val in _DEFAULT_INPUT.items():
@@ -106,7 +120,7 @@ class css_decode_sim:
         for key, val in _OUTPUT_VALUES.items():  # resume: output keys present in the input win (:117-119)
             if key not in self.__dict__:
                 self.__dict__[key] = val
-        self.output_keys = [k for k in self.__dict__ if k not in _NOT_SAVED]
+        self.output_keys = [k for k in self.__dict__ if k not in _NOT_SAVED and not k.startswith("_")]
         self._batch_size = int(batch_size)
         self._factory = decoder_factory or _default_decoder_factory
 
@@ -191,7 +205,107 @@ class css_decode_sim:
         p_if_zero = other_probs / (1 - first_probs - py)
         return p_if_one, p_if_zero
 
+    # ------------------------------------------------------------------ one batch, resident on the device
+    def _torch_setup(self):
+        import torch
+
+        self._torch = torch
+        dev = self._dev = torch.device("cuda", getattr(self.bpd_x, "device", 0))
+
+        def sparse_t(a):
+            a = sp.csr_matrix(a)
+            return torch.sparse_csr_tensor(torch.from_numpy(a.indptr.astype(np.int64)), torch.from_numpy(a.indices.astype(np.int64)),
+                                           torch.ones(a.nnz, dtype=torch.float32), size=a.shape).to(dev)
+
+        self._t_hx, self._t_hz = sparse_t(self.hx), sparse_t(self.hz)
+        self._t_lx = torch.from_numpy(np.asarray(self.lx, dtype=np.float32)).to(dev)
+        self._t_lz = torch.from_numpy(np.asarray(self.lz, dtype=np.float32)).to(dev)
+        self._t_p = [torch.from_numpy(np.asarray(v, dtype=np.float64)).to(dev)
+                     for v in (self.channel_probs_z, self.channel_probs_x, self.channel_probs_y)]
+        self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(int(self.seed))
+        self._t_out = {}
+
+    def _torch_outputs(self, name, B):
+        torch = self._torch
+        key = (name, B)
+        if key not in self._t_out:
+            mk = lambda: torch.empty((B, self.N), dtype=torch.uint8, device=self._dev)
+            self._t_out[key] = dict(osdw=mk(), osd0=mk(), bp=mk(), conv=torch.empty(B, dtype=torch.uint8, device=self._dev))
+        return self._t_out[key]
+
+    def _torch_launch(self, dec, syn, out, select=None, alt=None):
+        dec.decode_batch_device(syn.data_ptr(), syn.shape[0], out["osdw"].data_ptr(), out["osd0"].data_ptr(),
+                                out["bp"].data_ptr(), out["conv"].data_ptr(), None, None,
+                                d_prior_select=None if select is None else select.data_ptr(), alt_channel_probs=alt)
+
+    def _run_batch_torch(self, B):
+        if not hasattr(self, "_dev"):
+            self._torch_setup()
+        torch = self._torch
+        if self._rng == "numpy":
+            rand = torch.from_numpy(np.random.random((B, self.N))).to(self._dev)
+        else:
+            rand = torch.rand((B, self.N), dtype=torch.float64, device=self._dev, generator=self._gen)
+        pz, px, py = self._t_p
+        is_y = (pz + px <= rand) & (rand < px + py + pz)
+        error_z = ((rand < pz) | is_y).to(torch.uint8)
+        error_x = (((pz <= rand) & (rand < pz + px)) | is_y).to(torch.uint8)
+        del rand, is_y
+
+        def mod2(a, x):  # (A @ X^T mod 2)^T, uint8 [B, rows]; exact in float32 (row weights far below 2^24)
+            return (torch.sparse.mm(a, x.to(torch.float32).T) if a.layout != torch.strided else a @ x.to(torch.float32).T
+                    ).remainder_(2).T.contiguous().to(torch.uint8)
+
+        synd_z, synd_x = mod2(self._t_hx, error_z), mod2(self._t_hz, error_x)
+        torch.cuda.synchronize(self._dev)  # the decoders run on their own streams
+        oz, ox = self._torch_outputs("z", B), self._torch_outputs("x", B)
+        if self.channel_update is None:
+            self._torch_launch(self.bpd_z, synd_z, oz)
+            self._torch_launch(self.bpd_x, synd_x, ox)
+        elif self.channel_update == "x->z":
+            self._torch_launch(self.bpd_x, synd_x, ox)
+            self.bpd_x.synchronize()
+            p1, p0 = self._updated_channel(self.channel_probs_x, self.channel_probs_z)
+            self.bpd_z.update_channel_probs(p0)
+            self._torch_launch(self.bpd_z, synd_z, oz, select=ox["osdw"], alt=p1)
+        elif self.channel_update == "z->x":
+            self._torch_launch(self.bpd_z, synd_z, oz)
+            self.bpd_z.synchronize()
+            p1, p0 = self._updated_channel(self.channel_probs_z, self.channel_probs_x)
+            self.bpd_x.update_channel_probs(p0)
+            self._torch_launch(self.bpd_x, synd_x, ox, select=oz["osdw"], alt=p1)
+        else:
+            raise ValueError(f"channel_update='{self.channel_update}' is invalid")
+        self.bpd_z.synchronize()
+        self.bpd_x.synchronize()
+
+        def logical_fail(dx, dz):  # css_decode_sim.py:257-272
+            rx_, rz_ = error_x ^ dx, error_z ^ dz
+            fx = (mod2(self._t_lz, rx_) != 0).any(dim=1)  # bool (torch.any of a uint8 tensor would stay uint8)
+            fz = (mod2(self._t_lx, rz_) != 0).any(dim=1)
+            weight = torch.where(fx, rx_.sum(dim=1, dtype=torch.int64), rz_.sum(dim=1, dtype=torch.int64))
+            return fx, fz, weight
+
+        self.run_count += B
+        conv_z, conv_x = oz["conv"] != 0, ox["conv"] != 0
+        self.bp_converge_count_z += int(conv_z.sum().item())
+        self.bp_converge_count_x += int(conv_x.sum().item())
+        fx, fz, _ = logical_fail(ox["bp"], oz["bp"])
+        self.bp_success_count += int(((conv_z & conv_x) & ~(fx | fz)).sum().item())
+        for key in ("osdw", "osd0"):
+            fx, fz, weight = logical_fail(ox[key], oz[key])
+            failed = fx | fz
+            if bool(failed.any().item()):
+                wmin = int(weight[failed].min().item())
+                if wmin < self.min_logical_weight:
+                    self.min_logical_weight = wmin
+            setattr(self, f"{key}_success_count", getattr(self, f"{key}_success_count") + int((~failed).sum().item()))
+        self._update_rates()
+
     def _run_batch(self, B):
+        if self._engine == "torch":
+            return self._run_batch_torch(B)
         error_x, error_z = self._generate_errors(B)
         synd_z = _mod2_mul(self.hx, error_z)
         synd_x = _mod2_mul(self.hz, error_x)

@@ -852,3 +852,25 @@ def test_device_pointer_api_with_prior_select(gpu_ready, h1922):
     assert (d_out.cpu().numpy() == want).all() and (d_conv.cpu().numpy().astype(bool) == a.batch_converge).all()
     with pytest.raises(ValueError):
         b.decode_batch_device(d_syn.data_ptr(), 700, d_out.data_ptr(), d_prior_select=d_sel.data_ptr())
+
+
+@pytest.mark.parametrize("channel_update", [None, "x->z", "z->x"])
+def test_harness_torch_engine_equals_numpy_engine(gpu_ready, hgp400, channel_update):
+    """engine="torch" (errors, syndromes, decoders and logical checks resident on the GPU) fed with numpy's random
+    stream ends with exactly the counters of the default engine; with its own device RNG it agrees statistically."""
+    from bp_osd_amd.sim import css_decode_sim
+
+    opts = dict(error_rate=0.08, xyz_error_bias=[1, 1, 1], target_runs=3000, seed=11, channel_update=channel_update,
+                bp_method="ms", ms_scaling_factor=0, max_iter=0, osd_method="osd_cs", osd_order=5, tqdm_disable=1)
+    a = css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, batch_size=1024, **opts)
+    b = css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, batch_size=1024, engine="torch", rng="numpy", **opts)
+    for k in ("run_count", "osdw_success_count", "osd0_success_count", "bp_success_count", "bp_converge_count_x",
+              "bp_converge_count_z", "min_logical_weight", "osdw_logical_error_rate", "osdw_word_error_rate"):
+        assert getattr(a, k) == getattr(b, k), (k, getattr(a, k), getattr(b, k))
+    c = css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, batch_size=1500, engine="torch", rng="torch", **opts)
+    assert c.run_count == 3000
+    assert abs(c.osdw_logical_error_rate - a.osdw_logical_error_rate) < 5 * max(a.osdw_logical_error_rate_eb, 1e-3)
+    assert abs(c.bp_converge_count_x - a.bp_converge_count_x) < 200
+    assert "engine" not in c.output_dict() and "_engine" not in c.output_dict()
+    with pytest.raises(ValueError):
+        css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, engine="numpy", rng="torch", run_sim=0, **opts)
