@@ -51,3 +51,21 @@ def test_output_dict_keys_and_resume(surface13, tmp_path):
 def test_invalid_code_rejected(surface13):
     with pytest.raises(Exception, match="invalid CSS code"):
         css_decode_sim(hx=surface13.hx, hz=surface13.hx, decoder_factory=OracleAdapter, error_rate=0.05)
+
+
+def test_engine_arguments_are_validated():
+    """engine / rng switches of the batched harness (host-side checks only; the torch engine itself needs a GPU)."""
+    from bp_osd_amd.codes import surface13
+    from bp_osd_amd.sim import css_decode_sim
+    from tests.sim_util import OracleAdapter
+
+    c = surface13()
+    base = dict(hx=c.hx, hz=c.hz, error_rate=0.05, target_runs=4, seed=3, run_sim=0, tqdm_disable=1)
+    with pytest.raises(ValueError):
+        css_decode_sim(engine="cuda", decoder_factory=OracleAdapter, **base)
+    with pytest.raises(ValueError):
+        css_decode_sim(engine="numpy", rng="torch", decoder_factory=OracleAdapter, **base)
+    with pytest.raises(ValueError):
+        css_decode_sim(engine="torch", decoder_factory=OracleAdapter, **base)
+    sim = css_decode_sim(decoder_factory=OracleAdapter, **base)
+    assert "engine" not in sim.output_dict() and "_rng" not in sim.output_dict()
