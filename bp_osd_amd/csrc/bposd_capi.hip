@@ -55,7 +55,8 @@ struct bposd_handle {
     int local_mp = 0;
     long long local_passes = 0;  // simulated LDS passes of the bit pass in the chosen layout (ideal: 4 * MP / 32)
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
-    bool large = false;  // beyond the LDS-resident kernels: HBM-resident messages / matrix
+    bool large = false;   // beyond the register-resident OSD kernel: HBM-resident matrix, device rank probe
+    bool bp_hbm = false;  // BP messages do not fit one CU's LDS either: HBM-resident BP kernel
     DevBuf bpl_msg, bpl_llr;  // large BP workspaces (bpl_llr also serves the local-edge kernel: LLRs of the current syndrome)
     DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
     int max_iter = 0;
@@ -379,10 +380,13 @@ int pow2_at_least(int x) {
 // The regular (6,3) kernels are compiled for MP = 1024 exactly (H1922: 961 checks, 1922 bits).
 bool is_reg63(const bposd_handle* h) { return h->regular && h->dc_max == 6 && h->dv_max == 3; }
 
+// shape 8 = "mid-size": 2 checks / 4 bits per thread with 1024 threads (1024 < m <= 2048, n <= 4096): one workgroup per CU
+int shape_cpt(int shape) { return shape == 8 ? 2 : shape; }
+
 int shape_threads(const bposd_handle* h, int shape) {
-    const int cpt = shape, vpt = 2 * shape;
+    const int cpt = shape_cpt(shape), vpt = 2 * cpt;
     int nt = pow2_at_least(std::max((h->m + cpt - 1) / cpt, (h->n + vpt - 1) / vpt));
-    if (is_reg63(h) && nt <= 1024 / shape) nt = 1024 / shape;
+    if (is_reg63(h) && shape != 8 && nt <= 1024 / shape) nt = 1024 / shape;
     return nt;
 }
 
@@ -396,6 +400,7 @@ int pick_shape(const bposd_handle* h) {
     // generic kernels: one check per thread when that fits, else two
     if (shape_threads(h, 1) <= 1024) return 1;
     if (shape_threads(h, 2) <= 512) return 2;
+    if (shape_threads(h, 8) <= 1024) return 8;
     return 0;
 }
 
@@ -410,6 +415,8 @@ int launch_bp_shape(bposd_handle* h, const BpParams& P, int shape, int NT) {
     if (shape == 2) return launch_bp_t<DC, DV, 2, 4, 512, (REG ? BPOSD_SHAPE2_MINW : 2), REG, (REG ? 1024 : 0)>(h, P, NT);
     if constexpr (REG) {
         if (shape == 4) return launch_bp_t<DC, DV, 4, 8, 256, 3, REG, 1024>(h, P, NT);
+    } else {
+        if (shape == 8) return launch_bp_t<DC, DV, 2, 4, 1024, 4, false, 0>(h, P, NT);
     }
     return fail(h, BPOSD_ERR_UNSUPPORTED, "no BP kernel shape %d for this code", shape);
 }
@@ -418,11 +425,11 @@ int launch_bp(bposd_handle* h, BpParams& P) {
     int shape = pick_shape(h);
     if (!shape) return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the LDS-resident BP kernel (m=%d n=%d)", h->m, h->n);
     const int NT = shape_threads(h, shape);
-    const int MP = NT * shape;
-    const int NPOS = NT * 2 * shape;
+    const int MP = NT * shape_cpt(shape);
+    const int NPOS = NT * 2 * shape_cpt(shape);
     if (MP != h->tab_mp || NPOS != h->tab_np) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        int rc = build_tables(h, h->tab_dc, h->tab_dv, MP, NT, 2 * shape);
+        int rc = build_tables(h, h->tab_dc, h->tab_dv, MP, NT, 2 * shape_cpt(shape));
         if (rc) return rc;
         P.chk_deg = h->d_chk_deg;
         P.var_deg = h->d_var_deg;
@@ -616,7 +623,7 @@ int build_tables_local(bposd_handle* h) {
     h->local_ok = false;
     const int m = h->m, n = h->n;
     if (!(h->regular && h->dc_max == 6 && h->dv_max == 3 && n == 2 * m)) return 0;
-    const int MP = 1024;  // the kernels are compiled for 1024 positions (H1922: 961 checks)
+    const int MP = m <= 1024 ? 1024 : 2048;  // the kernels are compiled for 1024 (H1922: 961 checks) and 2048 positions
     if (m > MP) return 0;
     Graph g;
     g.m = m; g.n = n; g.MP = MP;
@@ -779,10 +786,10 @@ int build_tables_local(bposd_handle* h) {
     return 0;
 }
 
-template <int CPT, int MINW>
+template <int CPT, int MP, int MINW>
 int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
-    auto k = bp_local_kernel<CPT, 1024, MINW>;
-    const int nt = 1024 / CPT;
+    auto k = bp_local_kernel<CPT, MP, MINW>;
+    const int nt = MP / CPT;
     const size_t lds = bp_local_lds_bytes(L.mp);
     HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int wg_per_cu = 1;
@@ -809,9 +816,10 @@ int launch_bp_local(bposd_handle* h, const BpParams& P) {
     L.grp_dl = h->d_lgrp_dl; L.pos_dl = h->d_lpos_dl;
     L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv; L.out_iters = P.out_iters;
     L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list; L.counters = P.counters; L.iter_total = P.iter_total;
-    if (h->bp_variant == 17) return launch_bp_local_t<2, 8>(h, L);   // 512 threads, <= 64 VGPRs: 4 workgroups per CU
-    if (h->bp_variant == 18) return launch_bp_local_t<1, 8>(h, L);   // 1024 threads, <= 64 VGPRs: 2 workgroups per CU
-    return launch_bp_local_t<2, 6>(h, L);                            // 512 threads, <= 80 VGPRs: 3 workgroups per CU
+    if (h->local_mp == 2048) return launch_bp_local_t<2, 2048, 4>(h, L);  // 1024 threads, one workgroup per CU
+    if (h->bp_variant == 17) return launch_bp_local_t<2, 1024, 8>(h, L);   // 512 threads, <= 64 VGPRs: 4 workgroups per CU
+    if (h->bp_variant == 18) return launch_bp_local_t<1, 1024, 8>(h, L);   // 1024 threads, <= 64 VGPRs: 2 workgroups per CU
+    return launch_bp_local_t<2, 1024, 6>(h, L);                            // 512 threads, <= 80 VGPRs: 3 workgroups per CU
 }
 
 // ------------------------------------------------------------------------ large-code BP launch
@@ -1165,10 +1173,13 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
         return BPOSD_ERR_UNSUPPORTED;
     }
     // small path: messages in LDS, OSD rows in registers.  Anything beyond goes to the HBM-resident kernels.
-    h->large = (m > 1024) || (osd_words(n) == 0) || !pick_shape(h) ||
-               bp_lds_bytes(pair.dc, shape_threads(h, pick_shape(h)) * pick_shape(h)) > h->lds_per_cu;
+    // BP in LDS whenever a workgroup shape holds the messages (up to 2048 checks); OSD in registers up to m = 1024 /
+    // n = 2047.  Anything beyond goes to the HBM-resident kernels, BP and OSD independently.
+    const int shp = pick_shape(h);
+    h->bp_hbm = !shp || bp_lds_bytes(pair.dc, shape_threads(h, shp) * shape_cpt(shp)) > h->lds_per_cu;
+    h->large = (m > 1024) || (osd_words(n) == 0) || h->bp_hbm;
     if (h->large) {
-        if (n > 32767 || m > 16384 || bp_large_lds_bytes(m, n) > h->lds_per_cu) {
+        if (n > 32767 || m > 16384 || (h->bp_hbm && bp_large_lds_bytes(m, n) > h->lds_per_cu)) {
             fail(nullptr, BPOSD_ERR_UNSUPPORTED, "code too large even for the HBM-resident kernels (m=%d n=%d; limits 16384 / 32767)", m, n);
             bposd_destroy(h);
             return BPOSD_ERR_UNSUPPORTED;
@@ -1226,10 +1237,9 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(hipMalloc((void**)&h->d_iter_total, sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc((void**)&h->h_counters, sizeof(int) * 4));
     CREATE_TRY(hipHostMalloc((void**)&h->h_iter_total, sizeof(unsigned long long)));
-    if (h->large) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
-    else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, pick_shape(h)) * pick_shape(h),
-                                shape_threads(h, pick_shape(h)), 2 * pick_shape(h)));
-    if (!h->large && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
+    if (h->bp_hbm) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
+    else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, shp) * shape_cpt(shp), shape_threads(h, shp), 2 * shape_cpt(shp)));
+    if (!h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
     CREATE_RC(upload_priors(h));
     if (h->large) {
         CREATE_RC(probe_rank_large(h, &h->rank));
@@ -1352,7 +1362,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.iter_total = h->d_iter_total;
 
     HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
-    if (h->large) {
+    if (h->bp_hbm) {
         BpLargeParams L{};
         L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling;
         L.osd_enabled = P.osd_enabled; L.mp = h->tab_mp;

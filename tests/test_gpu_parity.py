@@ -715,14 +715,16 @@ def test_local_edge_kernel_on_a_random_regular_product_code(gpu_ready):
 
 
 def test_large_path_random_irregular_codes(gpu_ready):
-    """Large-code path on random irregular matrices (m > 1024): check degrees 1..14, bit degrees 0..8 -> the <16,8>
-    BP instantiation, isolated bits, a rank-deficient instance, product-sum, tie policy; RPT = 2 OSD kernel."""
+    """Codes beyond m = 1024 on random irregular matrices: check degrees 1..14, bit degrees 0..8 -> the <16,8> HBM BP
+    instantiation, isolated bits, a rank-deficient instance, product-sum, tie policy, the RPT = 2 OSD kernel, and one
+    matrix with check degree <= 7 whose messages fit LDS (mid-size BP shape: 1024 threads, two checks each)."""
     import scipy.sparse as sp
     from bp_osd_amd import BpOsdDecoder
     from oracle import OracleDecoder
 
     rng = np.random.default_rng(99)
-    for trial, (m, n, wmax) in enumerate(((1100, 2600, 14), (1300, 2100, 9), (1500, 3200, 12))):
+    mats = []
+    for trial, (m, n, wmax) in enumerate(((1100, 2600, 14), (1300, 2100, 9), (1500, 3200, 12), (1200, 2500, 7))):
         rows, cols = [], []
         colw = np.zeros(n, dtype=int)
         for c in range(m):
@@ -737,27 +739,30 @@ def test_large_path_random_irregular_codes(gpu_ready):
         if trial == 1:  # rank deficient: the last check repeats the first
             H = sp.vstack([H[:-1], H[0]]).tocsr()
         H.sort_indices()
-        assert np.diff(H.indptr).max() > 8 or trial == 1
+        assert np.diff(H.indptr).max() > 8 or trial in (1, 3)  # trial 3 (check degree <= 7): mid-size LDS BP shape + large OSD
         q = 0.03
         err = (rng.random((24, n)) < q).astype(np.uint8)
         syn = np.asarray((H @ err.T) % 2).T.astype(np.uint8)
-        method, order = (("osd_cs", 5), ("osd_e", 6), ("osd_0", 0))[trial]
-        kw = dict(error_rate=q, max_iter=6 + trial, bp_method="ms", ms_scaling_factor=[0.0, 0.8, 1.0][trial],
+        method, order = (("osd_cs", 5), ("osd_e", 6), ("osd_0", 0), ("osd_cs", 4))[trial]
+        kw = dict(error_rate=q, max_iter=6 + trial, bp_method="ms", ms_scaling_factor=[0.0, 0.8, 1.0, 0.625][trial],
                   osd_method=method, osd_order=order, sort_tie_policy=trial % 2)
         g = BpOsdDecoder(H, **kw)
         c = OracleDecoder(H, **kw)
         assert g.rank == c.rank
         _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
-    # product-sum through the large BP kernel: integer outputs of converged shots, to the documented tolerance
-    kw = dict(error_rate=0.004, max_iter=40, bp_method="ps", osd_method="osd_off", osd_order=0)
-    err = (rng.random((64, n)) < 0.004).astype(np.uint8)
-    syn = np.asarray((H @ err.T) % 2).T.astype(np.uint8)
-    g = BpOsdDecoder(H, **kw)
-    r = _gpu_decode(g, syn, want_llr=False)
-    ref = OracleDecoder(H, **kw).decode_batch(syn)
-    both = r["converged"] & ref["converged"].astype(bool)
-    assert (r["converged"] == ref["converged"].astype(bool)).mean() > 0.9
-    assert both.sum() >= 16 and (r["bp"][both] == ref["bp"][both]).mean() > 0.9999
+        mats.append(H)
+    # product-sum through the HBM BP kernel (trial 2's matrix) and through the mid-size LDS shape (trial 3's): integer
+    # outputs of converged shots, to the documented tolerance
+    for H in (mats[2], mats[3]):
+        kw = dict(error_rate=0.002, max_iter=40, bp_method="ps", osd_method="osd_off", osd_order=0)
+        err = (rng.random((96, H.shape[1])) < 0.002).astype(np.uint8)
+        syn = np.asarray((H @ err.T) % 2).T.astype(np.uint8)
+        g = BpOsdDecoder(H, **kw)
+        r = _gpu_decode(g, syn, want_llr=False)
+        ref = OracleDecoder(H, **kw).decode_batch(syn)
+        both = r["converged"] & ref["converged"].astype(bool)
+        assert (r["converged"] == ref["converged"].astype(bool)).mean() > 0.9
+        assert both.sum() >= 8 and (r["bp"][both] == ref["bp"][both]).mean() > 0.9999
 
 
 def test_large_code_eight_rows_per_thread(gpu_ready):
