@@ -5,15 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W      (N > 1, one rank per GPU)
 
-A "step" is one pass of the hot path (BP kernel, then OSD kernel on the non-converged syndromes)
-over one batch of synthetic syndromes that is already resident in HBM, followed -- for N > 1 -- by
-the one exchange step the path has: the gather of the corrections to rank 0 over RCCL.  Syndromes
-are independent, so the batch is sharded across ranks with no other collective (weak scaling:
-per-GPU batch fixed at 131072 = 2^20 / 8, i.e. BASELINE.json configs[3] at N = 8).
+A "step" is one pass of the hot path (BP kernel, then OSD kernel on the non-converged syndromes) over one batch of
+synthetic syndromes that is already resident in HBM, producing every output the reference's decode produces
+(osdw, osd0, bp decodings, converge flag, iteration count), followed -- for N > 1 -- by the one exchange step the path
+has: the gather of the bit-packed corrections to rank 0 over RCCL.  Syndromes are independent, so the batch is sharded
+across ranks with no other collective (weak scaling: per-GPU batch fixed at 131072 = 2^20 / 8, i.e. BASELINE.json
+configs[3] at N = 8).  The step loop is bp_osd_amd.sharding.StepPipeline (the loop tests/test_sharding_cpu.py drives on
+gloo); consecutive steps overlap on the decoder handle's two lanes (HIP streams), --no-pipeline serialises them.
 
-Workload (BASELINE.json metric / north_star): [[1922,50]] hypergraph-product code, min-sum BP with
-the variable scaling factor, max_iter = n = 1922, osd_cs order 7, iid bit-flip noise p = 0.05.
-Other BASELINE configs are selectable with --config (parity-test cases, not the bench line).
+Workload (BASELINE.json metric / north_star): [[1922,50]] hypergraph-product code, min-sum BP with the variable scaling
+factor, max_iter = n = 1922, osd_cs order 7, iid bit-flip noise p = 0.05.  Other BASELINE configs are selectable with
+--config (parity-test cases, not the bench line).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the fields).
 """
@@ -32,16 +34,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (bp_method, ms_scaling_factor, max_iter, osd_method, osd_order, per-GPU batch)
-    "h1922_ms_cs7": ("ms", 0.0, 0, "osd_cs", 7, 131072),    # configs[3]: the metric's configuration
-    "h1922_ms_osd0": ("ms", 0.0, 0, "osd0", 0, 65536),      # configs[1]
-    "h1922_ps_cs60": ("ps", 0.0, 0, "osd_cs", 60, 65536),   # configs[2]
+    # name: (bp_method, ms_scaling_factor, max_iter, osd_method, osd_order, per-GPU batch, ps_clip)
+    "h1922_ms_cs7": ("ms", 0.0, 0, "osd_cs", 7, 131072, 0.0),    # configs[3]: the metric's configuration
+    "h1922_ms_osd0": ("ms", 0.0, 0, "osd0", 0, 65536, 0.0),      # configs[1]
+    # configs[2] as the reference computes it: product-sum without clipping saturates (tanh -> 1, log -> inf, NaN)
+    "h1922_ps_cs60": ("ps", 0.0, 0, "osd_cs", 60, 65536, 0.0),
+    # configs[2] with the build-owned switch ps_clip = 20 (check->bit messages clamped): the numerically live variant
+    "h1922_ps_cs60_clip20": ("ps", 0.0, 0, "osd_cs", 60, 65536, 20.0),
     # configs[4]: 14520 x 29524, HBM-resident kernels.  ms_scaling_factor = 0.625 is the reference harness's default
     # (css_decode_sim.py:71); with the variable factor (0) min-sum converges on < 0.1 % of these syndromes in 100 iterations
-    "l29k_ms_e15": ("ms", 0.625, 100, "osd_e", 15, 1024),
+    "l29k_ms_e15": ("ms", 0.625, 100, "osd_e", 15, 1024, 0.0),
 }
-CPU_SAMPLE = {"l29k_ms_e15": 1}  # the oracle needs ~4.5 s per elimination and ~7 ms per OSD-E candidate at this size
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# syndromes timed on ONE CPU thread / per worker of the all-cores leg (the oracle needs ~1 ms per H1922 syndrome,
+# ~4.5 s per L29k elimination plus ~7 ms per OSD-E candidate)
+CPU_SAMPLE = {"l29k_ms_e15": (1, 0), "h1922_ps_cs60": (512, 128)}
+CPU_SAMPLE_DEFAULT = (8192, 2048)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+CLOCK_HZ = 2.4e9        # peak shader clock (MI355X_MICROARCH.md, chip-level parameters)
+LDS_READ_B64_BYTES_PER_CLK = 256.0        # ds_read_b64, per CU (MI355X_MICROARCH.md, LDS table)
+LDS_WRITE_B64_BYTES_PER_CLK = 512.0 / 6   # ds_write_b64: 6 cycles per wave-instruction of 512 bytes
 
 
 def make_batch(H, q, B, seed, chunk=16384):
@@ -59,8 +70,21 @@ def make_batch(H, q, B, seed, chunk=16384):
     return err, syn
 
 
+def usable_cores():
+    """Host cores this process may use: the affinity mask, cut down to the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline_worker(args):
-    """Decode a slice with the CPU oracle (separate process, never touches the GPU)."""
+    """Decode a slice with the CPU oracle (in this process for the one-thread leg, in forked workers for the
+    all-cores leg; both run BEFORE the GPU is initialised and never touch it)."""
     hz_indptr, hz_indices, shape, kw, syn = args
     import scipy.sparse as sp
     from oracle import OracleDecoder
@@ -82,10 +106,13 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--p", type=float, default=0.05, help="bit-flip probability q")
     ap.add_argument("--cpu-sample", type=int, default=-1,
-                    help="syndromes timed on the CPU oracle (0 = skip; default 16384, 1 for the large code)")
-    ap.add_argument("--variant", type=int, default=0, help="BP workgroup shape (0 auto, 1, 2, 4)")
+                    help="syndromes timed on one CPU thread (0 = skip both CPU legs; default 8192, 1 for the large code)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="worker processes of the all-cores CPU leg (0 = skip it; default: usable cores, at most 64)")
+    ap.add_argument("--host-steps", type=int, default=3, help="steps of the host-to-host leg (0 = skip)")
+    ap.add_argument("--variant", type=int, default=0, help="BP kernel / workgroup shape (0 auto; see bposd_set_bp_variant)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gather")
-    ap.add_argument("--no-pipeline", action="store_true", help="one decoder handle, one step at a time (no overlap of consecutive steps)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (no overlap of consecutive steps)")
     ap.add_argument("--max-iter", type=int, default=-1, help="override max_iter (diagnostics; -1 = the config's)")
     args = ap.parse_args()
 
@@ -97,7 +124,7 @@ def main():
             raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    bp_method, ms, max_iter, osd_method, osd_order, B = CONFIGS[args.config]
+    bp_method, ms, max_iter, osd_method, osd_order, B, ps_clip = CONFIGS[args.config]
     if args.batch:
         B = args.batch
     if args.max_iter >= 0:
@@ -107,22 +134,24 @@ def main():
     from bp_osd_amd.codes import h1922, l29k
 
     large = args.config.startswith("l29k")
-    if args.cpu_sample < 0:
-        args.cpu_sample = CPU_SAMPLE.get(args.config, 16384)
-    code = l29k() if large else h1922(compute_logicals=(rank == 0))
+    cpu_one, cpu_per_proc = CPU_SAMPLE.get(args.config, CPU_SAMPLE_DEFAULT)
+    if args.cpu_sample >= 0:
+        cpu_one = args.cpu_sample
+    # logical operators: the reference's generic route for H1922, the closed-form product basis for the large code
+    code = l29k(compute_logicals="closed_form" if rank == 0 else False) if large else h1922(compute_logicals=(rank == 0))
     H = code.hz
     m, n = H.shape
     E = H.nnz
     kw = dict(error_rate=q, max_iter=max_iter, bp_method=bp_method, ms_scaling_factor=ms,
-              osd_method=osd_method, osd_order=osd_order)
+              osd_method=osd_method, osd_order=osd_order, ps_clip=ps_clip)
 
     nbatch = max(1, min(args.steps, 2))
     batches = [make_batch(H, q, B, seed=1000 * rank + k) for k in range(nbatch)]
 
-    # ---- CPU baseline leg (rank 0, N = 1 only), before the GPU is initialised in this process.
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        ns = min(args.cpu_sample, B)
+    # ---- CPU baseline legs (rank 0, N = 1 only), before the GPU is initialised in this process.
+    cpu = cpu_all = None
+    if rank == 0 and world == 1 and cpu_one > 0:
+        ns = min(cpu_one, B)
         sample = np.ascontiguousarray(batches[0][1][:ns])
         import threading
 
@@ -136,8 +165,22 @@ def main():
         hb = threading.Thread(target=heartbeat, daemon=True)
         hb.start()
         dt, c_osdw, c_conv, c_it = cpu_baseline_worker((H.indptr, H.indices, H.shape, kw, sample))
-        stop.set()
         cpu = dict(n=ns, dt=dt, osdw=c_osdw, conv=c_conv, iters=c_it)
+        # all host cores: one process per core over disjoint shards of the same batch (the reference's execution model
+        # is one decode at a time per process, css_decode_sim.py:519-520)
+        procs = args.cpu_procs if args.cpu_procs >= 0 else min(usable_cores(), 64)
+        per = min(cpu_per_proc, max(0, (B - ns)) // max(procs, 1))
+        if procs > 1 and per > 0:
+            import multiprocessing as mp
+
+            shards = [np.ascontiguousarray(batches[0][1][ns + i * per: ns + (i + 1) * per]) for i in range(procs)]
+            with mp.get_context("fork").Pool(procs) as pool:
+                t0 = time.perf_counter()
+                res = pool.map(cpu_baseline_worker, [(H.indptr, H.indices, H.shape, kw, s) for s in shards])
+                wall = time.perf_counter() - t0
+            cpu_all = dict(procs=procs, per=per, wall=wall, lo=ns, osdw=np.concatenate([r[1] for r in res]),
+                           iters=np.concatenate([r[3] for r in res]), busy=max(r[0] for r in res))
+        stop.set()
 
     import torch
     import torch.distributed as dist
@@ -148,83 +191,55 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.sharding import StepPipeline
 
-    # Two decoder handles (each owns a HIP stream) used alternately: step k + 1 is enqueued while step k is still
-    # draining -- its last max_iter = n stragglers and its OSD kernel -- so freed CUs are picked up by the next batch's
-    # workgroups.  Every step is complete before the closing barrier; --no-pipeline gives one handle, one step at a time.
-    ndec = 1 if args.no_pipeline else 2
-    decs = [BpOsdDecoder(H, device=local_rank, **kw) for _ in range(ndec)]
-    for d in decs:
-        if args.variant:
-            d.set_bp_variant(args.variant)
-    dec = decs[0]
+    # One decoder handle.  Its two lanes (HIP streams with their own workspaces) alternate between consecutive calls:
+    # step k + 1 is enqueued while step k is still draining its last max_iter = n stragglers and its OSD kernel, so
+    # freed CUs are picked up by the next batch's workgroups.  Every step is complete before the closing barrier.
+    dec = BpOsdDecoder(H, device=local_rank, **kw)
+    if args.variant:
+        dec.set_bp_variant(args.variant)
+    nslots = 1 if args.no_pipeline else dec.num_lanes
 
     dev = torch.device("cuda", local_rank)
     d_syn = [torch.from_numpy(b[1]).to(dev) for b in batches]
-    d_osdw_l = [torch.empty((B, n), dtype=torch.uint8, device=dev) for _ in range(ndec)]
-    d_conv_l = [torch.empty(B, dtype=torch.uint8, device=dev) for _ in range(ndec)]
-    d_iters_l = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(ndec)]
-    d_osdw, d_conv, d_iters = d_osdw_l[0], d_conv_l[0], d_iters_l[0]
-    # the one exchange step: corrections are bit-packed on the device (8x fewer xGMI bytes), then gathered to rank 0.
-    # The gather runs on torch's stream while later steps decode, so the packed rows are double-buffered and a buffer
-    # is reused only after its gather has completed.
+    mk = lambda *shape, dtype=torch.uint8: torch.empty(shape, dtype=dtype, device=dev)
+    outs = [dict(osdw=mk(B, n), osd0=mk(B, n), bp=mk(B, n), conv=mk(B), iters=mk(B, dtype=torch.int32)) for _ in range(nslots)]
+    # the one exchange step: corrections are bit-packed on the device (8x fewer xGMI bytes), then gathered to rank 0
     wpr = (n + 63) // 64
     do_gather = world > 1 and not args.no_gather
-    d_packed = [torch.empty((B, wpr), dtype=torch.int64, device=dev) for _ in range(2)]
-    gather_done = [None, None]
-    gather_list = None
-    if do_gather and rank == 0:
-        gather_list = [[torch.empty((B, wpr), dtype=torch.int64, device=dev) for _ in range(world)] for _ in range(2)]
+    d_packed = [torch.empty((B, wpr), dtype=torch.int64, device=dev) for _ in range(2)] if do_gather else None
     stats = {"bp_ms": [], "osd_ms": [], "iters": 0, "osd": 0}
-    pending = []  # steps enqueued but not yet finalised (at most ndec)
+    lane_of_slot = {}
 
-    def finalise(k, timed):
-        """Wait for step k on its handle, record its kernel times, start its gather."""
-        hnd = decs[k % ndec]
-        hnd.synchronize()
+    def launch(k, slot):
+        o = outs[slot]
+        dec.decode_batch_device(d_syn[k % nbatch].data_ptr(), B, o["osdw"].data_ptr(), o["osd0"].data_ptr(), o["bp"].data_ptr(),
+                                o["conv"].data_ptr(), o["iters"].data_ptr(), None)
+        lane_of_slot[slot] = dec.last_lane
+
+    def pack(slot, buf):  # queued on the lane of the decode just launched
+        dec.pack_rows_device(outs[slot]["osdw"].data_ptr(), B, n, d_packed[buf].data_ptr())
+
+    def wait(slot):
+        dec.synchronize(lane_of_slot[slot])
+
+    def on_finalised(k, timed):
         if timed:
-            t = hnd.last_timing()  # HIP events on the library's stream
+            t = dec.lane_timing(lane_of_slot[k % nslots])  # HIP events on the lane's own stream
             stats["bp_ms"].append(t["bp_ms"])
             stats["osd_ms"].append(t["osd_ms"])
             stats["iters"] += t["bp_iterations"]
             stats["osd"] += t["osd_invocations"]
-        if do_gather:
-            buf = k & 1
-            dist.gather(d_packed[buf], gather_list[buf] if rank == 0 else None, dst=0)
-            ev = torch.cuda.Event()
-            ev.record()
-            gather_done[buf] = ev
 
-    def step(k, timed):
-        i = k % ndec
-        while len(pending) >= ndec:  # the handle (and its output buffers) of step k - ndec must be free
-            finalise(*pending.pop(0))
-        decs[i].decode_batch_device(d_syn[k % nbatch].data_ptr(), B, d_osdw_l[i].data_ptr(), None, None,
-                                    d_conv_l[i].data_ptr(), d_iters_l[i].data_ptr(), None)
-        if do_gather:
-            buf = k & 1
-            if gather_done[buf] is not None:
-                gather_done[buf].synchronize()
-            decs[i].pack_rows_device(d_osdw_l[i].data_ptr(), B, n, d_packed[buf].data_ptr())
-        pending.append((k, timed))
-
-    def drain():
-        while pending:
-            finalise(*pending.pop(0))
-
-    def fence():
-        drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    pipe = StepPipeline(nslots, launch, wait, pack=pack, packed=d_packed, rows=B, gather=do_gather, on_finalised=on_finalised)
     for k in range(args.warmup):
-        step(k, False)
-    fence()
+        pipe.step(k, False)
+    pipe.fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(args.warmup + k, True)
-    fence()
+        pipe.step(args.warmup + k, True)
+    pipe.fence()
     elapsed = time.perf_counter() - t0
     bp_ms, osd_ms, iters_tot, osd_tot = stats["bp_ms"], stats["osd_ms"], stats["iters"], stats["osd"]
 
@@ -233,14 +248,34 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- one more decode of batch 0 for verification / LER (outside the timed region), with the OSD-0 and BP-only
-    # outputs as well (css_decode_sim.py:294-295,338-339 report those error rates next to OSD-W's)
-    d_osd0 = torch.empty((B, n), dtype=torch.uint8, device=dev)
-    d_bp = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    # ---- one more decode of batch 0 for verification / LER (outside the timed region, nothing else on the GPU: these are
+    # the "isolated" kernel durations)
+    o = outs[0]
+    d_osdw, d_osd0, d_bp, d_conv, d_iters = o["osdw"], o["osd0"], o["bp"], o["conv"], o["iters"]
     dec.decode_batch_device(d_syn[0].data_ptr(), B, d_osdw.data_ptr(), d_osd0.data_ptr(), d_bp.data_ptr(), d_conv.data_ptr(),
                             d_iters.data_ptr(), None)
     dec.synchronize()
     t_last = dec.last_timing()
+
+    # ---- host-to-host leg (rank 0, N = 1): the same batches through the host-pointer API from page-locked buffers
+    host = None
+    if rank == 0 and world == 1 and args.host_steps > 0:
+        h_syn = [dec.pinned_empty((B, m)) for _ in range(nbatch)]
+        for dst, b in zip(h_syn, batches):
+            dst[:] = b[1]
+        h_out = dict(osdw=dec.pinned_empty((B, n)), osd0=dec.pinned_empty((B, n)), bp=dec.pinned_empty((B, n)),
+                     conv=dec.pinned_empty((B,)), iters=dec.pinned_empty((B,), np.int32))
+        host = {}
+        for label, extra in (("osdw", {}), ("all", dict(osd0=h_out["osd0"], bp=h_out["bp"]))):
+            dec.decode_batch_into(h_syn[0], h_out["osdw"], converged=h_out["conv"], iters=h_out["iters"], **extra)  # warm-up
+            th = time.perf_counter()
+            for k in range(args.host_steps):
+                dec.decode_batch_into(h_syn[k % nbatch], h_out["osdw"], converged=h_out["conv"], iters=h_out["iters"], **extra)
+            host[label] = (time.perf_counter() - th) / args.host_steps
+        # last call decoded batch (host_steps - 1) % nbatch with all outputs: must equal the device-resident result
+        if (args.host_steps - 1) % nbatch == 0:
+            host["same"] = bool((torch.from_numpy(h_out["osdw"]).to(dev) == d_osdw).all().item() and
+                                (torch.from_numpy(h_out["osd0"]).to(dev) == d_osd0).all().item())
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -250,15 +285,17 @@ def main():
         avg_bp_ms = float(np.mean(bp_ms)) if bp_ms else float("nan")
         avg_iters = iters_tot / steps
         algo_bytes = avg_iters * bytes_per_iter + B * (m + n)
-        steps_iters_scale = (algo_bytes / (t_last["bp_iterations"] * bytes_per_iter + B * (m + n))) if t_last["bp_iterations"] else 1.0
+        algo_bytes_last = t_last["bp_iterations"] * bytes_per_iter + B * (m + n)
         achieved = algo_bytes / (avg_bp_ms * 1e-3) / 1e9 if avg_bp_ms > 0 else 0.0
-        traffic = osd_traffic = None
+        traffic = osd_traffic = traffic_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(args.config, {})
                 traffic = rec.get("hbm_bytes_per_launch")
                 osd_traffic = rec.get("osd_hbm_bytes_per_launch")
+                traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (" +
+                               str(rec.get("command", "?")) + "); PMC counters cannot be read from inside the run")
             except Exception:
                 traffic = osd_traffic = None
 
@@ -277,8 +314,12 @@ def main():
                 fails_bp += int((logical(d_bp) | (d_conv[sl] == 0)).sum().item())
             ler, ler0, ler_bp = fails / B, fails0 / B, fails_bp / B
         # every correction must reproduce its syndrome (checked on the device for the whole batch)
-        Hd = torch.sparse_csr_tensor(torch.from_numpy(H.indptr.astype(np.int64)), torch.from_numpy(H.indices.astype(np.int64)),
-                                     torch.ones(H.nnz, dtype=torch.float32), size=H.shape).to(dev)
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Hd = torch.sparse_csr_tensor(torch.from_numpy(H.indptr.astype(np.int64)), torch.from_numpy(H.indices.astype(np.int64)),
+                                         torch.ones(H.nnz, dtype=torch.float32), size=H.shape).to(dev)
         synd_ok = True
         for lo in range(0, B, 8192):
             got = torch.sparse.mm(Hd, d_osdw[lo:lo + 8192].to(torch.float32).T) % 2
@@ -286,6 +327,9 @@ def main():
         conv_frac = float(d_conv.to(torch.float32).mean().item())
         it_cpu = d_iters.cpu().numpy()
 
+        # which BP kernel ran, and what it moves through LDS per syndrome-iteration
+        local_edge = (not large) and bp_method == "ms" and args.variant in (0, 16, 17, 18)
+        num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         out = {
             "metric": "syndromes decoded/sec (whole node) + logical error rate, HGP [[1922,50]] p=0.05" if not large else
                       "syndromes decoded/sec (whole node), large HGP 14520x29524 (BASELINE configs[4])",
@@ -304,14 +348,16 @@ def main():
                 "workload": f"{args.config}: " + ("[[29524,484]] HGP of a seeded (5,6)-regular 110x132 matrix, hz 14520x29524, "
                                                   if large else "[[1922,50]] HGP (31x31 circulant 1+x^2+x^5) hz 961x1922, ") +
                             f"{'min-sum' if bp_method == 'ms' else 'product-sum'} BP"
-                            f"{' variable scaling' if bp_method == 'ms' and ms == 0 else (f' scaling {ms}' if bp_method == 'ms' else '')}, max_iter={max_iter or n}, "
-                            f"{osd_method} order {osd_order}, iid bit-flip q={q}",
+                            f"{' variable scaling' if bp_method == 'ms' and ms == 0 else (f' scaling {ms}' if bp_method == 'ms' else '')}"
+                            f"{f' (ps_clip {ps_clip})' if bp_method == 'ps' and ps_clip else (' (no clipping, as the reference)' if bp_method == 'ps' else '')}, "
+                            f"max_iter={max_iter or n}, {osd_method} order {osd_order}, iid bit-flip q={q}",
                 "per_gpu_batch": B,
                 "global_batch": B * world,
                 "sharding": f"independent syndromes, contiguous shards x{world}" +
                             ("" if world == 1 or args.no_gather else ", RCCL gather of bit-packed corrections to rank 0"),
                 "bp_variant": args.variant,
-                "pipelined_steps": ndec,
+                "pipelined_steps": nslots,
+                "timed_outputs": ["osdw", "osd0", "bp", "converged", "iters"],
             },
             "logical_error_rate": ler,
             "logical_error_rate_eb": None if ler is None else float(np.sqrt(ler * (1 - ler) / B)),
@@ -332,27 +378,57 @@ def main():
             "kernel_only_syndromes_per_s_per_gpu": B / ((t_last["bp_ms"] + t_last["osd_ms"]) * 1e-3),
             "roofline": {
                 "kernel": "bp_large_kernel (BP message passing, messages in HBM)" if large else
-                          "bp_local_kernel / bp_kernel (BP message passing, LDS- and register-resident messages)",
-                "bound": "hbm",
+                          ("bp_local_kernel" if local_edge else "bp_kernel") + " (BP message passing, LDS- and register-resident messages)",
+                "bound": "hbm" if large else "on-chip (HBM algorithmic for reference)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "bytes_per_iteration_per_syndrome": bytes_per_iter,
                 "avg_launch_ms": avg_bp_ms,
                 "isolated_launch_ms": t_last["bp_ms"],
-                "frac_isolated": (algo_bytes / steps_iters_scale / (t_last["bp_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_last["bp_ms"] > 0 else None,
+                "frac_isolated": (algo_bytes_last / (t_last["bp_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_last["bp_ms"] > 0 else None,
                 "note": (("algorithmic fp64 message bytes (4E+2n)*8 per executed iteration; messages stream through HBM "
                           "(1.4 MB per syndrome, far beyond LDS)") if large else
-                         ("algorithmic fp64 message bytes (4E+2n)*8 per executed iteration; messages stay in "
-                          "LDS / registers, so the fraction can exceed 1 and measured HBM traffic is far lower")) +
+                         ("SURVEY.md 8(d)'s algorithmic fp64 message bytes (4E+2n)*8 per executed iteration over the HBM peak; "
+                          "the messages never leave LDS / registers, so this fraction exceeds 1 and is NOT a utilisation -- "
+                          "roofline_lds is the kernel's real bound")) +
                         ("; avg_launch_ms is measured inside the timed region, where consecutive steps overlap on two streams "
                          "(rocprofv3 shows the same stretched durations); isolated_launch_ms / frac_isolated are the same kernel "
-                         "alone on the GPU" if ndec > 1 else ""),
+                         "alone on the GPU" if nslots > 1 else ""),
             },
         }
+        if not large and bp_method == "ms":
+            # LDS roofline of the BP kernel: messages that cross LDS per syndrome-iteration, each once in and once out.
+            # local-edge kernel: 4 of a check's 6 edges + 2 of a bit's 3 edges = 8m doubles each way (n = 2m);
+            # LDS kernel: 6m + 3n = 12m doubles each way.  Peaks per instruction from MI355X_MICROARCH.md.
+            doubles = (4 * m + 2 * n) if local_edge else (E + E)
+            rd = wr = doubles * 8
+            cyc = rd / LDS_READ_B64_BYTES_PER_CLK + wr / LDS_WRITE_B64_BYTES_PER_CLK
+            bound_ms = lambda iters: iters * cyc / (num_cu * CLOCK_HZ) * 1e3
+            # fp64 VALU issue: per check 14 v_min_f64 + 6 v_mul_f64 + 6 v_cmp (sign test), per bit 6 v_add_f64 + 1 v_cmp;
+            # a wave64 fp64 instruction issues over 4 cycles on one of the CU's 4 SIMDs
+            fp64_cyc = (26 * m + 7 * n) / 64 * 4 / 4
+            out["roofline_lds"] = {
+                "kernel": out["roofline"]["kernel"],
+                "bound": "lds",
+                "lds_bytes_per_syndrome_iteration": {"read": rd, "write": wr},
+                "lds_cycles_per_syndrome_iteration_per_cu": cyc,
+                "peak": {"ds_read_b64_B_per_clk_per_cu": LDS_READ_B64_BYTES_PER_CLK,
+                         "ds_write_b64_B_per_clk_per_cu": LDS_WRITE_B64_BYTES_PER_CLK, "cus": num_cu, "clock_hz": CLOCK_HZ},
+                "bound_ms_per_launch": bound_ms(avg_iters),
+                "frac": bound_ms(avg_iters) / avg_bp_ms if avg_bp_ms > 0 else None,
+                "frac_isolated": bound_ms(t_last["bp_iterations"]) / t_last["bp_ms"] if t_last["bp_ms"] > 0 else None,
+                "fp64_valu_issue_frac_isolated": (t_last["bp_iterations"] * fp64_cyc / (num_cu * CLOCK_HZ) * 1e3 / t_last["bp_ms"])
+                if t_last["bp_ms"] > 0 else None,
+                "ns_per_syndrome_iteration_isolated": t_last["bp_ms"] * 1e6 / max(t_last["bp_iterations"], 1),
+                "note": "LDS-pipe cycles the selected kernel needs per syndrome-iteration (conflict-free) x executed iterations / "
+                        "(CUs x peak clock) over the measured launch time; fp64_valu_issue_frac is the same ratio for the fp64 "
+                        "instruction issue slots",
+            }
         if large:
             # the OSD kernel dominates this configuration; SURVEY.md §8(d) prices it at one read+write pass over the
             # packed matrix plus the sort plus the candidate sweep per invoked syndrome
@@ -365,8 +441,21 @@ def main():
                 "kernel": "osd_large_kernel (sort + blocked GF(2) elimination + OSD-E sweep, matrix in HBM)",
                 "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                 "traffic": osd_traffic, "algorithmic_bytes_per_launch": osd_bytes, "avg_launch_ms": avg_osd_ms,
+                "isolated_launch_ms": t_last["osd_ms"],
                 "note": "the single-pass figure of SURVEY.md §8(d); a blocked elimination revisits the trailing matrix once "
                         "per group of pivot panels and its inner loop is bound by LDS table look-ups (DESIGN.md §4.5)",
+            }
+        if host is not None:
+            out["value_host_to_host"] = B / host["osdw"]
+            out["host_to_host"] = {
+                "unit": "syndromes/s",
+                "osdw_converged_iters": B / host["osdw"],
+                "all_outputs": B / host["all"],
+                "ms_per_step": {"osdw_converged_iters": 1e3 * host["osdw"], "all_outputs": 1e3 * host["all"]},
+                "steps": args.host_steps,
+                "matches_device_resident_run": host.get("same"),
+                "note": "bposd_decode_batch (numpy in / numpy out) from page-locked host buffers to page-locked host buffers, "
+                        "PCIe-inclusive, chunks overlapped on the handle's two lanes; never `value`",
             }
         if cpu is not None:
             got = d_osdw[:cpu["n"]].cpu().numpy()
@@ -379,8 +468,23 @@ def main():
                 "sample": f"first {cpu['n']} syndromes of batch 0, decoded one at a time by oracle/bposd_oracle.c "
                           f"(single thread, {cpu['dt']:.1f} s); the reference's ldpc/Cython path is not installable here",
                 "host_cores_available": len(os.sched_getaffinity(0)),
+                "host_cores_usable": usable_cores(),
                 "gpu_matches_cpu_bit_for_bit": same,
             }
+            if cpu_all is not None:
+                lo, cnt = cpu_all["lo"], cpu_all["procs"] * cpu_all["per"]
+                got = d_osdw[lo:lo + cnt].cpu().numpy()
+                same_all = bool((got == cpu_all["osdw"]).all() and (it_cpu[lo:lo + cnt] == cpu_all["iters"]).all())
+                out["cpu_baseline_all_cores"] = {
+                    "value": cnt / cpu_all["wall"],
+                    "unit": "syndromes/s",
+                    "cores": cpu_all["procs"],
+                    "kind": "port",
+                    "sample": f"syndromes {lo}..{lo + cnt} of batch 0 in {cpu_all['procs']} disjoint shards of {cpu_all['per']}, one "
+                              f"forked oracle process per usable host core (wall {cpu_all['wall']:.1f} s, slowest worker "
+                              f"{cpu_all['busy']:.1f} s busy)",
+                    "gpu_matches_cpu_bit_for_bit": same_all,
+                }
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -30,6 +30,12 @@ EXPORTED_SYMBOLS = (
     "bposd_decode_batch_select_device",
     "bposd_pack_rows_device",
     "bposd_synchronize",
+    "bposd_num_lanes",
+    "bposd_last_lane",
+    "bposd_synchronize_lane",
+    "bposd_lane_timing",
+    "bposd_host_alloc",
+    "bposd_host_free",
     "bposd_last_timing",
     "bposd_info",
     "bposd_layout_info",
@@ -49,7 +55,9 @@ class BposdConfig(C.Structure):
         ("osd_order", C.c_int32),
         ("sort_tie_policy", C.c_int32),
         ("weight_fn", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("reserved0", C.c_int32),
+        ("ps_clip", C.c_double),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -86,6 +94,19 @@ def load():
     lib.bposd_pack_rows_device.restype = C.c_int
     lib.bposd_synchronize.argtypes = [vp]
     lib.bposd_synchronize.restype = C.c_int
+    lib.bposd_num_lanes.argtypes = []
+    lib.bposd_num_lanes.restype = C.c_int
+    lib.bposd_last_lane.argtypes = [vp]
+    lib.bposd_last_lane.restype = C.c_int
+    lib.bposd_synchronize_lane.argtypes = [vp, C.c_int32]
+    lib.bposd_synchronize_lane.restype = C.c_int
+    lib.bposd_lane_timing.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.bposd_lane_timing.restype = C.c_int
+    lib.bposd_host_alloc.argtypes = [C.c_size_t]
+    lib.bposd_host_alloc.restype = vp
+    lib.bposd_host_free.argtypes = [vp]
+    lib.bposd_host_free.restype = None
     lib.bposd_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.bposd_last_timing.restype = C.c_int

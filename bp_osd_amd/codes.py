@@ -211,7 +211,10 @@ class HgpCode:
     that the decode path reads: hx, hz, lx, lz, N, K
     (/root/reference/src/bposd/hgp.py:26-57, css.py:75-95)."""
 
-    def __init__(self, h1, h2=None, compute_logicals: bool = True):
+    def __init__(self, h1, h2=None, compute_logicals=True):
+        """compute_logicals: True = the reference's generic route (nullspace + pivot rows, css.py:75-95; dense GF(2)
+        work on the N-column matrices), "closed_form" = the product structure's own basis (closed_form_logicals below;
+        only the seed matrices are row-reduced, so it also serves the 29524-qubit code), False = none."""
         h1 = _dense(h1)
         h2 = h1.copy() if h2 is None else _dense(h2)
         self.h1, self.h2 = h1, h2
@@ -233,10 +236,49 @@ class HgpCode:
         self.hx.sort_indices()
         self.hz.sort_indices()
         self.lx = self.lz = None
-        if compute_logicals:
+        if isinstance(compute_logicals, str):
+            if compute_logicals != "closed_form":
+                raise ValueError("compute_logicals must be True, False or 'closed_form'")
+            self.lx, self.lz = self.closed_form_logicals()
+        elif compute_logicals:
             self.lx = self._logicals(self.hz, self.hx)
             self.lz = self._logicals(self.hx, self.hz)
             assert self.lx.shape[0] == self.K and self.lz.shape[0] == self.K
+
+    def closed_form_logicals(self):
+        """(lx, lz) from the seed codes alone (Tillich-Zemor).  With hx = [h1 (x) I | I (x) h2^T] and
+        hz = [I (x) h2 | h1^T (x) I] (hgp.py:48-54), a Z-type operator (x (x) y | 0) commutes with every X check iff
+        h1 x = 0, and (x (x) h2^T u | 0) is a product of Z checks, so y only matters modulo rowspace(h2): take x over a
+        basis of ker(h1) and y = e_j over the free (non-pivot) columns of h2.  Likewise (0 | a (x) b) with h2^T b = 0 and
+        a = e_i over the free columns of h1^T.  That is k1 k2 + k1t k2t = K operators; lx follows by exchanging the roles
+        of the two seeds.  The logical error test (lz . residual != 0 for some row, css_decode_sim.py:257-272) does not
+        depend on which basis of the logical space is used."""
+        h1, h2 = self.h1, self.h2
+        m1, n1 = h1.shape
+        m2, n2 = h2.shape
+
+        def free_cols(a):
+            piv = set(gf2_row_echelon(a)[3])
+            return [j for j in range(a.shape[1]) if j not in piv]
+
+        def unit(k, i):
+            e = np.zeros(k, dtype=np.uint8)
+            e[i] = 1
+            return e
+
+        def block(first, second):  # rows (u (x) v | 0) for (u, v) in first, (0 | a (x) b) for (a, b) in second
+            rows = [np.concatenate([np.kron(u, v), np.zeros(m1 * m2, dtype=np.uint8)]) for u, v in first]
+            rows += [np.concatenate([np.zeros(n1 * n2, dtype=np.uint8), np.kron(a, b)]) for a, b in second]
+            return np.array(rows, dtype=np.uint8).reshape(len(rows), self.N)
+
+        ker1, ker2 = gf2_nullspace(h1), gf2_nullspace(h2)        # ker(h1) in F^n1, ker(h2) in F^n2
+        ker1t, ker2t = gf2_nullspace(h1.T), gf2_nullspace(h2.T)  # ker(h1^T) in F^m1, ker(h2^T) in F^m2
+        lz = block([(x, unit(n2, j)) for x in ker1 for j in free_cols(h2)],
+                   [(unit(m1, i), b) for i in free_cols(h1.T) for b in ker2t])
+        lx = block([(unit(n1, i), y) for i in free_cols(h1) for y in ker2],
+                   [(a, unit(m2, j)) for a in ker1t for j in free_cols(h2.T)])
+        assert lx.shape[0] == self.K and lz.shape[0] == self.K
+        return lx, lz
 
     @staticmethod
     def _logicals(h_commute, h_stab) -> np.ndarray:
@@ -284,7 +326,7 @@ class CssCode:
     test = HgpCode.test
 
 
-def hgp(h1, h2=None, compute_logicals: bool = True) -> HgpCode:
+def hgp(h1, h2=None, compute_logicals=True) -> HgpCode:
     return HgpCode(h1, h2, compute_logicals)
 
 
@@ -293,14 +335,15 @@ def surface13() -> HgpCode:
     return hgp(rep_code(3))
 
 
-def h1922(compute_logicals: bool = True) -> HgpCode:
+def h1922(compute_logicals=True) -> HgpCode:
     """[[1922,50]] HGP of the 31x31 circulant 1 + x^2 + x^5 (SURVEY.md §7 'config
     ambiguities', §8d): hx, hz are 961 x 1922, row weight 6, column weight 3."""
     return hgp(circulant(31, (0, 2, 5)), compute_logicals=compute_logicals)
 
 
-def l29k(seed: int = 0) -> HgpCode:
+def l29k(seed: int = 0, compute_logicals=False) -> HgpCode:
     """The large configuration of SURVEY.md §8d: HGP of a seeded (5,6)-regular 110 x 132 matrix --
-    hx, hz are 14520 x 29524, check weight 11, bit weight 5 or 6, 159 720 non-zeros.  No logicals (the
-    throughput benchmark needs none and the dense GF(2) routines above are too slow at this size)."""
-    return hgp(regular_ldpc_seed(110, 132, 5, 6, seed=seed), compute_logicals=False)
+    hx, hz are 14520 x 29524, check weight 11, bit weight 5 or 6, 159 720 non-zeros.  The reference's generic logicals
+    (dense nullspace of a 14520 x 29524 matrix) are out of reach of the setup-time GF(2) helpers above; pass
+    compute_logicals="closed_form" for the product-structure basis (484 x 29524), which is all the LER needs."""
+    return hgp(regular_ldpc_seed(110, 132, 5, 6, seed=seed), compute_logicals=compute_logicals)

@@ -49,6 +49,7 @@ struct BpParams {
     long long B;
     int max_iter;
     double ms_scaling;  // 0 => 1 - 2^-it
+    double ps_clip;     // product-sum: 0 = no clipping (upstream), C > 0 = check->bit messages clamped to [-C, C]
     int osd_enabled;    // 0: osd off, results = bp decoding even when not converged
     int mp;             // padded check count = blockDim.x * CPT (stride of the LDS layout)
     const uint8_t* __restrict__ synd;   // [B, m]
@@ -271,7 +272,12 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                             for (int k = DC - 1; k >= 0; --k) {
                                 if (REG || k < deg) {
                                     const double x = pre[k] * t;
-                                    mc[k * MP] = sg * log((1 + x) / (1 - x));
+                                    double o = sg * log((1 + x) / (1 - x));
+                                    if (P.ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
+                                        if (o > P.ps_clip) o = P.ps_clip;
+                                        if (o < -P.ps_clip) o = -P.ps_clip;
+                                    }
+                                    mc[k * MP] = o;
                                     t *= th[k];
                                 }
                             }

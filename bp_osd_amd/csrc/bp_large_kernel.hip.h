@@ -30,6 +30,7 @@ struct BpLargeParams {
     long long B;
     int max_iter;
     double ms_scaling;
+    double ps_clip;  // product-sum: 0 = none, C > 0 = check->bit messages clamped to [-C, C]
     int osd_enabled;
     int mp;                              // check stride of the message layout (m rounded up to 64)
     const uint8_t* __restrict__ synd;    // [B, m]
@@ -171,7 +172,12 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                         for (int k = DC - 1; k >= 0; --k) {
                             if (k < deg) {
                                 const double x = pre[k] * t;
-                                mc[(size_t)k * MP] = sg * log((1 + x) / (1 - x));
+                                double o = sg * log((1 + x) / (1 - x));
+                                if (P.ps_clip > 0.0) {
+                                    if (o > P.ps_clip) o = P.ps_clip;
+                                    if (o < -P.ps_clip) o = -P.ps_clip;
+                                }
+                                mc[(size_t)k * MP] = o;
                                 t *= th[k];
                             }
                         }

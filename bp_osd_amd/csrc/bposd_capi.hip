@@ -40,11 +40,44 @@ struct DevBuf {
 
 }  // namespace
 
+// Per-call state.  A handle owns BPOSD_LANES of these and alternates between them: consecutive decode calls (and the
+// chunks of one host-pointer call) run on different HIP streams with their own workspaces, so the persistent
+// workgroups of call k + 1 pick up the CUs that call k's last max_iter stragglers and its OSD kernel leave idle.
+constexpr int BPOSD_LANES = 2;
+constexpr int BPOSD_MAX_CHUNKS = 8;  // chunks of one host-pointer call (bposd_decode_batch)
+
+struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf bpl_msg, bpl_llr;  // large BP workspaces (bpl_llr also serves the local-edge kernel: LLRs of the current syndrome)
+    DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
+    DevBuf osd_rows_ws;       // OSD kernel's per-workgroup spill area for finished row words
+    DevBuf llr_ws, osd_list, io_synd, io_osdw, io_osd0, io_bp, io_conv, io_iters, io_llr, io_sel;
+    long long* d_osd_dbg = nullptr;  // diagnostics (BPOSD_OSD_DEBUG=1): phase timestamps
+    int* d_counters = nullptr;       // 4 ints
+    unsigned long long* d_iter_total = nullptr;
+};
+
+// What bposd_last_timing reports: one record per kernel pair launched by the last call (one per chunk for a
+// host-pointer call).  Events and the pinned counter copies live in the handle so that records outlive lane reuse.
+struct CallRecord {
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int* h_counters = nullptr;               // pinned: 4 ints
+    unsigned long long* h_iter_total = nullptr;  // pinned
+    bool ran_osd = false;
+    bool recorded = false;  // the events have been recorded at least once
+};
+
 struct bposd_handle {
     bposd_config cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    Lane lanes[BPOSD_LANES];
+    Lane* cur = nullptr;      // lane of the call being enqueued
+    int next_lane = 0;
+    CallRecord lane_rec[BPOSD_LANES];  // device-pointer calls: the record of the last call queued on each lane
+    CallRecord rec[BPOSD_MAX_CHUNKS];  // host-pointer calls: one record per chunk
+    CallRecord* currec = nullptr;
+    int nrec = 0;             // > 0: the last call was a host-pointer call of that many chunks
+    int last_lane = 0;        // lane of the last device-pointer call
     int num_cu = 0;
     size_t lds_per_cu = 160 * 1024;
     int m = 0, n = 0, E = 0;
@@ -57,8 +90,6 @@ struct bposd_handle {
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
     bool large = false;   // beyond the register-resident OSD kernel: HBM-resident matrix, device rank probe
     bool bp_hbm = false;  // BP messages do not fit one CU's LDS either: HBM-resident BP kernel
-    DevBuf bpl_msg, bpl_llr;  // large BP workspaces (bpl_llr also serves the local-edge kernel: LLRs of the current syndrome)
-    DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
     int max_iter = 0;
     int rank = 0, kprime = 0, ncand = 0;
     bool probs_uniform = true;
@@ -74,19 +105,9 @@ struct bposd_handle {
     double* d_llr0 = nullptr;
     double* d_cost = nullptr;  // log(1/p_i): OSD-W weights of the ldpc-v2 weight function
     double *d_llr0_alt = nullptr, *d_cost_alt = nullptr;  // alternative channel of the two-valued per-shot form
-    DevBuf io_sel;
     bool fp_weights = false;   // non-uniform (or degenerate) channel: candidate weights need the fp64 sums
     int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
-    // workspace (grow-only)
-    DevBuf osd_rows_ws;  // OSD kernel's per-workgroup spill area for finished row words
-    DevBuf llr_ws, osd_list, io_synd, io_osdw, io_osd0, io_bp, io_conv, io_iters, io_llr;
-    long long* d_osd_dbg = nullptr;         // diagnostics (BPOSD_OSD_DEBUG=1): phase timestamps
-    int* d_counters = nullptr;              // 4 ints
-    unsigned long long* d_iter_total = nullptr;
-    int* h_counters = nullptr;              // pinned: 4 ints
-    unsigned long long* h_iter_total = nullptr;  // pinned
     bool have_timing = false;
-    bool ran_osd = false;
     std::string err;
 };
 
@@ -110,6 +131,28 @@ int fail(bposd_handle* h, int code, const char* fmt, ...) {
             return fail(h, BPOSD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                         __FILE__, __LINE__);                                                   \
     } while (0)
+
+// Every entry point works on the handle's device and puts the caller's current device back on exit (a process that
+// also drives torch, or handles on other GPUs, must not find its thread's device changed by a decode call).
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+int sync_all_lanes(bposd_handle* h) {
+    for (auto& l : h->lanes)
+        if (l.stream) HIP_TRY(h, hipStreamSynchronize(l.stream));
+    return 0;
+}
 
 int ensure(bposd_handle* h, DevBuf& b, size_t bytes) {
     if (bytes <= b.bytes && b.p) return 0;
@@ -359,11 +402,11 @@ int launch_bp_t(bposd_handle* h, const BpParams& P, int NT) {
     if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
         auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 1, MPT>;
         HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, P);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
     } else {
         auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 0, MPT>;
         HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, P);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
     }
     HIP_TRY(h, hipGetLastError());
     return 0;
@@ -428,7 +471,7 @@ int launch_bp(bposd_handle* h, BpParams& P) {
     const int MP = NT * shape_cpt(shape);
     const int NPOS = NT * 2 * shape_cpt(shape);
     if (MP != h->tab_mp || NPOS != h->tab_np) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        { int rcs = sync_all_lanes(h); if (rcs) return rcs; }  // kernels in flight still read the old tables
         int rc = build_tables(h, h->tab_dc, h->tab_dv, MP, NT, 2 * shape_cpt(shape));
         if (rc) return rc;
         P.chk_deg = h->d_chk_deg;
@@ -798,11 +841,11 @@ int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
     wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
     long long grid = std::min<long long>(L.B, (long long)h->num_cu * wg_per_cu);
     if (grid < 1) grid = 1;
-    int rc = ensure(h, h->bpl_llr, sizeof(double) * (size_t)grid * h->n);
+    int rc = ensure(h, h->cur->bpl_llr, sizeof(double) * (size_t)grid * h->n);
     if (rc) return rc;
     BpLocalParams Lq = L;
-    Lq.llr_tmp = (double*)h->bpl_llr.p;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->stream, Lq);
+    Lq.llr_tmp = (double*)h->cur->bpl_llr.p;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->cur->stream, Lq);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
@@ -855,18 +898,18 @@ int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
     const int wg_per_cu = std::max<int>(1, std::min<size_t>(4, h->lds_per_cu / lds));
     const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
     int rc;
-    if ((rc = ensure(h, h->bpl_msg, sizeof(double) * (size_t)grid * DC * P.mp))) return rc;
-    if ((rc = ensure(h, h->bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
-    P.msg_ws = (double*)h->bpl_msg.p;
-    P.llr_tmp = (double*)h->bpl_llr.p;
+    if ((rc = ensure(h, h->cur->bpl_msg, sizeof(double) * (size_t)grid * DC * P.mp))) return rc;
+    if ((rc = ensure(h, h->cur->bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
+    P.msg_ws = (double*)h->cur->bpl_msg.p;
+    P.llr_tmp = (double*)h->cur->bpl_llr.p;
     if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
         auto k = bp_large_kernel<DC, DV, 1>;
         HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->stream, P);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->cur->stream, P);
     } else {
         auto k = bp_large_kernel<DC, DV, 0>;
         HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->stream, P);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->cur->stream, P);
     }
     HIP_TRY(h, hipGetLastError());
     return 0;
@@ -887,13 +930,13 @@ int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
     const size_t lds = osd_lds_bytes(W, NT * OSD_RPT);
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
-    int rc = ensure(h, h->osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
+    int rc = ensure(h, h->cur->osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
     if (rc) return rc;
     OsdParams Q = P;
-    Q.rows_ws = (unsigned long long*)h->osd_rows_ws.p;
+    Q.rows_ws = (unsigned long long*)h->cur->osd_rows_ws.p;
     auto k = osd_kernel<W>;
     HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->stream, Q);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, Q);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
@@ -953,11 +996,11 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
                              g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.W * 64};    // pro
     size_t total = 0;
     for (size_t b : sizes) total += a256(b);
-    int rc = ensure(h, h->osdl_ws, total);
+    int rc = ensure(h, h->cur->osdl_ws, total);
     if (rc) return rc;
     unsigned char* ptrs[10];
     {
-        unsigned char* base = (unsigned char*)h->osdl_ws.p;
+        unsigned char* base = (unsigned char*)h->cur->osdl_ws.p;
         for (int i = 0; i < 10; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
     }
     Q.mat = (unsigned long long*)ptrs[0];
@@ -976,7 +1019,7 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     case R: {                                                                                               \
         auto k = osd_large_kernel<R>;                                                                       \
         HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(OSDL_NT), lds, h->stream, Q);                      \
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(OSDL_NT), lds, h->cur->stream, Q);                      \
     } break;
     switch (RPT) {
         OSDL_LAUNCH(2)
@@ -998,9 +1041,9 @@ int probe_rank_large(bposd_handle* h, int* rank) {
     int rc = ensure(h, tmp, total);
     if (rc) return rc;
     unsigned char* b = (unsigned char*)tmp.p;
-    HIP_TRY(h, hipMemsetAsync(b, 0, total, h->stream));
+    HIP_TRY(h, hipMemsetAsync(b, 0, total, h->cur->stream));
     const int cnt[8] = {0, 1, 0, 0, /*osd_list*/ 0, /*rank_out*/ -1, 0, 0};
-    HIP_TRY(h, hipMemcpyAsync(b + off_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(b + off_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, h->cur->stream));
     OsdParams P{};
     P.m = h->m; P.n = h->n; P.rank = std::min(h->m, h->n);
     P.osd_method = BPOSD_OSD_0; P.osd_order = 0; P.tie_policy = 0;
@@ -1010,7 +1053,7 @@ int probe_rank_large(bposd_handle* h, int* rank) {
     rc = launch_osd_large(h, P, 1, (int*)(b + off_cnt) + 5);
     if (!rc) {
         int got[8];
-        hipError_t e = hipStreamSynchronize(h->stream);
+        hipError_t e = hipStreamSynchronize(h->cur->stream);
         if (e == hipSuccess) e = hipMemcpy(got, b + off_cnt, sizeof(got), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(h, BPOSD_ERR_HIP, "rank probe failed: %s", hipGetErrorString(e));
         else if (got[5] < 0 || got[5] > std::min(h->m, h->n)) rc = fail(h, BPOSD_ERR_HIP, "rank probe returned %d", got[5]);
@@ -1060,21 +1103,28 @@ const char* bposd_last_error(bposd_handle* h) { return h ? h->err.c_str() : g_cr
 
 void bposd_destroy(bposd_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->bpl_msg, &h->bpl_llr, &h->osdl_ws, &h->io_sel, &h->osd_rows_ws, &h->llr_ws, &h->osd_list, &h->io_synd, &h->io_osdw, &h->io_osd0, &h->io_bp,
-                      &h->io_conv, &h->io_iters, &h->io_llr})
-        release(*b);
+    DeviceGuard dev_guard(h->device);
+    for (auto& l : h->lanes) {
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        for (DevBuf* b : {&l.bpl_msg, &l.bpl_llr, &l.osdl_ws, &l.io_sel, &l.osd_rows_ws, &l.llr_ws, &l.osd_list, &l.io_synd, &l.io_osdw,
+                          &l.io_osd0, &l.io_bp, &l.io_conv, &l.io_iters, &l.io_llr})
+            release(*b);
+        for (void* p : {(void*)l.d_counters, (void*)l.d_iter_total, (void*)l.d_osd_dbg})
+            if (p) (void)hipFree(p);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
-                    (void*)h->d_var_pos, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt, (void*)h->d_counters,
-                    (void*)h->d_iter_total, (void*)h->d_osd_dbg, (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
+                    (void*)h->d_var_pos, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt,
+                    (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
                     (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl})
         if (p) (void)hipFree(p);
-    if (h->h_counters) (void)hipHostFree(h->h_counters);
-    if (h->h_iter_total) (void)hipHostFree(h->h_iter_total);
-    for (auto& e : h->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (CallRecord* rs : {h->rec, h->lane_rec})
+        for (int k = 0; k < (rs == h->rec ? BPOSD_MAX_CHUNKS : BPOSD_LANES); ++k) {
+            if (rs[k].h_counters) (void)hipHostFree(rs[k].h_counters);
+            if (rs[k].h_iter_total) (void)hipHostFree(rs[k].h_iter_total);
+            for (auto& e : rs[k].ev)
+                if (e) (void)hipEventDestroy(e);
+        }
     delete h;
 }
 
@@ -1091,8 +1141,9 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     if (cfg->max_iter < 0 || cfg->osd_order < 0) return fail(nullptr, BPOSD_ERR_INVALID, "negative max_iter / osd_order");
     if (cfg->sort_tie_policy < 0 || cfg->sort_tie_policy > 1 || cfg->weight_fn < 0 || cfg->weight_fn > 1)
         return fail(nullptr, BPOSD_ERR_INVALID, "sort_tie_policy / weight_fn out of range");
-    for (int k = 0; k < 4; ++k)
-        if (cfg->reserved[k] != 0) return fail(nullptr, BPOSD_ERR_INVALID, "reserved config fields must be 0");
+    if (cfg->reserved0 != 0 || cfg->reserved[0] != 0 || cfg->reserved[1] != 0)
+        return fail(nullptr, BPOSD_ERR_INVALID, "reserved config fields must be 0");
+    if (!(cfg->ps_clip >= 0.0) || std::isinf(cfg->ps_clip)) return fail(nullptr, BPOSD_ERR_INVALID, "ps_clip must be 0 (off) or a finite positive bound");
     if (indptr[0] != 0) return fail(nullptr, BPOSD_ERR_INVALID, "csr_indptr[0] must be 0");
     for (int c = 0; c < m; ++c) {
         if (indptr[c + 1] < indptr[c]) return fail(nullptr, BPOSD_ERR_INVALID, "csr_indptr not monotone");
@@ -1141,13 +1192,27 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
         }                                                                                       \
     } while (0)
 
-    CREATE_TRY(hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    CREATE_TRY(dev_guard.err);
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
     h->num_cu = prop.multiProcessorCount;
     if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (auto& e : h->ev) CREATE_TRY(hipEventCreate(&e));
+    for (auto& l : h->lanes) {
+        CREATE_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        CREATE_TRY(hipMalloc((void**)&l.d_counters, sizeof(int) * 4));
+        CREATE_TRY(hipMalloc((void**)&l.d_iter_total, sizeof(unsigned long long)));
+    }
+    for (CallRecord* rs : {h->rec, h->lane_rec})
+        for (int k = 0; k < (rs == h->rec ? BPOSD_MAX_CHUNKS : BPOSD_LANES); ++k) {
+            for (auto& e : rs[k].ev) CREATE_TRY(hipEventCreate(&e));
+            CREATE_TRY(hipHostMalloc((void**)&rs[k].h_counters, sizeof(int) * 4));
+            CREATE_TRY(hipHostMalloc((void**)&rs[k].h_iter_total, sizeof(unsigned long long)));
+            rs[k].h_counters[0] = rs[k].h_counters[1] = 0;
+            *rs[k].h_iter_total = 0;
+        }
+    h->cur = &h->lanes[0];
+    h->currec = &h->rec[0];
 
     // degrees
     std::vector<int> vdeg(n, 0);
@@ -1233,10 +1298,6 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(hipMalloc((void**)&h->d_cost, sizeof(double) * n));
     CREATE_TRY(hipMalloc((void**)&h->d_llr0_alt, sizeof(double) * n));
     CREATE_TRY(hipMalloc((void**)&h->d_cost_alt, sizeof(double) * n));
-    CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(int) * 4));
-    CREATE_TRY(hipMalloc((void**)&h->d_iter_total, sizeof(unsigned long long)));
-    CREATE_TRY(hipHostMalloc((void**)&h->h_counters, sizeof(int) * 4));
-    CREATE_TRY(hipHostMalloc((void**)&h->h_iter_total, sizeof(unsigned long long)));
     if (h->bp_hbm) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
     else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, shp) * shape_cpt(shp), shape_threads(h, shp), 2 * shape_cpt(shp)));
     if (!h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
@@ -1262,8 +1323,9 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
     for (int i = 0; i < h->n; ++i)
         if (!(channel_probs[i] >= 0.0 && channel_probs[i] <= 1.0))
             return fail(h, BPOSD_ERR_INVALID, "channel_probs[%d] = %g is not a probability", i, channel_probs[i]);
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    { int rcs = sync_all_lanes(h); if (rcs) return rcs; }
     h->probs.assign(channel_probs, channel_probs + h->n);
     return upload_priors(h);
 }
@@ -1291,13 +1353,15 @@ int bposd_pack_rows_device(bposd_handle* h, const uint8_t* d_bytes, int64_t B, i
     if (!h) return BPOSD_ERR_INVALID;
     if (B < 0 || n <= 0 || (B > 0 && (!d_bytes || !d_words))) return fail(h, BPOSD_ERR_INVALID, "bad pack arguments");
     if (B == 0) return BPOSD_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
     const int wpr = (n + 63) / 64;
     const long long nwords = (long long)B * wpr;
     const int threads = 256;
     const long long want = (nwords * 64 + threads - 1) / threads;
     const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 16);
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(threads), 0, h->stream, d_bytes, (long long)B, (int)n, wpr,
+    // queued behind the last device-pointer decode (same lane, stream order)
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(threads), 0, h->lanes[h->last_lane].stream, d_bytes, (long long)B, (int)n, wpr,
                        (unsigned long long*)d_words);
     HIP_TRY(h, hipGetLastError());
     return BPOSD_OK;
@@ -1313,27 +1377,40 @@ int bposd_layout_info(bposd_handle* h, int64_t* natural, int64_t* chosen, int64_
 
 int bposd_synchronize(bposd_handle* h) {
     if (!h) return BPOSD_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return BPOSD_OK;
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    return sync_all_lanes(h);
 }
 
+// One BP launch + one OSD launch on a lane.  lane < 0: a stand-alone device-pointer call, which takes the handle's next
+// lane and is record 0 of a new "last call"; lane >= 0, rec_idx: chunk `rec_idx` of a host-pointer call on that lane.
 static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B, const uint8_t* d_sel,
                               uint8_t* d_osdw, uint8_t* d_osd0, uint8_t* d_bp, uint8_t* d_conv,
-                              int32_t* d_iters, double* d_llr) {
+                              int32_t* d_iters, double* d_llr, int lane = -1, int rec_idx = 0) {
     if (!h) return BPOSD_ERR_INVALID;
     if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
     if (B == 0) return BPOSD_OK;
     if (!d_synd || !d_osdw) return fail(h, BPOSD_ERR_INVALID, "syndromes and osdw buffers are required");
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    if (lane < 0) {
+        lane = h->next_lane;
+        h->next_lane = (h->next_lane + 1) % BPOSD_LANES;
+        h->last_lane = lane;
+        h->nrec = 0;
+        h->currec = &h->lane_rec[lane];  // stream order on the lane: its previous call has filled the record by now
+    } else {
+        h->currec = &h->rec[rec_idx];
+    }
+    h->cur = &h->lanes[lane];
     const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF;
     int rc;
     if (osd_on) {
-        if ((rc = ensure(h, h->llr_ws, sizeof(double) * (size_t)B * h->n))) return rc;
-        if ((rc = ensure(h, h->osd_list, sizeof(int) * (size_t)B))) return rc;
+        if ((rc = ensure(h, h->cur->llr_ws, sizeof(double) * (size_t)B * h->n))) return rc;
+        if ((rc = ensure(h, h->cur->osd_list, sizeof(int) * (size_t)B))) return rc;
     }
-    HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(int) * 4, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_iter_total, 0, sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->cur->d_counters, 0, sizeof(int) * 4, h->cur->stream));
+    HIP_TRY(h, hipMemsetAsync(h->cur->d_iter_total, 0, sizeof(unsigned long long), h->cur->stream));
 
     BpParams P{};
     P.m = h->m;
@@ -1341,6 +1418,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.B = B;
     P.max_iter = h->max_iter;
     P.ms_scaling = h->cfg.ms_scaling_factor;
+    P.ps_clip = h->cfg.ps_clip;
     P.osd_enabled = osd_on ? 1 : 0;
     P.synd = d_synd;
     P.llr0 = h->d_llr0;
@@ -1356,15 +1434,15 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.out_conv = d_conv;
     P.out_iters = d_iters;
     P.out_llr = d_llr;
-    P.llr_ws = (double*)h->llr_ws.p;
-    P.osd_list = (int*)h->osd_list.p;
-    P.counters = h->d_counters;
-    P.iter_total = h->d_iter_total;
+    P.llr_ws = (double*)h->cur->llr_ws.p;
+    P.osd_list = (int*)h->cur->osd_list.p;
+    P.counters = h->cur->d_counters;
+    P.iter_total = h->cur->d_iter_total;
 
-    HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+    HIP_TRY(h, hipEventRecord(h->currec->ev[0], h->cur->stream));
     if (h->bp_hbm) {
         BpLargeParams L{};
-        L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling;
+        L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling; L.ps_clip = P.ps_clip;
         L.osd_enabled = P.osd_enabled; L.mp = h->tab_mp;
         L.synd = P.synd; L.llr0 = P.llr0; L.sel = P.sel; L.llr0_alt = P.llr0_alt;
         L.chk_deg = h->d_chk_deg; L.var_deg = h->d_var_deg; L.var_pos = h->d_var_pos;
@@ -1375,8 +1453,8 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || h->bp_variant >= 16)) {
         if ((rc = launch_bp_local(h, P))) return rc;
     } else if ((rc = launch_bp(h, P))) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-    h->ran_osd = false;
+    HIP_TRY(h, hipEventRecord(h->currec->ev[1], h->cur->stream));
+    h->currec->ran_osd = false;
     if (osd_on) {
         OsdParams Q{};
         Q.m = h->m;
@@ -1388,9 +1466,9 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.synd = d_synd;
         Q.rp = h->d_rp;
         Q.ci = h->d_ci;
-        Q.llr_ws = (const double*)h->llr_ws.p;
-        Q.osd_list = (const int*)h->osd_list.p;
-        Q.counters = h->d_counters;
+        Q.llr_ws = (const double*)h->cur->llr_ws.p;
+        Q.osd_list = (const int*)h->cur->osd_list.p;
+        Q.counters = h->cur->d_counters;
         Q.out_osd0 = d_osd0;
         Q.out_osdw = d_osdw;
         Q.dbg = nullptr;
@@ -1399,9 +1477,9 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.cost_alt = h->d_cost_alt;
         const char* dbg_env = getenv("BPOSD_OSD_DEBUG");
         if (dbg_env && dbg_env[0] == '1') {
-            if (!h->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->d_osd_dbg, 2048 * sizeof(long long)));
-            HIP_TRY(h, hipMemsetAsync(h->d_osd_dbg, 0, 2048 * sizeof(long long), h->stream));
-            Q.dbg = h->d_osd_dbg;
+            if (!h->cur->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->cur->d_osd_dbg, 2048 * sizeof(long long)));
+            HIP_TRY(h, hipMemsetAsync(h->cur->d_osd_dbg, 0, 2048 * sizeof(long long), h->cur->stream));
+            Q.dbg = h->cur->d_osd_dbg;
         }
         if (h->large) {
             if (Q.cost && Q.osd_method >= BPOSD_OSD_E)
@@ -1411,18 +1489,18 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
             if (Q.dbg) {
                 long long st[13];
-                HIP_TRY(h, hipStreamSynchronize(h->stream));
-                HIP_TRY(h, hipMemcpy(st, h->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
+                HIP_TRY(h, hipStreamSynchronize(h->cur->stream));
+                HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[bposd large osd, s_memtime ticks, list slot 0] sort %lld  build %lld  E1 %lld  E2 %lld  E3 %lld  apply %lld  "
                         "sweep %lld | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld apply table builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12]);
                 Q.dbg = nullptr;
             }
         } else if ((rc = launch_osd(h, Q, B))) return rc;
-        h->ran_osd = true;
+        h->currec->ran_osd = true;
         if (Q.dbg) {
             static long long st[2048];
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            HIP_TRY(h, hipMemcpy(st, h->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
+            HIP_TRY(h, hipStreamSynchronize(h->cur->stream));
+            HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
             if (const char* dump = getenv("BPOSD_OSD_DUMP")) {
                 if (FILE* f = fopen(dump, "wb")) { fwrite(st, sizeof(long long), 2048, f); fclose(f); }
             }
@@ -1431,10 +1509,11 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             fprintf(stderr, "[bposd osd elimination] panel phase %lld  trailing phase %lld  pivots %lld\n", st[1190], st[1191], st[1192]);
         }
     }
-    HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->h_counters, h->d_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->h_iter_total, h->d_iter_total, sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->currec->ev[2], h->cur->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->currec->h_counters, h->cur->d_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->cur->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->currec->h_iter_total, h->cur->d_iter_total, sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, h->cur->stream));
+    h->currec->recorded = true;
     h->have_timing = true;
     return BPOSD_OK;
 }
@@ -1454,8 +1533,9 @@ static int upload_alt_channel(bposd_handle* h, const double* alt) {
         l0[i] = std::log((1 - alt[i]) / alt[i]);
         cost[i] = std::log(1 / alt[i]);
     }
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));  // the previous call may still read the old tables
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    { int rcs = sync_all_lanes(h); if (rcs) return rcs; }  // earlier calls may still read the old tables
     HIP_TRY(h, hipMemcpy(h->d_llr0_alt, l0.data(), sizeof(double) * h->n, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_cost_alt, cost.data(), sizeof(double) * h->n, hipMemcpyHostToDevice));
     return 0;
@@ -1489,40 +1569,85 @@ int bposd_decode_batch_select(bposd_handle* h, const uint8_t* synd, int64_t B, c
     return decode_host_impl(h, synd, B, sel, osdw, osd0, bp, conv, iters, llr);
 }
 
+// Host-pointer decode: the batch is cut into chunks that alternate between the handle's lanes, so that the upload of
+// chunk c + 1, the kernels of chunk c and the download of chunk c - 1 overlap, and the BP workgroups of chunk c + 1 take
+// over the CUs that chunk c's stragglers and OSD kernel leave idle.  Within a lane everything is stream-ordered
+// (upload, BP, OSD, downloads), so a lane's staging buffers are reused safely two chunks later.  Page-locked host
+// buffers (bposd_host_alloc) make the copies asynchronous; with pageable memory the host thread blocks inside each
+// copy while the other lane's kernels keep running.
 static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, const uint8_t* sel, uint8_t* osdw,
                             uint8_t* osd0, uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr) {
     if (!h) return BPOSD_ERR_INVALID;
     if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
     if (B == 0) return BPOSD_OK;
     if (!synd || !osdw) return fail(h, BPOSD_ERR_INVALID, "syndromes and osdw buffers are required");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bn = (size_t)B * h->n, bm = (size_t)B * h->m;
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    // the records and lanes are about to be reused: earlier asynchronous calls must have drained
+    { int rcs = sync_all_lanes(h); if (rcs) return rcs; }
+    // chunk size: at least 4 resident grids' worth of syndromes (so that a chunk's own tail stays small against its
+    // body), at most BPOSD_MAX_CHUNKS chunks
+    long long min_chunk = 16384;
+    if (const char* e = getenv("BPOSD_HOST_CHUNK")) min_chunk = std::max(1LL, atoll(e));
+    int nchunks = (int)std::min<long long>(BPOSD_MAX_CHUNKS, std::max<long long>(1, B / min_chunk));
+    if (h->large) nchunks = (int)std::min<long long>(nchunks, std::max<long long>(1, B / (4LL * h->num_cu)));
+    const long long CH = (B + nchunks - 1) / nchunks;
+    nchunks = (int)((B + CH - 1) / CH);
+    const size_t n = (size_t)h->n, m = (size_t)h->m;
     int rc;
-    if ((rc = ensure(h, h->io_synd, bm))) return rc;
-    if ((rc = ensure(h, h->io_osdw, bn))) return rc;
-    if (osd0 && (rc = ensure(h, h->io_osd0, bn))) return rc;
-    if (bp && (rc = ensure(h, h->io_bp, bn))) return rc;
-    if (conv && (rc = ensure(h, h->io_conv, (size_t)B))) return rc;
-    if (iters && (rc = ensure(h, h->io_iters, sizeof(int) * (size_t)B))) return rc;
-    if (llr && (rc = ensure(h, h->io_llr, sizeof(double) * bn))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->io_synd.p, synd, bm, hipMemcpyHostToDevice, h->stream));
-    if (sel) {
-        if ((rc = ensure(h, h->io_sel, bn))) return rc;
-        HIP_TRY(h, hipMemcpyAsync(h->io_sel.p, sel, bn, hipMemcpyHostToDevice, h->stream));
+    for (int c = 0; c < nchunks; ++c) {
+        const long long lo = (long long)c * CH, cnt = std::min<long long>(CH, B - lo);
+        const int lane = c % BPOSD_LANES;
+        Lane& L = h->lanes[lane];
+        h->cur = &L;
+        const size_t bn = (size_t)cnt * n, bm = (size_t)cnt * m;
+        if ((rc = ensure(h, L.io_synd, (size_t)CH * m))) return rc;
+        if ((rc = ensure(h, L.io_osdw, (size_t)CH * n))) return rc;
+        if (osd0 && (rc = ensure(h, L.io_osd0, (size_t)CH * n))) return rc;
+        if (bp && (rc = ensure(h, L.io_bp, (size_t)CH * n))) return rc;
+        if (conv && (rc = ensure(h, L.io_conv, (size_t)CH))) return rc;
+        if (iters && (rc = ensure(h, L.io_iters, sizeof(int) * (size_t)CH))) return rc;
+        if (llr && (rc = ensure(h, L.io_llr, sizeof(double) * (size_t)CH * n))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(L.io_synd.p, synd + (size_t)lo * m, bm, hipMemcpyHostToDevice, L.stream));
+        if (sel) {
+            if ((rc = ensure(h, L.io_sel, (size_t)CH * n))) return rc;
+            HIP_TRY(h, hipMemcpyAsync(L.io_sel.p, sel + (size_t)lo * n, bn, hipMemcpyHostToDevice, L.stream));
+        }
+        rc = decode_device_impl(h, (const uint8_t*)L.io_synd.p, cnt, sel ? (const uint8_t*)L.io_sel.p : nullptr,
+                                (uint8_t*)L.io_osdw.p, osd0 ? (uint8_t*)L.io_osd0.p : nullptr,
+                                bp ? (uint8_t*)L.io_bp.p : nullptr, conv ? (uint8_t*)L.io_conv.p : nullptr,
+                                iters ? (int32_t*)L.io_iters.p : nullptr, llr ? (double*)L.io_llr.p : nullptr, lane, c);
+        if (rc) { (void)sync_all_lanes(h); return rc; }
+        HIP_TRY(h, hipMemcpyAsync(osdw + (size_t)lo * n, L.io_osdw.p, bn, hipMemcpyDeviceToHost, L.stream));
+        if (osd0) HIP_TRY(h, hipMemcpyAsync(osd0 + (size_t)lo * n, L.io_osd0.p, bn, hipMemcpyDeviceToHost, L.stream));
+        if (bp) HIP_TRY(h, hipMemcpyAsync(bp + (size_t)lo * n, L.io_bp.p, bn, hipMemcpyDeviceToHost, L.stream));
+        if (conv) HIP_TRY(h, hipMemcpyAsync(conv + lo, L.io_conv.p, (size_t)cnt, hipMemcpyDeviceToHost, L.stream));
+        if (iters) HIP_TRY(h, hipMemcpyAsync(iters + lo, L.io_iters.p, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, L.stream));
+        if (llr) HIP_TRY(h, hipMemcpyAsync(llr + (size_t)lo * n, L.io_llr.p, sizeof(double) * bn, hipMemcpyDeviceToHost, L.stream));
     }
-    rc = decode_device_impl(h, (const uint8_t*)h->io_synd.p, B, sel ? (const uint8_t*)h->io_sel.p : nullptr,
-                                   (uint8_t*)h->io_osdw.p,
-                                   osd0 ? (uint8_t*)h->io_osd0.p : nullptr, bp ? (uint8_t*)h->io_bp.p : nullptr,
-                                   conv ? (uint8_t*)h->io_conv.p : nullptr, iters ? (int32_t*)h->io_iters.p : nullptr,
-                                   llr ? (double*)h->io_llr.p : nullptr);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(osdw, h->io_osdw.p, bn, hipMemcpyDeviceToHost, h->stream));
-    if (osd0) HIP_TRY(h, hipMemcpyAsync(osd0, h->io_osd0.p, bn, hipMemcpyDeviceToHost, h->stream));
-    if (bp) HIP_TRY(h, hipMemcpyAsync(bp, h->io_bp.p, bn, hipMemcpyDeviceToHost, h->stream));
-    if (conv) HIP_TRY(h, hipMemcpyAsync(conv, h->io_conv.p, (size_t)B, hipMemcpyDeviceToHost, h->stream));
-    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, h->io_iters.p, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->stream));
-    if (llr) HIP_TRY(h, hipMemcpyAsync(llr, h->io_llr.p, sizeof(double) * bn, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->nrec = nchunks;
+    return sync_all_lanes(h);
+}
+
+static int record_timing(bposd_handle* h, CallRecord* recs, int count, double* bp_ms, double* osd_ms,
+                         int64_t* bp_iterations, int64_t* osd_invocations) {
+    double a_sum = 0.0, b_sum = 0.0;
+    int64_t it_sum = 0, osd_sum = 0;
+    for (int r = 0; r < count; ++r) {
+        CallRecord& R = recs[r];
+        if (!R.recorded) continue;
+        float a = 0.f, b = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&a, R.ev[0], R.ev[1]));
+        HIP_TRY(h, hipEventElapsedTime(&b, R.ev[1], R.ev[2]));
+        a_sum += a;
+        if (R.ran_osd) b_sum += b;
+        it_sum += (int64_t)*R.h_iter_total;
+        osd_sum += R.h_counters[1];
+    }
+    if (bp_ms) *bp_ms = a_sum;
+    if (osd_ms) *osd_ms = b_sum;
+    if (bp_iterations) *bp_iterations = it_sum;
+    if (osd_invocations) *osd_invocations = osd_sum;
     return BPOSD_OK;
 }
 
@@ -1530,16 +1655,51 @@ int bposd_last_timing(bposd_handle* h, double* bp_ms, double* osd_ms, int64_t* b
                       int64_t* osd_invocations) {
     if (!h) return BPOSD_ERR_INVALID;
     if (!h->have_timing) return fail(h, BPOSD_ERR_INVALID, "no decode call has been made on this handle");
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    float a = 0.f, b = 0.f;
-    HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-    HIP_TRY(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
-    if (bp_ms) *bp_ms = a;
-    if (osd_ms) *osd_ms = h->ran_osd ? b : 0.0;
-    if (bp_iterations) *bp_iterations = (int64_t)*h->h_iter_total;
-    if (osd_invocations) *osd_invocations = h->h_counters[1];
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    if (h->nrec > 0) {
+        // a host-pointer call is several kernel pairs (one per chunk); their durations are summed (chunks overlap on
+        // the device, so the sum can exceed the call's wall time), the counters add up to the batch's totals
+        int rcs = sync_all_lanes(h);
+        if (rcs) return rcs;
+        return record_timing(h, h->rec, h->nrec, bp_ms, osd_ms, bp_iterations, osd_invocations);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->lanes[h->last_lane].stream));
+    return record_timing(h, &h->lane_rec[h->last_lane], 1, bp_ms, osd_ms, bp_iterations, osd_invocations);
+}
+
+int bposd_num_lanes(void) { return BPOSD_LANES; }
+
+int bposd_last_lane(bposd_handle* h) { return h ? h->last_lane : BPOSD_ERR_INVALID; }
+
+int bposd_synchronize_lane(bposd_handle* h, int32_t lane) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (lane < 0 || lane >= BPOSD_LANES) return fail(h, BPOSD_ERR_INVALID, "lane %d out of range", lane);
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    HIP_TRY(h, hipStreamSynchronize(h->lanes[lane].stream));
     return BPOSD_OK;
+}
+
+int bposd_lane_timing(bposd_handle* h, int32_t lane, double* bp_ms, double* osd_ms, int64_t* bp_iterations,
+                      int64_t* osd_invocations) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (lane < 0 || lane >= BPOSD_LANES) return fail(h, BPOSD_ERR_INVALID, "lane %d out of range", lane);
+    if (!h->have_timing) return fail(h, BPOSD_ERR_INVALID, "no decode call has been made on this handle");
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    HIP_TRY(h, hipStreamSynchronize(h->lanes[lane].stream));
+    return record_timing(h, &h->lane_rec[lane], 1, bp_ms, osd_ms, bp_iterations, osd_invocations);
+}
+
+void* bposd_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void bposd_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 }  // extern "C"

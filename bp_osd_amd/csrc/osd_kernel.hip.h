@@ -91,7 +91,11 @@ struct OsdParams {
 #endif
 
 __device__ __forceinline__ unsigned long long llr_sort_key(double x) {
-    // order-preserving map double -> u64 (x + 0.0 folds -0.0 into +0.0: they compare equal)
+    // order-preserving map double -> u64 (x + 0.0 folds -0.0 into +0.0: they compare equal).  A NaN (product-sum
+    // without clipping) compares "equal" to everything in the reference's comparator; all NaNs share the key of the
+    // padding entries, i.e. they sort last and keep their index order -- for an all-NaN vector (what a non-converged
+    // product-sum run ends in) that is the identity order the reference's stable sort returns.
+    if (x != x) return ~0ull;
     const unsigned long long u = (unsigned long long)__double_as_longlong(x + 0.0);
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }

@@ -60,12 +60,14 @@ class BpOsdDecoder:
     osd_method : "osd_0" | "osd_e" | "osd_cs" (aliases "osd0", "exhaustive", "combination_sweep")
     osd_order : int
     device : int -- HIP device ordinal (build-native; default 0)
+    ps_clip : float -- build-native, product-sum only: 0 (default) keeps the reference formula, whose check-to-bit
+        messages reach +-inf / NaN once tanh rounds to 1; C > 0 clamps them to [-C, C] (DESIGN.md "Product-sum")
     """
 
     def __init__(self, pcm, error_rate=None, error_channel=None, max_iter=0, bp_method="minimum_sum",
                  ms_scaling_factor=1.0, schedule="parallel", omp_thread_count=1, osd_method="osd_0",
                  osd_order=0, input_vector_type="syndrome", channel_probs=None, device=0,
-                 sort_tie_policy=0, weight_fn=0, **kwargs):
+                 sort_tie_policy=0, weight_fn=0, ps_clip=0.0, **kwargs):
         if kwargs:
             raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
         if str(schedule).lower() != "parallel":
@@ -132,6 +134,9 @@ class BpOsdDecoder:
         cfg.osd_order = osd_order
         cfg.sort_tie_policy = int(sort_tie_policy)
         cfg.weight_fn = int(weight_fn)
+        cfg.ps_clip = float(ps_clip)
+        if not (cfg.ps_clip >= 0.0 and np.isfinite(cfg.ps_clip)):
+            raise ValueError("ps_clip must be 0 (no clipping) or a finite positive bound")
         self._h = C.c_void_p()
         rc = lib.bposd_create(C.byref(cfg), self._indptr.ctypes.data, self._indices.ctypes.data,
                               self.m, self.n, self._probs.ctypes.data, C.byref(self._h))
@@ -286,8 +291,68 @@ class BpOsdDecoder:
         """Bit-pack B device rows of n 0/1 bytes into ceil(n/64) uint64 words each (asynchronous)."""
         _lib.check(self._lib, self._h, self._lib.bposd_pack_rows_device(self._h, d_bytes, int(B), int(n), d_words))
 
-    def synchronize(self):
-        _lib.check(self._lib, self._h, self._lib.bposd_synchronize(self._h))
+    def synchronize(self, lane=None):
+        """Wait for everything queued on this decoder, or (``lane``) for the calls queued on one lane only."""
+        if lane is None:
+            _lib.check(self._lib, self._h, self._lib.bposd_synchronize(self._h))
+        else:
+            _lib.check(self._lib, self._h, self._lib.bposd_synchronize_lane(self._h, int(lane)))
+
+    @property
+    def num_lanes(self):
+        """Streams the handle alternates between: consecutive ``decode_batch_device`` calls overlap on the device."""
+        return int(self._lib.bposd_num_lanes())
+
+    @property
+    def last_lane(self):
+        """Lane the last ``decode_batch_device`` call was queued on."""
+        return int(self._lib.bposd_last_lane(self._h))
+
+    def lane_timing(self, lane):
+        """:meth:`last_timing` for the last call queued on ``lane`` (waits for that lane only)."""
+        a, b = C.c_double(), C.c_double()
+        it, no = C.c_int64(), C.c_int64()
+        rc = self._lib.bposd_lane_timing(self._h, int(lane), C.byref(a), C.byref(b), C.byref(it), C.byref(no))
+        _lib.check(self._lib, self._h, rc)
+        return {"bp_ms": a.value, "osd_ms": b.value, "bp_iterations": it.value, "osd_invocations": no.value}
+
+    def pinned_empty(self, shape, dtype=np.uint8):
+        """numpy array in page-locked host memory of the library's HIP runtime (``bposd_host_alloc``): passing such
+        arrays to :meth:`decode_batch_into` makes its chunked uploads / downloads asynchronous."""
+        import weakref
+
+        count = int(np.prod(shape))
+        nbytes = max(1, count * np.dtype(dtype).itemsize)
+        ptr = self._lib.bposd_host_alloc(nbytes)
+        if not ptr:
+            raise MemoryError(f"bposd_host_alloc({nbytes}) failed")
+        buf = (C.c_uint8 * nbytes).from_address(ptr)
+        arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes)[:count * np.dtype(dtype).itemsize].view(dtype).reshape(shape)
+        weakref.finalize(buf, self._lib.bposd_host_free, ptr)  # freed when the last view of the buffer is gone
+        return arr
+
+    def decode_batch_into(self, syndromes, osdw, osd0=None, bp=None, converged=None, iters=None, llr=None):
+        """Host-pointer decode into caller-owned C-contiguous arrays (``uint8 [B, m]`` in; ``uint8 [B, n]``, ``uint8 [B]``,
+        ``int32 [B]``, ``float64 [B, n]`` out; any output but ``osdw`` may be None) -- ``bposd_decode_batch`` with no
+        allocation or conversion on the way."""
+        s = syndromes
+        if s.dtype != np.uint8 or s.ndim != 2 or s.shape[1] != self.m or not s.flags.c_contiguous:
+            raise ValueError(f"syndromes must be a C-contiguous uint8 array of shape (B, {self.m})")
+        B = s.shape[0]
+        for name, a, dt, shp in (("osdw", osdw, np.uint8, (B, self.n)), ("osd0", osd0, np.uint8, (B, self.n)),
+                                 ("bp", bp, np.uint8, (B, self.n)), ("converged", converged, np.uint8, (B,)),
+                                 ("iters", iters, np.int32, (B,)), ("llr", llr, np.float64, (B, self.n))):
+            if a is None:
+                if name == "osdw":
+                    raise ValueError("osdw is required")
+                continue
+            if a.dtype != dt or a.shape != shp or not a.flags.c_contiguous:
+                raise ValueError(f"{name} must be a C-contiguous {np.dtype(dt).name} array of shape {shp}")
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        rc = self._lib.bposd_decode_batch(self._h, s.ctypes.data, B, ptr(osdw), ptr(osd0), ptr(bp), ptr(converged),
+                                          ptr(iters), ptr(llr)) if B else 0
+        _lib.check(self._lib, self._h, rc)
+        return osdw
 
     def last_timing(self):
         """dict(bp_ms, osd_ms, bp_iterations, osd_invocations) of the last decode call (HIP events)."""

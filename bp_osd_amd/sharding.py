@@ -30,6 +30,9 @@ def gather_to_root(local, dst: int = 0, group=None):
         return local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    home = local.device
+    if dist.get_backend(group) == "nccl" and not local.is_cuda:
+        local = local.cuda()  # RCCL moves device tensors only; a numpy-returning decode_fn hands over host memory
     rows = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     all_rows = [torch.zeros_like(rows) for _ in range(world)]
     dist.all_gather(all_rows, rows, group=group)
@@ -42,7 +45,7 @@ def gather_to_root(local, dst: int = 0, group=None):
     dist.gather(local.contiguous(), bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(home)
 
 
 def reduce_counts(counts, group=None):
@@ -73,3 +76,95 @@ def decode_sharded(decode_fn, syndromes, group=None, dst: int = 0):
     if isinstance(out, np.ndarray):
         out = torch.from_numpy(np.ascontiguousarray(out))
     return gather_to_root(out, dst=dst, group=group)
+
+
+class StepPipeline:
+    """Steps of the sharded decode path with the one exchange step overlapped: decode -> bit-pack -> gather to `dst`.
+
+    This is the loop `bench.py --gpus N` times and the loop tests/test_sharding_cpu.py drives on gloo with a stub
+    decoder -- one code path.  The caller supplies the device-side work as callables, all asynchronous except `wait`:
+
+      launch(k, slot)      enqueue the decode of step k on decoder slot `slot` (a slot = one handle + its output buffers)
+      pack(slot, buf)      enqueue the bit-packing of that slot's corrections into packed[buf], ordered after the decode
+      wait(slot)           block until everything enqueued on that slot has finished
+      on_finalised(k, timed)  optional: called once step k's decode has completed (kernel timings are read here)
+      on_gathered(k, rows) optional, `dst` only: rows = the gathered packed corrections of step k, rank order, padding
+                           rows of short shards removed (the caller must synchronise before reading device tensors)
+
+    `packed` is a pair of tensors [rows_max, words] (rows_max = the largest shard over ranks: short shards are padded,
+    a gather needs equal shapes); step k uses packed[k & 1], and a buffer is packed again only after the gather that
+    read it has completed (event-guarded on CUDA tensors, synchronous on CPU tensors).  At most `nslots` steps are in
+    flight; a slot is reused only after its previous step has been finalised."""
+
+    def __init__(self, nslots, launch, wait, pack=None, packed=None, rows=None, gather=True, group=None, dst=0,
+                 on_finalised=None, on_gathered=None):
+        import torch
+        import torch.distributed as dist
+
+        self._torch, self._dist = torch, dist
+        self.nslots = int(nslots)
+        self.launch, self.wait, self.pack = launch, wait, pack
+        self.on_finalised, self.on_gathered = on_finalised, on_gathered
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.do_gather = bool(gather) and self.world > 1
+        self.packed = packed
+        self.pending = []          # (k, timed) enqueued, not yet finalised
+        self.gather_done = [None, None]
+        self.gather_bufs = None
+        self.counts = None
+        if self.do_gather:
+            if pack is None or packed is None or len(packed) != 2:
+                raise ValueError("gathering needs `pack` and a pair of packed buffers")
+            rows = packed[0].shape[0] if rows is None else int(rows)
+            if rows > packed[0].shape[0]:
+                raise ValueError("packed buffers are smaller than the local shard")
+            t = torch.tensor([rows], dtype=torch.int64, device=packed[0].device)
+            allr = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(allr, t, group=group)
+            self.counts = [int(r.item()) for r in allr]
+            if max(self.counts) != packed[0].shape[0]:
+                raise ValueError(f"packed buffers must have max-shard rows = {max(self.counts)}, not {packed[0].shape[0]}")
+            if self.rank == dst:
+                self.gather_bufs = [[torch.empty_like(packed[0]) for _ in range(self.world)] for _ in range(2)]
+
+    def _finalise(self, k, timed):
+        self.wait(k % self.nslots)
+        if self.on_finalised is not None:
+            self.on_finalised(k, timed)
+        if self.do_gather:
+            buf = k & 1
+            src = self.packed[buf]
+            self._dist.gather(src, self.gather_bufs[buf] if self.rank == self.dst else None, dst=self.dst, group=self.group)
+            if src.is_cuda:  # the gather runs on torch's stream: guard the buffer's reuse with an event
+                ev = self._torch.cuda.Event()
+                ev.record()
+                self.gather_done[buf] = ev
+            if self.on_gathered is not None and self.rank == self.dst:
+                self.on_gathered(k, [b[:c] for b, c in zip(self.gather_bufs[buf], self.counts)])
+
+    def step(self, k, timed=True):
+        slot = k % self.nslots
+        while len(self.pending) >= self.nslots:  # slot (and its output buffers) of step k - nslots must be free
+            self._finalise(*self.pending.pop(0))
+        self.launch(k, slot)
+        if self.do_gather:
+            buf = k & 1
+            if self.gather_done[buf] is not None:
+                self.gather_done[buf].synchronize()
+                self.gather_done[buf] = None
+            self.pack(slot, buf)
+        self.pending.append((k, timed))
+
+    def drain(self):
+        while self.pending:
+            self._finalise(*self.pending.pop(0))
+
+    def fence(self):
+        """Everything enqueued so far is complete on every rank (the bracket of a timed region)."""
+        self.drain()
+        if self.world > 1:
+            self._dist.barrier(group=self.group)
+        if self._torch.cuda.is_available() and self._torch.cuda.is_initialized():
+            self._torch.cuda.synchronize()

@@ -128,6 +128,13 @@ class css_decode_sim:
             self.seed = int(np.random.randint(low=1, high=2 ** 32 - 1))
         np.random.seed(self.seed)
 
+        if engine == "torch":
+            # torch bundles its own HIP runtime and must initialise it BEFORE libbposd_mi355x.so pulls in the system
+            # one: otherwise torch reports "No HIP GPUs are available" on the first batch
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
         self.hx = sp.csr_matrix(hx).astype(np.uint8)
         self.hz = sp.csr_matrix(hz).astype(np.uint8)
         self._construct_code()
@@ -140,6 +147,8 @@ class css_decode_sim:
     def _construct_code(self):
         qcode = CssCode(self.hx, self.hz)
         self.lx, self.lz, self.K, self.N = qcode.lx, qcode.lz, qcode.K, qcode.N
+        if self.min_logical_weight == 1e9:  # css_decode_sim.py:142-145: the 1e9 placeholder becomes N before the run
+            self.min_logical_weight = self.N
         if self.check_code and not qcode.test():
             raise Exception("Error: invalid CSS code. Check the form of your hx and hz matrices!")
         self._lx = sp.csr_matrix(self.lx)

@@ -56,7 +56,13 @@ typedef struct {
     int32_t osd_order;         /* osd_e: patterns on the first w non-pivots; osd_cs: pair span */
     int32_t sort_tie_policy;   /* 0 = stable ascending index among equal LLRs, 1 = descending */
     int32_t weight_fn;         /* 0 = sum log(1/p_i) (ldpc v2), 1 = Hamming weight (ldpc v1)  */
-    int32_t reserved[4];       /* must be 0                                                  */
+    int32_t reserved0;         /* must be 0                                                  */
+    double ps_clip;            /* product-sum only.  0 = upstream behaviour: no clipping, so check->bit messages
+                                  reach +-inf once tanh rounds to 1 and NaN follows;
+                                  C > 0 = every check->bit message is clamped to [-C, C] (build-owned switch,
+                                  DESIGN.md "Product-sum").  Occupies two of the four formerly reserved words: a
+                                  zero-filled old config means "no clipping"                  */
+    int32_t reserved[2];       /* must be 0                                                  */
 } bposd_config;
 
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
@@ -131,13 +137,38 @@ int bposd_decode_batch_select_device(bposd_handle *h, const uint8_t *d_syndromes
 int bposd_pack_rows_device(bposd_handle *h, const uint8_t *d_bytes, int64_t B, int32_t n,
                            uint64_t *d_words);
 
-/* Wait for all work queued on the handle's stream. */
+/* Wait for all work queued on the handle (every lane, see below). */
 int bposd_synchronize(bposd_handle *h);
+
+/*
+ * Lanes.  A handle owns bposd_num_lanes() HIP streams with their own workspaces and uses them in turn: consecutive
+ * device-pointer calls (and the chunks of one host-pointer call) overlap on the device, so the next call's workgroups
+ * take over the CUs that the previous call's last max_iter stragglers and its OSD kernel leave idle.  Consequences
+ * for a caller of the asynchronous device-pointer API: two consecutive calls are NOT ordered against each other (give
+ * them different output buffers, or synchronise in between); a call is ordered behind the call before the previous
+ * one (same lane).  bposd_last_lane() names the lane of the last device-pointer call; bposd_synchronize_lane() waits
+ * for that lane only; bposd_lane_timing() is bposd_last_timing() for the last call queued on one lane.
+ * (No counterpart in the reference: its decoder is a synchronous single-thread object.)
+ */
+int bposd_num_lanes(void);
+int bposd_last_lane(bposd_handle *h);
+int bposd_synchronize_lane(bposd_handle *h, int32_t lane);
+int bposd_lane_timing(bposd_handle *h, int32_t lane, double *bp_ms, double *osd_ms, int64_t *bp_iterations,
+                      int64_t *osd_invocations);
+
+/*
+ * Page-locked host memory for the host-pointer API: with buffers from here bposd_decode_batch's chunked uploads and
+ * downloads are truly asynchronous (pageable memory works too; the host thread then blocks inside each copy).
+ * Returns NULL on failure.
+ */
+void *bposd_host_alloc(size_t bytes);
+void bposd_host_free(void *p);
 
 /*
  * Timing and work counters of the LAST decode call, measured with HIP events on the
  * stream the kernels were launched on (waits for that call to finish):
- *   bp_ms, osd_ms    kernel durations
+ *   bp_ms, osd_ms    kernel durations (a host-pointer call runs in chunks: the sum over its chunks, which
+ *                    overlap on the device)
  *   bp_iterations    sum over syndromes of BP iterations executed
  *   osd_invocations  syndromes that went through OSD (BP did not converge)
  * Any pointer may be NULL.

@@ -38,6 +38,8 @@ struct oracle_decoder {
     int *order, *pivcol, *nonpiv, *sort_tmp;
     uint8_t *sol, *best, *tsyn;
     uint8_t *ispiv;
+    /* diagnostics of the last BP run */
+    int diag_first_nonfinite, diag_has_inf, diag_has_nan;
 };
 
 static int parity64(uint64_t x) { return __builtin_parityll(x); }
@@ -156,6 +158,7 @@ int oracle_num_candidates(const oracle_decoder *d) {
 static void bp_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *converged, int32_t *iters) {
     const int m = d->m, n = d->n;
     int conv = 0, it_done = 0;
+    d->diag_first_nonfinite = d->diag_has_inf = d->diag_has_nan = 0;
     /* a3: every edge's bit->check message starts at the prior */
     for (int i = 0; i < n; i++)
         for (int k = d->cp[i]; k < d->cp[i + 1]; k++) d->b2c[d->ce[k]] = d->llr0[i];
@@ -175,6 +178,11 @@ static void bp_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *converged,
                     d->c2b[e] *= temp;
                     int message_sign = syn[c] ? -1 : 1;
                     d->c2b[e] = message_sign * log((1 + d->c2b[e]) / (1 - d->c2b[e]));
+                    if (d->cfg.ps_clip > 0) { /* build-owned switch; upstream does not clip (Appendix A.3 [M]) */
+                        if (d->c2b[e] > d->cfg.ps_clip) d->c2b[e] = d->cfg.ps_clip;
+                        if (d->c2b[e] < -d->cfg.ps_clip) d->c2b[e] = -d->cfg.ps_clip;
+                    }
+                    if (!d->diag_first_nonfinite && !isfinite(d->c2b[e])) d->diag_first_nonfinite = it;
                     temp *= tanh(d->b2c[e] / 2);
                 }
             }
@@ -215,6 +223,7 @@ static void bp_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *converged,
                 temp += d->c2b[e];
             }
             d->llr[i] = temp;
+            if (!d->diag_first_nonfinite && !isfinite(temp)) d->diag_first_nonfinite = it;
             if (temp <= 0) {
                 d->dec[i] = 1;
                 for (int k = d->cp[i]; k < d->cp[i + 1]; k++) d->cand[d->erow[d->ce[k]]] ^= 1;
@@ -235,8 +244,21 @@ static void bp_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *converged,
             }
         }
     }
+    for (int i = 0; i < n && it_done > 0; i++) {
+        if (isnan(d->llr[i])) d->diag_has_nan = 1;
+        else if (isinf(d->llr[i])) d->diag_has_inf = 1;
+    }
     *converged = (uint8_t)conv;
     *iters = it_done;
+}
+
+int oracle_last_bp_diag(const oracle_decoder *d, int32_t *first_nonfinite_iter, int32_t *final_has_inf,
+                        int32_t *final_has_nan) {
+    if (!d) return -1;
+    if (first_nonfinite_iter) *first_nonfinite_iter = d->diag_first_nonfinite;
+    if (final_has_inf) *final_has_inf = d->diag_has_inf;
+    if (final_has_nan) *final_has_nan = d->diag_has_nan;
+    return 0;
 }
 
 /* ---------------------------------------------------------------------------------
@@ -459,6 +481,23 @@ int oracle_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *osdw, uint8_t 
         return 0;
     }
     return oracle_osd(d, syn, d->llr, osdw, osd0, NULL, NULL);
+}
+
+int oracle_decode_batch_diag(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,
+                             uint8_t *osd0, uint8_t *bp, uint8_t *converged, int32_t *iters, double *llr,
+                             int32_t *first_nonfinite_iter, uint8_t *final_has_inf, uint8_t *final_has_nan) {
+    for (int64_t b = 0; b < B; b++) {
+        d->diag_first_nonfinite = d->diag_has_inf = d->diag_has_nan = 0; /* zero syndrome: BP is not run */
+        int rc = oracle_decode(d, syndromes + b * d->m, osdw ? osdw + b * d->n : NULL,
+                               osd0 ? osd0 + b * d->n : NULL, bp ? bp + b * d->n : NULL,
+                               converged ? converged + b : NULL, iters ? iters + b : NULL,
+                               llr ? llr + b * d->n : NULL);
+        if (rc) return rc;
+        if (first_nonfinite_iter) first_nonfinite_iter[b] = d->diag_first_nonfinite;
+        if (final_has_inf) final_has_inf[b] = (uint8_t)d->diag_has_inf;
+        if (final_has_nan) final_has_nan[b] = (uint8_t)d->diag_has_nan;
+    }
+    return 0;
 }
 
 int oracle_decode_batch(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,

@@ -37,6 +37,8 @@ typedef struct {
     int32_t osd_order;
     int32_t sort_tie_policy;
     int32_t weight_fn;
+    double ps_clip;           /* product-sum only: 0 = none (upstream: no clipping, messages reach +-inf and
+                                 NaN); C > 0 = every check->bit message is clamped to [-C, C] (build-owned switch) */
 } oracle_config;
 
 /* pcm as CSR with sorted column indices; channel_probs[n]. Returns 0 or <0. */
@@ -55,6 +57,16 @@ int oracle_decode(oracle_decoder *d, const uint8_t *syndrome, uint8_t *osdw, uin
 int oracle_decode_batch(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,
                         uint8_t *osd0, uint8_t *bp, uint8_t *converged, int32_t *iters,
                         double *llr);
+
+/* oracle_decode_batch plus per-shot BP diagnostics (see oracle_last_bp_diag); the three arrays are nullable. */
+int oracle_decode_batch_diag(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,
+                             uint8_t *osd0, uint8_t *bp, uint8_t *converged, int32_t *iters, double *llr,
+                             int32_t *first_nonfinite_iter, uint8_t *final_has_inf, uint8_t *final_has_nan);
+
+/* Diagnostics of the LAST oracle_decode call's BP run: first iteration in which a check->bit message or a
+ * posterior LLR was not finite (0 = never), and whether the final LLRs contain +-inf / NaN. */
+int oracle_last_bp_diag(const oracle_decoder *d, int32_t *first_nonfinite_iter, int32_t *final_has_inf,
+                        int32_t *final_has_nan);
 
 /* OSD alone on caller-supplied LLRs (used to pin OSD semantics independently of BP). */
 int oracle_osd(oracle_decoder *d, const uint8_t *syndrome, const double *llr, uint8_t *osdw,

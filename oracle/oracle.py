@@ -27,6 +27,7 @@ class _Cfg(C.Structure):
         ("osd_order", C.c_int32),
         ("sort_tie_policy", C.c_int32),
         ("weight_fn", C.c_int32),
+        ("ps_clip", C.c_double),
     ]
 
 
@@ -54,6 +55,8 @@ def _load():
         _lib.oracle_num_candidates.argtypes = [vp]
         _lib.oracle_decode_batch.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
         _lib.oracle_decode_batch.restype = C.c_int
+        _lib.oracle_decode_batch_diag.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        _lib.oracle_decode_batch_diag.restype = C.c_int
         _lib.oracle_osd.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         _lib.oracle_osd.restype = C.c_int
     return _lib
@@ -66,7 +69,8 @@ _OSD = {"osd_off": 0, "off": 0, "osd_0": 1, "osd0": 1, "0": 1, "osd_e": 2, "e": 
 
 class OracleDecoder:
     def __init__(self, pcm, error_rate=None, channel_probs=None, max_iter=0, bp_method="ms",
-                 ms_scaling_factor=1.0, osd_method="osd0", osd_order=0, sort_tie_policy=0, weight_fn=0):
+                 ms_scaling_factor=1.0, osd_method="osd0", osd_order=0, sort_tie_policy=0, weight_fn=0,
+                 ps_clip=0.0):
         lib = _load()
         h = sp.csr_matrix(pcm).astype(np.uint8)
         h.eliminate_zeros()
@@ -79,7 +83,7 @@ class OracleDecoder:
         self._indptr = np.ascontiguousarray(h.indptr, dtype=np.int32)
         self._indices = np.ascontiguousarray(h.indices, dtype=np.int32)
         cfg = _Cfg(_BP[str(bp_method).lower()], float(ms_scaling_factor), int(max_iter),
-                   _OSD[str(osd_method).lower()], int(osd_order), int(sort_tie_policy), int(weight_fn))
+                   _OSD[str(osd_method).lower()], int(osd_order), int(sort_tie_policy), int(weight_fn), float(ps_clip))
         self._h = C.c_void_p()
         rc = lib.oracle_create(C.byref(cfg), self._indptr.ctypes.data, self._indices.ctypes.data,
                                self.m, self.n, probs.ctypes.data, C.byref(self._h))
@@ -98,7 +102,7 @@ class OracleDecoder:
         assert probs.shape == (self.n,)
         _load().oracle_update_channel_probs(self._h, probs.ctypes.data)
 
-    def decode_batch(self, syndromes, want_llr=True):
+    def decode_batch(self, syndromes, want_llr=True, want_diag=False):
         s = np.ascontiguousarray(np.asarray(syndromes) & 1, dtype=np.uint8)
         if s.ndim == 1:
             s = s[None, :]
@@ -112,10 +116,20 @@ class OracleDecoder:
             "iters": np.zeros(B, np.int32),
             "llr": np.zeros((B, self.n), np.float64) if want_llr else None,
         }
-        rc = _load().oracle_decode_batch(
-            self._h, s.ctypes.data, B, out["osdw"].ctypes.data, out["osd0"].ctypes.data,
-            out["bp"].ctypes.data, out["converged"].ctypes.data, out["iters"].ctypes.data,
-            out["llr"].ctypes.data if want_llr else None)
+        if want_diag:  # per-shot BP saturation record (product-sum): first non-finite iteration, final inf / NaN
+            out["first_nonfinite_iter"] = np.zeros(B, np.int32)
+            out["final_has_inf"] = np.zeros(B, np.uint8)
+            out["final_has_nan"] = np.zeros(B, np.uint8)
+            rc = _load().oracle_decode_batch_diag(
+                self._h, s.ctypes.data, B, out["osdw"].ctypes.data, out["osd0"].ctypes.data,
+                out["bp"].ctypes.data, out["converged"].ctypes.data, out["iters"].ctypes.data,
+                out["llr"].ctypes.data if want_llr else None, out["first_nonfinite_iter"].ctypes.data,
+                out["final_has_inf"].ctypes.data, out["final_has_nan"].ctypes.data)
+        else:
+            rc = _load().oracle_decode_batch(
+                self._h, s.ctypes.data, B, out["osdw"].ctypes.data, out["osd0"].ctypes.data,
+                out["bp"].ctypes.data, out["converged"].ctypes.data, out["iters"].ctypes.data,
+                out["llr"].ctypes.data if want_llr else None)
         if rc != 0:
             raise RuntimeError(f"oracle_decode_batch failed ({rc})")
         return out

@@ -4,7 +4,9 @@ Same provenance as make_golden.py (this repository's oracle; no reference code).
 oracle needs minutes here: the elimination of one 14520 x 29524 matrix takes ~4.5 s and every OSD-W candidate
 another ~7 ms, so the orders are kept small (osd_e 10 -> 1023 candidates; osd_cs 3 -> 15004 + 3).
 
-    python tests/golden/make_golden_l29k.py
+    python tests/golden/make_golden_l29k.py            (e10 + cs3)
+    python tests/golden/make_golden_l29k.py e15        (BASELINE configs[4]'s own settings: osd_e 15, max_iter 100,
+                                                        q = 0.05; 32767 candidates x ~7 ms -> ~4 min per OSD shot)
 """
 import hashlib
 import os
@@ -24,9 +26,31 @@ def pack(a):
     return np.packbits(np.asarray(a, dtype=np.uint8), axis=1)
 
 
+def make_e15(H, digest):
+    """configs[4] at its stated settings.  Shots are picked with a BP-only pass (fast): two that do not converge in
+    100 iterations (they go through the 32767-candidate OSD-E sweep) and one that does."""
+    q = 0.05
+    rng = np.random.default_rng(15)
+    err = (rng.random((24, H.shape[1])) < q).astype(np.uint8)
+    syn = np.ascontiguousarray((H.astype(np.int32) @ err.T.astype(np.int32) % 2).T.astype(np.uint8))
+    bp_only = dict(error_rate=q, max_iter=100, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_off", osd_order=0)
+    conv = OracleDecoder(H, **bp_only).decode_batch(syn, want_llr=False)["converged"].astype(bool)
+    pick = list(np.flatnonzero(~conv)[:2]) + list(np.flatnonzero(conv)[:1])
+    sub = np.ascontiguousarray(syn[pick])
+    cfg = dict(error_rate=q, max_iter=100, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=15)
+    t0 = time.time()
+    r = OracleDecoder(H, **cfg).decode_batch(sub)
+    print("e15", "%.1fs" % (time.time() - t0), "converged", r["converged"], "weights", r["osdw"].sum(1), r["osd0"].sum(1), flush=True)
+    np.savez_compressed(os.path.join(HERE, "l29k_golden_e15.npz"), cfg=repr(cfg), code_sha256=digest,
+                        syn=pack(sub), osdw=pack(r["osdw"]), osd0=pack(r["osd0"]), bp=pack(r["bp"]),
+                        converged=r["converged"], iters=r["iters"])
+
+
 def main():
     H = l29k().hz
     digest = hashlib.sha256(H.indptr.tobytes() + H.indices.tobytes()).hexdigest()
+    if len(sys.argv) > 1 and sys.argv[1] == "e15":
+        return make_e15(H, digest)
     q = 0.06
     rng = np.random.default_rng(29524)
     err = (rng.random((4, H.shape[1])) < q).astype(np.uint8)

@@ -49,7 +49,7 @@ def serial_reference_loop(hx, hz, lx, lz, *, error_rate, xyz_error_bias, target_
     bpd_x = OracleDecoder(hz, channel_probs=cpx + cpy, **kw)
     np.random.seed(seed)
     c = dict(osdw_success_count=0, osd0_success_count=0, bp_success_count=0, bp_converge_count_x=0,
-             bp_converge_count_z=0, min_logical_weight=1e9)
+             bp_converge_count_z=0, min_logical_weight=N)  # css_decode_sim.py:142-145
     for _ in range(target_runs):
         ex, ez = np.zeros(N, dtype=np.uint8), np.zeros(N, dtype=np.uint8)
         for i in range(N):

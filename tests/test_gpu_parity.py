@@ -563,10 +563,12 @@ def test_large_code_rank_deficient_osd(gpu_ready):
     _compare_exact(r, o.decode_batch(syn))
 
 
-@pytest.mark.parametrize("name", ["e10", "cs3"])
+@pytest.mark.parametrize("name", ["e10", "cs3", "e15"])
 def test_l29k_golden(gpu_ready, name):
     """BASELINE configs[4]'s code (14520 x 29524, 16 rows per thread in the OSD kernel) against oracle vectors
-    frozen in tests/golden/l29k_golden_*.npz (tests/golden/make_golden_l29k.py; the oracle needs minutes there)."""
+    frozen in tests/golden/l29k_golden_*.npz (tests/golden/make_golden_l29k.py; the oracle needs minutes there).
+    "e15" is configs[4] at its stated settings: min-sum, max_iter = 100, osd_e order 15 (32767 candidates), q = 0.05;
+    two shots through OSD, one converged."""
     import ast
     import hashlib
     import os
@@ -879,3 +881,195 @@ def test_harness_torch_engine_equals_numpy_engine(gpu_ready, hgp400, channel_upd
     assert "engine" not in c.output_dict() and "_engine" not in c.output_dict()
     with pytest.raises(ValueError):
         css_decode_sim(hx=hgp400.hx, hz=hgp400.hz, engine="numpy", rng="torch", run_sim=0, **opts)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[2] itself: H1922, product-sum, max_iter = n, osd_cs order 60 (a5)
+def _llr_margins(llr):
+    """per row: all finite?, smallest gap between two distinct values, smallest |value| (inf where not finite)."""
+    fin = np.isfinite(llr).all(axis=1)
+    gap = np.full(len(llr), np.inf)
+    mabs = np.full(len(llr), np.inf)
+    for b in np.flatnonzero(fin):
+        d = np.diff(np.sort(llr[b]))
+        d = d[d > 0]
+        gap[b] = d.min() if len(d) else np.inf
+        mabs[b] = np.abs(llr[b]).min()
+    return fin, gap, mabs
+
+
+@pytest.mark.parametrize("name", ["noclip", "clip20"])
+def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
+    """configs[2] at its stated settings against 2048 oracle shots frozen in tests/golden/ps_cs60_*.npz
+    (tests/golden/make_golden_ps.py).  Device tanh / log differ from glibc's by ulps, so the bar is SURVEY.md Appendix B
+    item 5, written out here:
+
+      * "clean" shots -- final LLRs finite on BOTH sides, smallest gap between distinct LLR values > 1e-9 and smallest
+        |LLR| > 1e-9 on both sides: converge flag, iteration count, bp, osd0 and osdw decodings must be IDENTICAL;
+      * "all-NaN" shots (noclip only) -- both sides ended with NaN LLRs; the reliability order is then the index order
+        on both sides (the reference's comparator calls NaN equal to everything): outputs must be identical too;
+      * the rest (converged with +-inf LLRs, or an ulp-level event moved the iteration of convergence) are counted and
+        bounded; every correction, of every class, must reproduce its syndrome;
+      * the logical error rate agrees with the oracle's within 3 binomial standard deviations.
+
+    noclip = the reference formula (messages saturate: ~8 iterations in, tanh rounds to 1, log gives inf, inf - inf NaN);
+    clip20 = the build-owned ps_clip switch (DESIGN.md "Product-sum")."""
+    import ast
+    import os
+
+    from bp_osd_amd import BpOsdDecoder
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"ps_cs60_{name}.npz"), allow_pickle=False)
+    H = h1922.hz
+    m, n = H.shape
+    cfg = ast.literal_eval(str(g["cfg"]))
+    assert cfg["bp_method"] == "ps" and cfg["osd_order"] == 60 and cfg["max_iter"] == 0
+    err = np.unpackbits(g["err"], axis=1)[:, :n]
+    syn = _syndrome_of(H, err)
+    B = len(syn)
+    assert B >= 2048
+    unpack = lambda k: np.unpackbits(g[k], axis=1)[:, :n]
+    ref = dict(osdw=unpack("osdw"), osd0=unpack("osd0"), bp=unpack("bp"), converged=g["converged"].astype(bool), iters=g["iters"])
+    r = _gpu_decode(BpOsdDecoder(H, **cfg), syn)
+    assert (_syndrome_of(H, r["osdw"]) == syn).all() and (_syndrome_of(H, r["osd0"]) == syn).all()
+
+    fin_g, gap_g, abs_g = _llr_margins(r["llr"])
+    fin_o = (g["final_has_inf"] == 0) & (g["final_has_nan"] == 0)
+    gap_o = np.where(np.isfinite(g["min_gap"]), g["min_gap"], np.inf)
+    abs_o = np.where(np.isfinite(g["min_abs"]), g["min_abs"], np.inf)
+    clean = fin_g & fin_o & (gap_g > 1e-9) & (gap_o > 1e-9) & (abs_g > 1e-9) & (abs_o > 1e-9)
+    allnan = np.isnan(r["llr"]).all(axis=1) & (g["final_has_nan"] != 0) & ~ref["converged"] & ~r["converged"]
+    same = ((r["converged"] == ref["converged"]) & (r["iters"] == ref["iters"]) & (r["bp"] == ref["bp"]).all(axis=1) &
+            (r["osd0"] == ref["osd0"]).all(axis=1) & (r["osdw"] == ref["osdw"]).all(axis=1))
+    rest = ~(clean | allnan)
+    print(f"\n[configs[2] {name}] shots {B}: clean {int(clean.sum())} (identical {int((same & clean).sum())}), "
+          f"all-NaN {int(allnan.sum())} (identical {int((same & allnan).sum())}), rest {int(rest.sum())} "
+          f"(identical {int((same & rest).sum())}); oracle saturation: {int((g['first_nonfinite_iter'] > 0).sum())} shots, "
+          f"median first non-finite iteration {np.median(g['first_nonfinite_iter'][g['first_nonfinite_iter'] > 0]) if (g['first_nonfinite_iter'] > 0).any() else None}; "
+          f"converged gpu {r['converged'].mean():.4f} oracle {ref['converged'].mean():.4f}")
+    assert (same | ~clean).all(), f"{int((~same & clean).sum())} clean shots differ from the oracle"
+    assert (same | ~allnan).all(), f"{int((~same & allnan).sum())} all-NaN shots differ from the oracle"
+    if name == "clip20":
+        assert clean.mean() >= 0.99, clean.mean()        # with clipping nothing saturates: (almost) every shot is clean
+        assert (~same).mean() <= 0.002, (~same).mean()
+    else:
+        assert (clean | allnan).mean() >= 0.55, (clean | allnan).mean()
+        assert (~same & rest).mean() <= 0.05, (~same & rest).mean()   # ulp-level events among the saturated, converged shots
+    # LER agreement (one sector: residual must commute with every logical Z)
+    lz = h1922.lz.astype(np.int64)
+    fails = lambda x: (((x ^ err).astype(np.int64) @ lz.T) % 2).any(axis=1).mean()
+    Lg, Lo = fails(r["osdw"]), fails(ref["osdw"])
+    sd = max(np.sqrt(max(Lo, 1.0 / B) * (1 - Lo) / B), 1e-9)
+    assert abs(Lg - Lo) <= 3 * sd + 1e-12, (Lg, Lo, sd)
+    if name == "clip20":
+        assert Lo < 0.01 and r["converged"].mean() > 0.99
+    else:
+        assert 0.3 < Lo < 0.55  # the unclipped formula is numerically dead: ~44 % of shots end all-NaN
+
+
+def test_product_sum_clip_vs_oracle_live(gpu_ready, h1922, hgp400):
+    """ps_clip through the whole stack against the live oracle (LDS kernel on two codes, several clip values)."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    for H, q, B in ((h1922.hz, 0.05, 192), (hgp400.hx, 0.06, 256)):
+        _, syn = _syndromes(H, q, B, 77)
+        for clip in (8.0, 20.0, 37.0):
+            kw = dict(error_rate=q, max_iter=40, bp_method="ps", osd_method="osd_cs", osd_order=10, ps_clip=clip)
+            r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
+            ref = OracleDecoder(H, **kw).decode_batch(syn)
+            assert np.isfinite(r["llr"]).all() and np.isfinite(ref["llr"]).all()
+            same = (r["iters"] == ref["iters"]) & (r["converged"] == ref["converged"].astype(bool)) & \
+                   (r["osdw"] == ref["osdw"]).all(axis=1) & (r["osd0"] == ref["osd0"]).all(axis=1)
+            assert same.mean() >= 0.99, (clip, same.mean())
+            close = np.abs(r["llr"][same] - ref["llr"][same]) <= 1e-9 * (1 + np.abs(ref["llr"][same]))
+            assert close.mean() >= 1 - 1e-4
+    with pytest.raises(ValueError):
+        BpOsdDecoder(h1922.hz, error_rate=0.05, bp_method="ps", ps_clip=-1.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# lanes: consecutive asynchronous calls overlap; chunked host-pointer calls
+def test_lanes_consecutive_device_calls_overlap_and_agree(gpu_ready, h1922):
+    import torch
+
+    from bp_osd_amd import BpOsdDecoder
+
+    H = h1922.hz
+    m, n = H.shape
+    q = 0.06
+    kw = dict(error_rate=q, max_iter=200, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_cs", osd_order=7)
+    dec = BpOsdDecoder(H, **kw)
+    assert dec.num_lanes >= 2
+    dev = torch.device("cuda", 0)
+    B = 6000
+    batches = [_syndromes(H, q, B, 100 + k)[1] for k in range(5)]
+    serial = []
+    for s in batches:  # one at a time through the host API
+        r = _gpu_decode(dec, s, want_llr=False)
+        serial.append((r["osdw"].copy(), r["iters"].copy(), int((~r["converged"]).sum())))
+    d_syn = [torch.from_numpy(s).to(dev) for s in batches]
+    outs = [dict(osdw=torch.empty((B, n), dtype=torch.uint8, device=dev), osd0=torch.empty((B, n), dtype=torch.uint8, device=dev),
+                 conv=torch.empty(B, dtype=torch.uint8, device=dev), iters=torch.empty(B, dtype=torch.int32, device=dev))
+            for _ in batches]
+    lanes = []
+    for s, o in zip(d_syn, outs):  # all five queued back to back, nothing synchronised in between
+        dec.decode_batch_device(s.data_ptr(), B, o["osdw"].data_ptr(), o["osd0"].data_ptr(), None, o["conv"].data_ptr(),
+                                o["iters"].data_ptr(), None)
+        lanes.append(dec.last_lane)
+    assert lanes == [lanes[0], 1 - lanes[0]] * 2 + [lanes[0]]
+    # per-lane timing refers to the LAST call queued on that lane: calls 5 and 4
+    t_a = dec.lane_timing(lanes[4])
+    t_b = dec.lane_timing(lanes[3])
+    dec.synchronize()
+    for k, o in enumerate(outs):
+        assert (o["osdw"].cpu().numpy() == serial[k][0]).all(), k
+        assert (o["iters"].cpu().numpy() == serial[k][1]).all(), k
+    assert t_a["bp_iterations"] == int(serial[4][1].sum()) and t_a["osd_invocations"] == serial[4][2]
+    assert t_b["bp_iterations"] == int(serial[3][1].sum()) and t_b["osd_invocations"] == serial[3][2]
+    assert dec.last_timing()["bp_iterations"] == int(serial[4][1].sum())
+
+
+def test_chunked_host_api_equals_single_chunk(gpu_ready, h1922, monkeypatch):
+    """bposd_decode_batch cuts large batches into chunks that alternate between the lanes; the chunk size must not
+    show in any output (pageable and page-locked buffers, with and without a per-shot channel)."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = h1922.hz
+    m, n = H.shape
+    q = 0.07
+    kw = dict(error_rate=q, max_iter=30, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_cs", osd_order=7)
+    B = 1237
+    _, syn = _syndromes(H, q, B, 5)
+    dec = BpOsdDecoder(H, **kw)
+    monkeypatch.setenv("BPOSD_HOST_CHUNK", "1000000")
+    one = _gpu_decode(dec, syn)
+    one = {k: np.array(v, copy=True) for k, v in one.items()}
+    t_one = dec.last_timing()
+    monkeypatch.setenv("BPOSD_HOST_CHUNK", "100")  # -> 8 chunks of 155 (the last one 152)
+    many = _gpu_decode(dec, syn)
+    _compare_exact(many, one)
+    t_many = dec.last_timing()
+    assert t_many["bp_iterations"] == t_one["bp_iterations"] == int(one["iters"].sum())
+    assert t_many["osd_invocations"] == t_one["osd_invocations"] == int((~one["converged"]).sum())
+    ref = OracleDecoder(H, **kw).decode_batch(syn[:200])
+    _compare_exact({k: v[:200] for k, v in many.items()}, ref)
+    # page-locked buffers through decode_batch_into
+    h_syn = dec.pinned_empty((B, m))
+    h_syn[:] = syn
+    h_out = dict(osdw=dec.pinned_empty((B, n)), osd0=dec.pinned_empty((B, n)), bp=dec.pinned_empty((B, n)),
+                 converged=dec.pinned_empty((B,)), iters=dec.pinned_empty((B,), np.int32), llr=dec.pinned_empty((B, n), np.float64))
+    dec.decode_batch_into(h_syn, **h_out)
+    pinned = dict(h_out, converged=h_out["converged"].astype(bool))
+    _compare_exact(pinned, one)
+    with pytest.raises(ValueError):
+        dec.decode_batch_into(h_syn.astype(np.int32), h_out["osdw"])
+    # per-shot channel (select) through the chunks
+    rng = np.random.default_rng(9)
+    sel = (rng.random((B, n)) < 0.1).astype(np.uint8)
+    alt = np.full(n, 0.2)
+    a = dec.decode_batch(syn, prior_select=sel, alt_channel_probs=alt).copy()
+    monkeypatch.setenv("BPOSD_HOST_CHUNK", "1000000")
+    b = dec.decode_batch(syn, prior_select=sel, alt_channel_probs=alt)
+    assert (a == b).all()

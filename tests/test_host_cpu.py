@@ -31,8 +31,9 @@ def test_library_exports_every_header_symbol(lib):
 
 
 def test_config_struct_layout_matches_header():
-    # int32, int32, double, int32 x5, int32[4]  -> 8-byte aligned double at offset 8
+    # int32, int32, double, int32 x6, double, int32[2]  -> 8-byte aligned doubles at offsets 8 and 40
     assert _lib.BposdConfig.ms_scaling_factor.offset == 8
+    assert _lib.BposdConfig.ps_clip.offset == 40
     assert ctypes.sizeof(_lib.BposdConfig) == 56
 
 

@@ -79,3 +79,103 @@ def test_world_size_2_gloo_shard_decode_gather(total):
         p.join(timeout=180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# StepPipeline: the loop bench.py --gpus N runs (decode -> pack -> gather, two slots, double-buffered packed rows),
+# driven here on gloo with a stub decoder whose "stream" is a per-slot queue executed in order at wait() time.
+def _pack_words(bits):
+    """numpy twin of bposd_pack_rows_device: bit (i & 63) of word (i >> 6) = bits[:, i]."""
+    B, n = bits.shape
+    wpr = (n + 63) // 64
+    padded = np.zeros((B, wpr * 64), dtype=np.uint8)
+    padded[:, :n] = bits
+    return np.packbits(padded, axis=1, bitorder="little").view(np.int64).reshape(B, wpr)
+
+
+def _pipeline_worker(rank, world, port, total, steps, q_out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bp_osd_amd.sharding import StepPipeline, shard_bounds
+
+        n, nslots = 100, 2
+        wpr = (n + 63) // 64
+        lo, hi = shard_bounds(total, rank, world)
+        rows = hi - lo
+        rows_max = max(shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world))
+
+        def truth(k, r):  # the "corrections" of rank r at step k: a deterministic function of (step, global row, column)
+            a, b = shard_bounds(total, r, world)
+            g = np.arange(a, b)[:, None]
+            return ((g * 31 + np.arange(n)[None, :] * 17 + k * 7) % 5 == 0).astype(np.uint8)
+
+        out = [np.zeros((rows, n), np.uint8) for _ in range(nslots)]       # a slot's output buffer
+        packed = [torch.zeros((rows_max, wpr), dtype=torch.int64) for _ in range(2)]
+        queues = [[] for _ in range(nslots)]                                # stream-ordered work of each slot
+        log = []
+
+        def launch(k, slot):
+            queues[slot].append(lambda: out[slot].__setitem__(slice(None), truth(k, rank)))
+
+        def pack(slot, buf):
+            queues[slot].append(lambda: packed[buf][:rows].copy_(torch.from_numpy(_pack_words(out[slot]))))
+
+        def wait(slot):
+            for job in queues[slot]:
+                job()
+            queues[slot].clear()
+
+        checked = []
+
+        def on_gathered(k, shards):
+            assert [s.shape[0] for s in shards] == [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]
+                                                    for r in range(world)]
+            for r, s in enumerate(shards):
+                assert (s.numpy() == _pack_words(truth(k, r))).all(), (k, r)
+            checked.append(k)
+
+        pipe = StepPipeline(nslots, launch, wait, pack=pack, packed=packed, rows=rows,
+                            on_finalised=lambda k, timed: log.append((k, timed)), on_gathered=on_gathered)
+        pipe.step(0, False)
+        pipe.fence()
+        for k in range(1, steps + 1):
+            pipe.step(k, True)
+            assert len(pipe.pending) <= nslots
+        pipe.fence()
+        assert log == [(0, False)] + [(k, True) for k in range(1, steps + 1)]
+        if rank == 0:
+            assert checked == list(range(steps + 1))
+            q_out.put("ok")
+        else:
+            assert checked == []
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [33, 64])
+def test_world_size_2_gloo_step_pipeline(total):
+    """Buffer reuse over 6 steps (3 rounds of each slot and of each packed buffer), unequal shards (17 + 16 of 33)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, total, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok"
+
+
+def test_step_pipeline_single_process_needs_no_process_group():
+    from bp_osd_amd.sharding import StepPipeline
+
+    done = []
+    pipe = StepPipeline(2, launch=lambda k, slot: done.append(("launch", k, slot)), wait=lambda slot: done.append(("wait", slot)))
+    for k in range(3):
+        pipe.step(k)
+    pipe.fence()
+    assert [d for d in done if d[0] == "launch"] == [("launch", 0, 0), ("launch", 1, 1), ("launch", 2, 0)]
+    assert done.index(("wait", 0)) < done.index(("launch", 2, 0))  # slot 0 is reused only after step 0 was finalised
