@@ -199,7 +199,7 @@ def main():
     dec = BpOsdDecoder(H, device=local_rank, **kw)
     if args.variant:
         dec.set_bp_variant(args.variant)
-    nslots = 1 if args.no_pipeline else dec.num_lanes
+    nslots = 1 if args.no_pipeline else 2  # steps in flight (the handle has dec.num_lanes >= 2 lanes)
 
     dev = torch.device("cuda", local_rank)
     d_syn = [torch.from_numpy(b[1]).to(dev) for b in batches]

@@ -94,7 +94,7 @@ def load():
     lib.bposd_pack_rows_device.restype = C.c_int
     lib.bposd_synchronize.argtypes = [vp]
     lib.bposd_synchronize.restype = C.c_int
-    lib.bposd_num_lanes.argtypes = []
+    lib.bposd_num_lanes.argtypes = [vp]
     lib.bposd_num_lanes.restype = C.c_int
     lib.bposd_last_lane.argtypes = [vp]
     lib.bposd_last_lane.restype = C.c_int

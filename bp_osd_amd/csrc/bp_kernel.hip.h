@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "portable_math.h"  // bit-reproducible tanh / log of the product-sum update
+
 namespace bposd {
 
 // LDS message array type: volatile LDS-address-space accesses stop hipcc from fusing pairs into
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                             for (int k = 0; k < DC; ++k) {
                                 if (REG || k < deg) {
                                     pre[k] = t;
-                                    th[k] = tanh(v[k] / 2);
+                                    th[k] = pm_tanh(v[k] / 2);
                                     t *= th[k];
                                 }
                             }
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                             for (int k = DC - 1; k >= 0; --k) {
                                 if (REG || k < deg) {
                                     const double x = pre[k] * t;
-                                    double o = sg * log((1 + x) / (1 - x));
+                                    double o = sg * pm_log((1 + x) / (1 - x));
                                     if (P.ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
                                         if (o > P.ps_clip) o = P.ps_clip;
                                         if (o < -P.ps_clip) o = -P.ps_clip;

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "portable_math.h"  // bit-reproducible tanh / log of the product-sum update
+
 #include "bp_kernel.hip.h"
 
 namespace bposd {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                         for (int k = 0; k < DC; ++k) {
                             if (k < deg) {
                                 pre[k] = t;
-                                th[k] = tanh(v[k] / 2);
+                                th[k] = pm_tanh(v[k] / 2);
                                 t *= th[k];
                             }
                         }
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                         for (int k = DC - 1; k >= 0; --k) {
                             if (k < deg) {
                                 const double x = pre[k] * t;
-                                double o = sg * log((1 + x) / (1 - x));
+                                double o = sg * pm_log((1 + x) / (1 - x));
                                 if (P.ps_clip > 0.0) {
                                     if (o > P.ps_clip) o = P.ps_clip;
                                     if (o < -P.ps_clip) o = -P.ps_clip;

@@ -68,26 +68,24 @@ __host__ __device__ inline size_t bp_local_lds_bytes(int mp) {
 // check that follows the owner cyclically (rank DL+1 mod 3), Y the one after (rank DL+2 mod 3): the roles are tied to
 // the owner, not to the index order, which keeps the LDS access pattern of structured codes regular across the
 // wrap-around of their circulants.  The sums run in rank order.
+// The reference starts the suffix sums at 0.0 ("temp = 0; b2c += temp; temp += c2b", bottom edge first).  Two of its
+// additions are identities and are not executed here: pre2 + 0.0 (== pre2 unless pre2 is -0.0) and 0.0 + c2 (== c2
+// unless c2 is -0.0, in which case the +0.0 it would give differs from c2 only in the sign of a zero that is then added
+// to pre1 / to c1 + pre0).  A prefix is -0.0 only if the prior is, and a prior log((1 - p) / p) never is (log(1) = +0.0);
+// with non-negative-zero prefixes x + (+0.0) == x + (-0.0) bit for bit.  tests/test_gpu_parity.py compares LLR bits.
 template <int DL>
 __device__ __forceinline__ void bit_update(double l0, double R, double X, double Y, double& llr, double& oR, double& oX,
                                            double& oY) {
     const double c0 = DL == 0 ? R : (DL == 1 ? Y : X);
     const double c1 = DL == 0 ? X : (DL == 1 ? R : Y);
     const double c2 = DL == 0 ? Y : (DL == 1 ? X : R);
-    double t = l0;
-    const double pre0 = t;  // prefix from the top of the column (prior included)
-    t += c0;
-    const double pre1 = t;
-    t += c1;
-    const double pre2 = t;
-    t += c2;
-    llr = t;
-    double suf = 0.0;  // suffix from the bottom of the column
-    const double o2 = pre2 + suf;
-    suf += c2;
-    const double o1 = pre1 + suf;
-    suf += c1;
-    const double o0 = pre0 + suf;
+    const double pre0 = l0;  // prefix from the top of the column (prior included)
+    const double pre1 = pre0 + c0;
+    const double pre2 = pre1 + c1;
+    llr = pre2 + c2;
+    const double o2 = pre2;            // + suffix 0.0
+    const double o1 = pre1 + c2;       // + suffix (0.0 + c2)
+    const double o0 = pre0 + (c2 + c1);
     oR = DL == 0 ? o0 : (DL == 1 ? o1 : o2);
     oX = DL == 0 ? o1 : (DL == 1 ? o2 : o0);
     oY = DL == 0 ? o2 : (DL == 1 ? o0 : o1);
@@ -100,27 +98,23 @@ __device__ __forceinline__ void bit_update_mixed(int dlv, double l0, double R, d
     const double c0 = d0 ? R : (d1 ? Y : X);
     const double c1 = d0 ? X : (d1 ? R : Y);
     const double c2 = d0 ? Y : (d1 ? X : R);
-    double t = l0;
-    const double pre0 = t;
-    t += c0;
-    const double pre1 = t;
-    t += c1;
-    const double pre2 = t;
-    t += c2;
-    llr = t;
-    double suf = 0.0;
-    const double o2 = pre2 + suf;
-    suf += c2;
-    const double o1 = pre1 + suf;
-    suf += c1;
-    const double o0 = pre0 + suf;
+    const double pre0 = l0;
+    const double pre1 = pre0 + c0;
+    const double pre2 = pre1 + c1;
+    llr = pre2 + c2;
+    const double o2 = pre2;
+    const double o1 = pre1 + c2;
+    const double o0 = pre0 + (c2 + c1);
     oR = d0 ? o0 : (d1 ? o1 : o2);
     oX = d0 ? o1 : (d1 ? o2 : o0);
     oY = d0 ? o2 : (d1 ? o0 : o1);
 }
 
-// CPT: checks per thread (each with its two owned bits); MPT: positions (power of two) = blockDim.x * CPT
-template <int CPT, int MPT, int MINW>
+// CPT: checks per thread (each with its two owned bits); MPT: positions (power of two) = blockDim.x * CPT;
+// EARLY: the check pass requests the LDS messages of all its checks before it computes the first one (the LDS accesses
+// are volatile, i.e. issued in program order: without this the read latency is exposed once per check)
+// UPRIOR: every bit has the same prior (uniform channel, no per-shot channel): it lives in a scalar register pair
+template <int CPT, int MPT, int MINW, bool EARLY, bool UPRIOR>
 __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocalParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n;
@@ -136,10 +130,16 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
     int* sh = reinterpret_cast<int*>(diffw + (MP / 32 + 2));
 
     // ---- per-thread graph tables
+    // Padding positions (no check, no bits) need no predicate anywhere in the iteration loop: the host wires the two
+    // "bits" of a padding position to that position's own four LDS slots, i.e. a closed toy graph of one check and two
+    // bits, three edges each, with a zero syndrome bit and a positive prior.  All its messages stay positive for ever
+    // (they grow; sums of positive numbers never produce a NaN), its bits never change their decision and its check
+    // never mismatches.  Only the stores that leave the workgroup (LLRs, results) test pos_bit >= 0.
     int alo[NB], ahi[NB], dl[NB];
     unsigned int dlpack = 0u;  // 2 bits per owned bit: its dl (needed per lane only in mixed groups)
-    bool bvalid[NB];
-    double l0[NB];
+    double l0[UPRIOR ? 1 : NB];
+    if (UPRIOR) l0[0] = P.llr0[0];
+#define BPL_L0(r) l0[UPRIOR ? 0 : (r)]
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int p = tid + j * NT;
@@ -147,9 +147,8 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
         for (int b = 0; b < 2; ++b) {
             const int r = 2 * j + b;
             const int bit = P.pos_bit[b * MP + p];
-            bvalid[r] = bit >= 0;
-            l0[r] = bvalid[r] ? P.llr0[bit] : 1.0;
-            alo[r] = P.pos_alo[b * MP + p];  // padding points at the dummy slot 4 * MP
+            if (!UPRIOR) l0[r] = bit >= 0 ? P.llr0[bit] : 1.0;  // (UPRIOR: the host has checked that the prior is > 0)
+            alo[r] = P.pos_alo[b * MP + p];
             ahi[r] = P.pos_ahi[b * MP + p];
             dl[r] = __builtin_amdgcn_readfirstlane(P.grp_dl[b * (MP >> 6) + (p >> 6)]);  // uniform per wave
             dlpack |= (unsigned int)P.pos_dl[b * MP + p] << (2 * r);
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                 if (bal) sh[0] = 1;
             }
         }
-        if (P.sel) {
+        if (!UPRIOR && P.sel) {
 #pragma unroll
             for (int j = 0; j < CPT; ++j)
 #pragma unroll
@@ -196,15 +195,15 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
         unsigned int decmask = 0u;  // bit r: hard decision of my r-th bit
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-            loc[r] = l0[r];
-            msg[alo[r]] = l0[r];
-            msg[ahi[r]] = l0[r];
+            loc[r] = BPL_L0(r);
+            msg[alo[r]] = BPL_L0(r);
+            msg[ahi[r]] = BPL_L0(r);
         }
         if (P.out_llr) {  // a syndrome that needs no iteration reports the priors
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 const int i = P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT];
-                if (i >= 0) llrt[i] = l0[r];
+                if (i >= 0) llrt[i] = BPL_L0(r);
             }
         }
         __syncthreads();
@@ -233,21 +232,22 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                 }
                 // =================== check -> bit pass (a4), speculative for it >= 2 ===========
                 const double alpha = alpha_for_iteration(P.ms_scaling, it);
+                const int alpha_lo = __double2loint(alpha), alpha_hi = __double2hiint(alpha), nalpha_hi = alpha_hi ^ (int)0x80000000;
+                double vl[EARLY ? CPT : 1][4];
+                if (EARLY) {
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) vl[j][k] = msg[(tid + j * NT) + k * MP];
+                }
 #pragma unroll
                 for (int j = 0; j < CPT; ++j) {
                     msg_ptr mc = msg + (tid + j * NT);
                     double v[6];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = mc[k * MP];
+                    for (int k = 0; k < 4; ++k) v[k] = EARLY ? vl[j][k] : mc[k * MP];
                     v[4] = loc[2 * j];
                     v[5] = loc[2 * j + 1];
-                    bool neg[6];
-                    bool par = sbit[j];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        neg[k] = (v[k] <= 0.0);
-                        par ^= neg[k];
-                    }
                     double pre[6], suf[6];
                     pre[0] = __DBL_MAX__;
 #pragma unroll
@@ -255,10 +255,21 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                     suf[5] = __DBL_MAX__;
 #pragma unroll
                     for (int k = 4; k >= 0; --k) suf[k] = min_abs(suf[k + 1], v[k + 1]);
+                    // signs: a message counts as negative when b2c <= 0 (a zero too, as in the reference); the outgoing
+                    // message is mag * ((-1)^(syndrome + #negatives + own) * alpha).  The sign rides on the multiplier:
+                    // one select of alpha's high word per edge (mag * (-alpha) == -(mag * alpha) bit for bit).
+                    bool neg[6];
+                    bool par = sbit[j];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        neg[k] = (v[k] <= 0.0);
+                        par ^= neg[k];
+                    }
 #pragma unroll
                     for (int k = 0; k < 6; ++k) {
                         const double mag = (k == 0) ? suf[0] : (k == 5 ? pre[5] : min_pos(pre[k], suf[k]));
-                        const double o = flip_sign(mag * alpha, par ^ neg[k]);
+                        const double sa = __hiloint2double((par ^ neg[k]) ? nalpha_hi : alpha_hi, alpha_lo);
+                        const double o = mag * sa;
                         if (k < 4) mc[k * MP] = o;
                         else loc[2 * j + (k - 4)] = o;
                     }
@@ -286,16 +297,19 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                         }
                     }
                     double oR, oX, oY, t;
-                    if (dl[r] == 0) bit_update<0>(l0[r], loc[r], X[r], Y[r], t, oR, oX, oY);
-                    else if (dl[r] == 1) bit_update<1>(l0[r], loc[r], X[r], Y[r], t, oR, oX, oY);
-                    else if (dl[r] == 2) bit_update<2>(l0[r], loc[r], X[r], Y[r], t, oR, oX, oY);
-                    else bit_update_mixed((int)((dlpack >> (2 * r)) & 3u), l0[r], loc[r], X[r], Y[r], t, oR, oX, oY);
-                    if (keep_llr && bvalid[r]) llrt[P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT]] = t;
+                    if (dl[r] == 0) bit_update<0>(BPL_L0(r), loc[r], X[r], Y[r], t, oR, oX, oY);
+                    else if (dl[r] == 1) bit_update<1>(BPL_L0(r), loc[r], X[r], Y[r], t, oR, oX, oY);
+                    else if (dl[r] == 2) bit_update<2>(BPL_L0(r), loc[r], X[r], Y[r], t, oR, oX, oY);
+                    else bit_update_mixed((int)((dlpack >> (2 * r)) & 3u), BPL_L0(r), loc[r], X[r], Y[r], t, oR, oX, oY);
+                    if (keep_llr) {
+                        const int bi = P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT];
+                        if (bi >= 0) llrt[bi] = t;
+                    }
                     loc[r] = oR;
                     msg[alo[r]] = oX;
                     msg[ahi[r]] = oY;
                     const unsigned int dnew = (t <= 0.0) ? 1u : 0u;
-                    if (bvalid[r] && dnew != ((decmask >> r) & 1u)) {
+                    if (dnew != ((decmask >> r) & 1u)) {  // (a padding bit never gets here: see the tables above)
                         decmask ^= 1u << r;
                         int pa = alo[r], pb = ahi[r];
                         asm volatile("" : "+v"(pa), "+v"(pb));  // keep the rare path's address arithmetic in the branch
@@ -342,5 +356,7 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
         __syncthreads();
     }
 }
+
+#undef BPL_L0
 
 }  // namespace bposd

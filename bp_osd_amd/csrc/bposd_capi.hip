@@ -43,7 +43,7 @@ struct DevBuf {
 // Per-call state.  A handle owns BPOSD_LANES of these and alternates between them: consecutive decode calls (and the
 // chunks of one host-pointer call) run on different HIP streams with their own workspaces, so the persistent
 // workgroups of call k + 1 pick up the CUs that call k's last max_iter stragglers and its OSD kernel leave idle.
-constexpr int BPOSD_LANES = 2;
+constexpr int BPOSD_LANES = 4;  // large codes (HBM-resident workspaces of several GB per lane) use two of them
 constexpr int BPOSD_MAX_CHUNKS = 8;  // chunks of one host-pointer call (bposd_decode_batch)
 
 struct Lane {
@@ -72,6 +72,7 @@ struct bposd_handle {
     int device = 0;
     Lane lanes[BPOSD_LANES];
     Lane* cur = nullptr;      // lane of the call being enqueued
+    int nlanes = BPOSD_LANES; // lanes this handle cycles through
     int next_lane = 0;
     CallRecord lane_rec[BPOSD_LANES];  // device-pointer calls: the record of the last call queued on each lane
     CallRecord rec[BPOSD_MAX_CHUNKS];  // host-pointer calls: one record per chunk
@@ -93,6 +94,8 @@ struct bposd_handle {
     int max_iter = 0;
     int rank = 0, kprime = 0, ncand = 0;
     bool probs_uniform = true;
+    bool priors_finite = true;  // no channel probability is exactly 0 or 1
+    bool alt_finite = true;     // the same for the alternative channel of the last select call
     int bp_variant = 0;
     // host copies
     std::vector<int> rp, ci;
@@ -216,6 +219,9 @@ int upload_priors(bposd_handle* h) {
     h->probs_uniform = true;
     for (int i = 1; i < h->n; ++i)
         if (h->probs[i] != h->probs[0]) { h->probs_uniform = false; break; }
+    h->priors_finite = true;
+    for (int i = 0; i < h->n; ++i)
+        if (!std::isfinite(l0[i])) h->priors_finite = false;
     // a11: weight(x) = sum over set bits of log(1/p_i) (ldpc v2).  For a uniform 0 < p < 1 every term is
     // the same positive number, so the sums order candidates exactly like Hamming weights (identical
     // partial sums, strictly increasing in the count) and the integer path is used.
@@ -796,7 +802,14 @@ int build_tables_local(bposd_handle* h) {
         }
         return -1;
     };
-    std::vector<int> pos_bit(2 * (size_t)MP, -1), pos_alo(2 * (size_t)MP, 4 * MP), pos_ahi(2 * (size_t)MP, 4 * MP), pos_dl(2 * (size_t)MP, 0);
+    // Padding positions (pos_chk < 0): the two "bits" of such a position are wired to the position's own four LDS slots
+    // (slot k * MP + p), a closed toy graph that needs no predicate in the kernel (bp_local_kernel.hip.h).
+    std::vector<int> pos_bit(2 * (size_t)MP, -1), pos_alo(2 * (size_t)MP, 0), pos_ahi(2 * (size_t)MP, 0), pos_dl(2 * (size_t)MP, 0);
+    for (int p = 0; p < MP; ++p)
+        for (int b = 0; b < 2; ++b) {
+            pos_alo[(size_t)b * MP + p] = (2 * b) * MP + p;
+            pos_ahi[(size_t)b * MP + p] = (2 * b + 1) * MP + p;
+        }
     for (int c = 0; c < m; ++c) {
         const int p = pos_of[c];
         for (int b = 0; b < 2; ++b) {
@@ -829,9 +842,9 @@ int build_tables_local(bposd_handle* h) {
     return 0;
 }
 
-template <int CPT, int MP, int MINW>
+template <int CPT, int MP, int MINW, bool EARLY, bool UPRIOR = false>
 int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
-    auto k = bp_local_kernel<CPT, MP, MINW>;
+    auto k = bp_local_kernel<CPT, MP, MINW, EARLY, UPRIOR>;
     const int nt = MP / CPT;
     const size_t lds = bp_local_lds_bytes(L.mp);
     HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -859,10 +872,18 @@ int launch_bp_local(bposd_handle* h, const BpParams& P) {
     L.grp_dl = h->d_lgrp_dl; L.pos_dl = h->d_lpos_dl;
     L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv; L.out_iters = P.out_iters;
     L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list; L.counters = P.counters; L.iter_total = P.iter_total;
-    if (h->local_mp == 2048) return launch_bp_local_t<2, 2048, 4>(h, L);  // 1024 threads, one workgroup per CU
-    if (h->bp_variant == 17) return launch_bp_local_t<2, 1024, 8>(h, L);   // 512 threads, <= 64 VGPRs: 4 workgroups per CU
-    if (h->bp_variant == 18) return launch_bp_local_t<1, 1024, 8>(h, L);   // 1024 threads, <= 64 VGPRs: 2 workgroups per CU
-    return launch_bp_local_t<2, 1024, 6>(h, L);                            // 512 threads, <= 80 VGPRs: 3 workgroups per CU
+    if (h->local_mp == 2048) return launch_bp_local_t<2, 2048, 4, false>(h, L);  // 1024 threads, one workgroup per CU
+    if (h->bp_variant == 17) return launch_bp_local_t<2, 1024, 8, false>(h, L);   // 512 threads, <= 64 VGPRs: 4 workgroups per CU
+    if (h->bp_variant == 18) return launch_bp_local_t<1, 1024, 8, false>(h, L);   // 1024 threads, <= 64 VGPRs: 2 workgroups per CU
+    if (h->bp_variant == 19) return launch_bp_local_t<4, 1024, 4, true>(h, L);    // 256 threads, <= 128 VGPRs: 4 workgroups per CU
+    if (h->bp_variant == 20) return launch_bp_local_t<2, 1024, 6, true>(h, L);    // as the default with early check-pass loads
+    if (h->bp_variant == 21) return launch_bp_local_t<4, 1024, 3, true>(h, L);    // 256 threads, <= 168 VGPRs: 3 workgroups per CU
+    // one finite positive prior for every bit: it can live in scalar registers (positive: the padding positions share it)
+    const bool uprior = h->probs_uniform && !L.sel && h->probs[0] > 0.0 && h->probs[0] < 0.5;
+    if ((h->bp_variant == 22 || h->bp_variant == 0) && uprior) return launch_bp_local_t<2, 1024, 8, false, true>(h, L);  // <= 64 VGPRs: 4 workgroups per CU
+    if (h->bp_variant == 23 && uprior) return launch_bp_local_t<2, 1024, 6, true, true>(h, L);
+    if (h->bp_variant == 24 && uprior) return launch_bp_local_t<2, 1024, 6, false, true>(h, L);
+    return launch_bp_local_t<2, 1024, 6, false>(h, L);                            // 512 threads, <= 80 VGPRs: 3 workgroups per CU
 }
 
 // ------------------------------------------------------------------------ large-code BP launch
@@ -1244,6 +1265,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     h->bp_hbm = !shp || bp_lds_bytes(pair.dc, shape_threads(h, shp) * shape_cpt(shp)) > h->lds_per_cu;
     h->large = (m > 1024) || (osd_words(n) == 0) || h->bp_hbm;
     if (h->large) {
+        h->nlanes = 2;
         if (n > 32767 || m > 16384 || (h->bp_hbm && bp_large_lds_bytes(m, n) > h->lds_per_cu)) {
             fail(nullptr, BPOSD_ERR_UNSUPPORTED, "code too large even for the HBM-resident kernels (m=%d n=%d; limits 16384 / 32767)", m, n);
             bposd_destroy(h);
@@ -1332,8 +1354,8 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && variant != 16 && variant != 17 && variant != 18)
-        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes) or 16, 17, 18 (local-edge kernel)");
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 24))
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes) or 16 .. 24 (local-edge kernel)");
     if (variant >= 16 && !(h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM))
         return fail(h, BPOSD_ERR_UNSUPPORTED, "the local-edge BP kernel needs a (3,6)-regular code with n = 2m and min-sum");
     h->bp_variant = variant;
@@ -1395,7 +1417,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     HIP_TRY(h, dev_guard.err);
     if (lane < 0) {
         lane = h->next_lane;
-        h->next_lane = (h->next_lane + 1) % BPOSD_LANES;
+        h->next_lane = (h->next_lane + 1) % h->nlanes;
         h->last_lane = lane;
         h->nrec = 0;
         h->currec = &h->lane_rec[lane];  // stream order on the lane: its previous call has filled the record by now
@@ -1533,6 +1555,9 @@ static int upload_alt_channel(bposd_handle* h, const double* alt) {
         l0[i] = std::log((1 - alt[i]) / alt[i]);
         cost[i] = std::log(1 / alt[i]);
     }
+    h->alt_finite = true;
+    for (int i = 0; i < h->n; ++i)
+        if (!std::isfinite(l0[i])) h->alt_finite = false;
     DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dev_guard.err);
     { int rcs = sync_all_lanes(h); if (rcs) return rcs; }  // earlier calls may still read the old tables
@@ -1597,7 +1622,7 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     int rc;
     for (int c = 0; c < nchunks; ++c) {
         const long long lo = (long long)c * CH, cnt = std::min<long long>(CH, B - lo);
-        const int lane = c % BPOSD_LANES;
+        const int lane = c % h->nlanes;
         Lane& L = h->lanes[lane];
         h->cur = &L;
         const size_t bn = (size_t)cnt * n, bm = (size_t)cnt * m;
@@ -1668,7 +1693,7 @@ int bposd_last_timing(bposd_handle* h, double* bp_ms, double* osd_ms, int64_t* b
     return record_timing(h, &h->lane_rec[h->last_lane], 1, bp_ms, osd_ms, bp_iterations, osd_invocations);
 }
 
-int bposd_num_lanes(void) { return BPOSD_LANES; }
+int bposd_num_lanes(bposd_handle* h) { return h ? h->nlanes : BPOSD_LANES; }
 
 int bposd_last_lane(bposd_handle* h) { return h ? h->last_lane : BPOSD_ERR_INVALID; }
 

@@ -1,0 +1,179 @@
+/*
+ * portable_math.h -- bit-reproducible fp64 tanh and log for the product-sum check update (row a5).
+ *
+ * The reference's product-sum pass calls the platform libm (`tanh(b2c / 2)`, `log((1 + x) / (1 - x))`, SURVEY.md
+ * Appendix A.3), whose last-bit behaviour differs between glibc versions, CPU architectures (FMA or not) and the
+ * device math library; belief propagation amplifies such last-bit differences until iteration counts and hard
+ * decisions change on a few percent of shots (tests/test_gpu_parity.py::test_config2_product_sum_cs60_vs_golden).
+ * The kernels therefore evaluate both functions with the routines below: only IEEE-754 correctly rounded +, -, *, /
+ * in a fixed order (build with -ffp-contract=off), integer bit manipulation and comparisons, so the GPU and any CPU
+ * compile of this file produce identical bits.  Algorithms: the classic table-free reductions
+ *   log:   x = 2^k (1 + f), sqrt(2)/2 <= 1 + f < sqrt(2);  s = f / (2 + f);  log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
+ *   expm1: x = k ln2 + r, |r| <= ln2 / 2;  expm1(r) from a rational approximation in r^2;  rescale by 2^k
+ *   tanh:  1 - 2 / (expm1(2|x|) + 2) for |x| >= 1,  -t / (t + 2) with t = expm1(-2|x|) below
+ * with the published minimax coefficients of those reductions; errors stay below 1 ulp (tests/test_portable_math.py
+ * measures them against libm).  Plain C99; usable from host C, host C++ and HIP device code.
+ */
+#ifndef BPOSD_PORTABLE_MATH_H
+#define BPOSD_PORTABLE_MATH_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define PM_FN __host__ __device__ static inline
+#else
+#define PM_FN static inline
+#endif
+
+PM_FN uint64_t pm_bits(double x) {
+    uint64_t u;
+    memcpy(&u, &x, sizeof(u));
+    return u;
+}
+PM_FN double pm_from_bits(uint64_t u) {
+    double x;
+    memcpy(&x, &u, sizeof(x));
+    return x;
+}
+
+/* natural logarithm */
+PM_FN double pm_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
+    const double ln2_lo = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                 L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                 L7 = 1.479819860511658591e-01;
+    uint64_t u = pm_bits(x);
+    int k = 0;
+    if (x != x) return x;                                  /* NaN */
+    if (u >> 63) {                                         /* negative (or -0) */
+        if ((u << 1) == 0) return -1.0 / 0.0;              /* log(-0) = -inf */
+        return (x - x) / 0.0;                              /* NaN */
+    }
+    if (u == 0) return -1.0 / 0.0;                         /* log(+0) = -inf */
+    if (u == 0x7ff0000000000000ull) return x;              /* +inf */
+    if (u < 0x0010000000000000ull) {                       /* subnormal: scale by 2^54 */
+        x *= 18014398509481984.0;
+        u = pm_bits(x);
+        k -= 54;
+    }
+    /* x = 2^e * m, m in [1, 2); fold m >= sqrt(2) into the next binade so that 1 + f lies in [sqrt(2)/2, sqrt(2)) */
+    k += (int)(u >> 52) - 1023;
+    u = (u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m = pm_from_bits(u);
+    if (m >= 1.4142135623730951) {
+        m *= 0.5;
+        k += 1;
+    }
+    const double f = m - 1.0;
+    const double dk = (double)k;
+    const double s = f / (2.0 + f);
+    const double s2 = s * s;
+    const double s4 = s2 * s2;
+    const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+/* exp(x) - 1 */
+PM_FN double pm_expm1(double x) {
+    const double o_threshold = 7.09782712893383973096e+02;
+    const double ln2x56 = 3.88162421113569373274e+01;
+    const double ln2halfx3 = 1.03972077083991796413e+00;
+    const double ln2half = 3.46573590279972654709e-01;
+    const double ln2_hi = 6.93147180369123816490e-01;
+    const double ln2_lo = 1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const double tiny = 5.5511151231257827e-17; /* 2^-54 */
+    const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03, Q3 = -7.93650757867487942473e-05,
+                 Q4 = 4.00821782732936239552e-06, Q5 = -2.01099218183624371326e-07;
+    if (x != x) return x;
+    double absx = x;
+    int sign = 0;
+    if (x < 0.0) {
+        absx = -absx;
+        sign = 1;
+    }
+    if (absx >= ln2x56) { /* |x| >= 56 ln2 */
+        if (sign) return -1.0;
+        if (absx >= o_threshold) return 1.0 / 0.0;
+    }
+    double c = 0.0;
+    int k = 0;
+    if (absx > ln2half) {
+        double hi, lo;
+        if (absx < ln2halfx3) {
+            if (!sign) {
+                hi = x - ln2_hi;
+                lo = ln2_lo;
+                k = 1;
+            } else {
+                hi = x + ln2_hi;
+                lo = -ln2_lo;
+                k = -1;
+            }
+        } else {
+            k = (int)(sign ? invln2 * x - 0.5 : invln2 * x + 0.5);
+            const double t = (double)k;
+            hi = x - t * ln2_hi; /* t * ln2_hi is exact here */
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+        c = (hi - x) - lo;
+    } else if (absx < tiny) {
+        return x;
+    }
+    /* x is now in the primary range */
+    const double hfx = 0.5 * x;
+    const double hxs = x * hfx;
+    const double r1 = 1.0 + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+    double t = 3.0 - r1 * hfx;
+    double e = hxs * ((r1 - t) / (6.0 - x * t));
+    if (k == 0) return x - (x * e - hxs);
+    e = x * (e - c) - c;
+    e -= hxs;
+    if (k == -1) return 0.5 * (x - e) - 0.5;
+    if (k == 1) {
+        if (x < -0.25) return -2.0 * (e - (x + 0.5));
+        return 1.0 + 2.0 * (x - e);
+    }
+    if (k <= -2 || k > 56) { /* suffices to return exp(x) - 1 */
+        double y = 1.0 - (e - x);
+        y = pm_from_bits(pm_bits(y) + ((uint64_t)(int64_t)k << 52)); /* add k to y's exponent */
+        return y - 1.0;
+    }
+    if (k < 20) {
+        t = pm_from_bits(0x3ff0000000000000ull - (0x0020000000000000ull >> k)); /* 1 - 2^-k */
+        double y = t - (e - x);
+        return pm_from_bits(pm_bits(y) + ((uint64_t)k << 52));
+    }
+    t = pm_from_bits((uint64_t)(0x3ff - k) << 52); /* 2^-k */
+    double y = x - (e + t);
+    y += 1.0;
+    return pm_from_bits(pm_bits(y) + ((uint64_t)k << 52));
+}
+
+/* hyperbolic tangent */
+PM_FN double pm_tanh(double x) {
+    if (x != x) return x;
+    const uint64_t u = pm_bits(x);
+    const uint64_t a = u & 0x7fffffffffffffffull;
+    const double ax = pm_from_bits(a);
+    double z;
+    if (a >= 0x7ff0000000000000ull) z = 1.0;      /* +-inf */
+    else if (ax >= 22.0) z = 1.0;                 /* 1 - tiny rounds to 1 */
+    else if (a < 0x3c80000000000000ull) return x; /* |x| < 2^-55 (also +-0) */
+    else if (ax >= 1.0) {
+        const double t = pm_expm1(2.0 * ax);
+        z = 1.0 - 2.0 / (t + 2.0);
+    } else {
+        const double t = pm_expm1(-2.0 * ax);
+        z = -t / (t + 2.0);
+    }
+    return (u >> 63) ? -z : z;
+}
+
+#endif /* BPOSD_PORTABLE_MATH_H */

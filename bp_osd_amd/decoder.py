@@ -301,7 +301,7 @@ class BpOsdDecoder:
     @property
     def num_lanes(self):
         """Streams the handle alternates between: consecutive ``decode_batch_device`` calls overlap on the device."""
-        return int(self._lib.bposd_num_lanes())
+        return int(self._lib.bposd_num_lanes(self._h))
 
     @property
     def last_lane(self):

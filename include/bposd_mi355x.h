@@ -141,16 +141,16 @@ int bposd_pack_rows_device(bposd_handle *h, const uint8_t *d_bytes, int64_t B, i
 int bposd_synchronize(bposd_handle *h);
 
 /*
- * Lanes.  A handle owns bposd_num_lanes() HIP streams with their own workspaces and uses them in turn: consecutive
+ * Lanes.  A handle owns bposd_num_lanes(h) HIP streams with their own workspaces and uses them in turn: consecutive
  * device-pointer calls (and the chunks of one host-pointer call) overlap on the device, so the next call's workgroups
  * take over the CUs that the previous call's last max_iter stragglers and its OSD kernel leave idle.  Consequences
  * for a caller of the asynchronous device-pointer API: two consecutive calls are NOT ordered against each other (give
- * them different output buffers, or synchronise in between); a call is ordered behind the call before the previous
- * one (same lane).  bposd_last_lane() names the lane of the last device-pointer call; bposd_synchronize_lane() waits
+ * them different output buffers, or synchronise in between); a call is ordered behind the call bposd_num_lanes(h)
+ * calls earlier (same lane).  bposd_last_lane() names the lane of the last device-pointer call; bposd_synchronize_lane() waits
  * for that lane only; bposd_lane_timing() is bposd_last_timing() for the last call queued on one lane.
  * (No counterpart in the reference: its decoder is a synchronous single-thread object.)
  */
-int bposd_num_lanes(void);
+int bposd_num_lanes(bposd_handle *h); /* lanes this handle cycles through (4; 2 for HBM-resident codes); NULL: the maximum */
 int bposd_last_lane(bposd_handle *h);
 int bposd_synchronize_lane(bposd_handle *h, int32_t lane);
 int bposd_lane_timing(bposd_handle *h, int32_t lane, double *bp_ms, double *osd_ms, int64_t *bp_iterations,

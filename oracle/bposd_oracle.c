@@ -13,6 +13,8 @@
  * so that it shares no algorithmic shortcut with the GPU kernels it checks.
  */
 #include "bposd_oracle.h"
+/* the one file shared with the product: the bit-reproducible tanh / log the GPU kernels evaluate (ps_math = 1) */
+#include "../bp_osd_amd/csrc/portable_math.h"
 
 #include <float.h>
 #include <math.h>
@@ -166,24 +168,26 @@ static void bp_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *converged,
     for (int it = 1; it <= d->max_iter; it++) {
         if (d->cfg.bp_method == 0) {
             /* a5 product-sum: forward/backward partial products of tanh(b2c/2) */
+            const int pm = d->cfg.ps_math == 1;
             for (int c = 0; c < m; c++) {
                 d->cand[c] = 0;
                 double temp = 1.0;
                 for (int e = d->rp[c]; e < d->rp[c + 1]; e++) {
                     d->c2b[e] = temp;
-                    temp *= tanh(d->b2c[e] / 2);
+                    temp *= pm ? pm_tanh(d->b2c[e] / 2) : tanh(d->b2c[e] / 2);
                 }
                 temp = 1;
                 for (int e = d->rp[c + 1] - 1; e >= d->rp[c]; e--) {
                     d->c2b[e] *= temp;
                     int message_sign = syn[c] ? -1 : 1;
-                    d->c2b[e] = message_sign * log((1 + d->c2b[e]) / (1 - d->c2b[e]));
+                    const double ratio = (1 + d->c2b[e]) / (1 - d->c2b[e]);
+                    d->c2b[e] = message_sign * (pm ? pm_log(ratio) : log(ratio));
                     if (d->cfg.ps_clip > 0) { /* build-owned switch; upstream does not clip (Appendix A.3 [M]) */
                         if (d->c2b[e] > d->cfg.ps_clip) d->c2b[e] = d->cfg.ps_clip;
                         if (d->c2b[e] < -d->cfg.ps_clip) d->c2b[e] = -d->cfg.ps_clip;
                     }
                     if (!d->diag_first_nonfinite && !isfinite(d->c2b[e])) d->diag_first_nonfinite = it;
-                    temp *= tanh(d->b2c[e] / 2);
+                    temp *= pm ? pm_tanh(d->b2c[e] / 2) : tanh(d->b2c[e] / 2);
                 }
             }
         } else {
@@ -481,6 +485,11 @@ int oracle_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *osdw, uint8_t 
         return 0;
     }
     return oracle_osd(d, syn, d->llr, osdw, osd0, NULL, NULL);
+}
+
+/* vectorised access to bp_osd_amd/csrc/portable_math.h for tests/test_portable_math.py: which = 0 tanh, 1 log, 2 expm1 */
+void oracle_portable_math(int32_t which, const double *x, double *y, int64_t count) {
+    for (int64_t i = 0; i < count; i++) y[i] = which == 0 ? pm_tanh(x[i]) : (which == 1 ? pm_log(x[i]) : pm_expm1(x[i]));
 }
 
 int oracle_decode_batch_diag(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,

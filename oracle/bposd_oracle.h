@@ -39,6 +39,10 @@ typedef struct {
     int32_t weight_fn;
     double ps_clip;           /* product-sum only: 0 = none (upstream: no clipping, messages reach +-inf and
                                  NaN); C > 0 = every check->bit message is clamped to [-C, C] (build-owned switch) */
+    int32_t ps_math;          /* product-sum only: 0 = tanh / log of the platform libm (what the reference calls);
+                                 1 = the bit-reproducible routines of bp_osd_amd/csrc/portable_math.h, which is what the
+                                 GPU kernels evaluate -- with 1 the oracle and the GPU agree bit for bit, with 0 they
+                                 differ by the libm's last-bit behaviour (tests state both bars) */
 } oracle_config;
 
 /* pcm as CSR with sorted column indices; channel_probs[n]. Returns 0 or <0. */
@@ -57,6 +61,9 @@ int oracle_decode(oracle_decoder *d, const uint8_t *syndrome, uint8_t *osdw, uin
 int oracle_decode_batch(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,
                         uint8_t *osd0, uint8_t *bp, uint8_t *converged, int32_t *iters,
                         double *llr);
+
+/* y[i] = f(x[i]) with f from bp_osd_amd/csrc/portable_math.h (which: 0 tanh, 1 log, 2 expm1); for the accuracy test. */
+void oracle_portable_math(int32_t which, const double *x, double *y, int64_t count);
 
 /* oracle_decode_batch plus per-shot BP diagnostics (see oracle_last_bp_diag); the three arrays are nullable. */
 int oracle_decode_batch_diag(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,

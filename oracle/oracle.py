@@ -28,14 +28,14 @@ class _Cfg(C.Structure):
         ("sort_tie_policy", C.c_int32),
         ("weight_fn", C.c_int32),
         ("ps_clip", C.c_double),
+        ("ps_math", C.c_int32),
     ]
 
 
 def build_oracle(force: bool = False) -> str:
     src = os.path.join(_HERE, "bposd_oracle.c")
-    stale = (not os.path.exists(_SO)) or (
-        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)
-    )
+    deps = [src, os.path.join(_HERE, "bposd_oracle.h"), os.path.join(_HERE, "..", "bp_osd_amd", "csrc", "portable_math.h")]
+    stale = (not os.path.exists(_SO)) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(_SO) for f in deps)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
     return _SO
@@ -67,10 +67,21 @@ _OSD = {"osd_off": 0, "off": 0, "osd_0": 1, "osd0": 1, "0": 1, "osd_e": 2, "e": 
         "osd_cs": 3, "cs": 3, "combination_sweep": 3}
 
 
+def portable_math(which, x):
+    """tanh / log / expm1 of bp_osd_amd/csrc/portable_math.h (compiled into the oracle library) on an array."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib = _load()
+    lib.oracle_portable_math.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.oracle_portable_math.restype = None
+    lib.oracle_portable_math({"tanh": 0, "log": 1, "expm1": 2}[which], x.ctypes.data, y.ctypes.data, x.size)
+    return y
+
+
 class OracleDecoder:
     def __init__(self, pcm, error_rate=None, channel_probs=None, max_iter=0, bp_method="ms",
                  ms_scaling_factor=1.0, osd_method="osd0", osd_order=0, sort_tie_policy=0, weight_fn=0,
-                 ps_clip=0.0):
+                 ps_clip=0.0, ps_math=0):
         lib = _load()
         h = sp.csr_matrix(pcm).astype(np.uint8)
         h.eliminate_zeros()
@@ -83,7 +94,7 @@ class OracleDecoder:
         self._indptr = np.ascontiguousarray(h.indptr, dtype=np.int32)
         self._indices = np.ascontiguousarray(h.indices, dtype=np.int32)
         cfg = _Cfg(_BP[str(bp_method).lower()], float(ms_scaling_factor), int(max_iter),
-                   _OSD[str(osd_method).lower()], int(osd_order), int(sort_tie_policy), int(weight_fn), float(ps_clip))
+                   _OSD[str(osd_method).lower()], int(osd_order), int(sort_tie_policy), int(weight_fn), float(ps_clip), int(ps_math))
         self._h = C.c_void_p()
         rc = lib.oracle_create(C.byref(cfg), self._indptr.ctypes.data, self._indices.ctypes.data,
                                self.m, self.n, probs.ctypes.data, C.byref(self._h))

@@ -1,6 +1,8 @@
 """Golden vectors for BASELINE configs[2] itself: H1922, product-sum BP, max_iter = n = 1922, osd_cs order 60, q = 0.05.
 
-Same provenance as make_golden.py (this repository's oracle; no reference code).  Two fixtures, 2048 seeded shots each:
+Same provenance as make_golden.py (this repository's oracle; no reference code).  Four fixtures, 2048 seeded shots each
+(the `_pm` pair is the same two runs with ps_math = 1, i.e. tanh / log from bp_osd_amd/csrc/portable_math.h -- the
+routines the GPU kernels evaluate -- instead of the platform libm; those two the GPU must reproduce bit for bit):
 
   ps_cs60_noclip.npz   ps_clip = 0  -- the reference formula (no clipping).  tanh rounds to 1
                                        within ~8 iterations, log((1+x)/(1-x)) = inf, inf - inf = NaN: every shot that
@@ -56,10 +58,13 @@ def main():
     rng = np.random.default_rng(SEED)
     err = (rng.random((B, H.shape[1])) < Q).astype(np.uint8)
     syn = np.ascontiguousarray((H @ err.T % 2).T.astype(np.uint8))
-    for name, clip in (("noclip", 0.0), ("clip20", 20.0)):
+    only = sys.argv[1:]
+    for name, clip, pm in (("noclip", 0.0, 0), ("clip20", 20.0, 0), ("noclip_pm", 0.0, 1), ("clip20_pm", 20.0, 1)):
+        if only and name not in only:
+            continue
         cfg = dict(error_rate=Q, max_iter=0, bp_method="ps", osd_method="osd_cs", osd_order=60, ps_clip=clip)
         t0 = time.time()
-        r = OracleDecoder(H, **cfg).decode_batch(syn, want_diag=True)
+        r = OracleDecoder(H, ps_math=pm, **cfg).decode_batch(syn, want_diag=True)
         gap, mabs = margins(r["llr"])
         print(name, "%.0fs" % (time.time() - t0), "converged %.4f" % r["converged"].mean(), "mean iters %.1f" % r["iters"].mean(),
               "non-finite shots", int((r["first_nonfinite_iter"] > 0).sum()), "final NaN", int(r["final_has_nan"].sum()),
@@ -68,7 +73,10 @@ def main():
                             osdw=pack(r["osdw"]), osd0=pack(r["osd0"]), bp=pack(r["bp"]), converged=r["converged"],
                             iters=r["iters"], first_nonfinite_iter=r["first_nonfinite_iter"],
                             final_has_inf=r["final_has_inf"], final_has_nan=r["final_has_nan"],
-                            min_gap=gap, min_abs=mabs)
+                            min_gap=gap, min_abs=mabs, ps_math=pm,
+                            # wrapping sum of the LLR bit patterns of every shot without NaN (NaN payloads are not portable)
+                            llr_checksum=np.where(np.isnan(r["llr"]).any(axis=1), np.uint64(0),
+                                                  np.ascontiguousarray(r["llr"]).view(np.uint64).sum(axis=1, dtype=np.uint64)))
 
 
 if __name__ == "__main__":

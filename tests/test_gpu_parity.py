@@ -250,7 +250,9 @@ def _ps_llr_mismatch_fraction(a, b):
 
 
 def test_product_sum_vs_oracle(gpu_ready, h1922):
-    """a5: device tanh/log differ from glibc by ulps -> tolerance parity, stated here: on shots that
+    """a5 against the oracle in its libm mode (what the reference calls): the kernels' portable tanh / log differ from
+    glibc's in the last bit on ~1 % of arguments -> tolerance parity, stated here (the bit-exact comparison against the
+    oracle's portable-math mode is test_product_sum_clip_vs_oracle_live / test_config2_...): on shots that
     converge in the same iteration on both sides (>= 98% of shots) the integer outputs are identical
     and LLRs agree to 1e-9 relative after clipping to +-30 on all but 1e-4 of entries; every output,
     converged or not, reproduces its syndrome; OSD outputs of non-converged shots are compared
@@ -561,6 +563,15 @@ def test_large_code_rank_deficient_osd(gpu_ready):
     assert g.rank == o.rank and g.rank < 3844
     r = _gpu_decode(g, syn)
     _compare_exact(r, o.decode_batch(syn))
+    # product-sum on the HBM-resident BP kernel (m > 2048), clipped and not: bit for bit against the portable-math oracle
+    for clip in (0.0, 12.0):
+        kw = dict(error_rate=0.06, max_iter=12, bp_method="ps", osd_method="osd_0", ps_clip=clip)
+        r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
+        ref = OracleDecoder(H, ps_math=1, **kw).decode_batch(syn)
+        assert (np.isnan(r["llr"]) == np.isnan(ref["llr"])).all()
+        nonan = ~np.isnan(ref["llr"]).any(axis=1)
+        _compare_exact({k: (v[nonan] if k == "llr" else v) for k, v in r.items()},
+                       {k: (v[nonan] if k == "llr" else v) for k, v in ref.items()})
 
 
 @pytest.mark.parametrize("name", ["e10", "cs3", "e15"])
@@ -634,10 +645,13 @@ def test_local_edge_kernel_equals_lds_kernel(gpu_ready, h1922, side):
     a = BpOsdDecoder(H, **kw)            # auto: local-edge kernel
     b = BpOsdDecoder(H, **kw)
     b.set_bp_variant(2)                  # LDS kernel, 512 threads
-    c = BpOsdDecoder(H, **kw)
-    c.set_bp_variant(18)                 # local-edge kernel, one check per thread
-    ra, rb, rc = _gpu_decode(a, syn), _gpu_decode(b, syn), _gpu_decode(c, syn)
-    for r in (rb, rc):
+    ra, rb = _gpu_decode(a, syn), _gpu_decode(b, syn)
+    others = [rb]
+    for variant in (17, 18, 19, 20, 21):  # the local-edge kernel's other shapes: 1 / 2 / 4 checks per thread, early loads
+        c = BpOsdDecoder(H, **kw)
+        c.set_bp_variant(variant)
+        others.append({k: (np.array(v, copy=True) if v is not None else None) for k, v in _gpu_decode(c, syn).items()})
+    for r in others:
         for k in ("osdw", "osd0", "bp", "converged", "iters"):
             assert (ra[k] == r[k]).all(), k
         assert (ra["llr"].view(np.uint64) == r["llr"].view(np.uint64)).all()
@@ -898,10 +912,17 @@ def _llr_margins(llr):
     return fin, gap, mabs
 
 
-@pytest.mark.parametrize("name", ["noclip", "clip20"])
+@pytest.mark.parametrize("name", ["noclip_pm", "clip20_pm", "noclip", "clip20"])
 def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
     """configs[2] at its stated settings against 2048 oracle shots frozen in tests/golden/ps_cs60_*.npz
-    (tests/golden/make_golden_ps.py).  Device tanh / log differ from glibc's by ulps, so the bar is SURVEY.md Appendix B
+    (tests/golden/make_golden_ps.py).
+
+    `*_pm` fixtures: the oracle evaluated tanh / log with bp_osd_amd/csrc/portable_math.h, the routines the kernels use.
+    Bar: EVERY shot identical -- converge flag, iteration count, bp / osd0 / osdw decodings, and the bit patterns of the
+    final LLRs of every shot without NaN.
+
+    Fixtures without the suffix: the oracle called the platform libm, as the reference does.  glibc's tanh / log differ
+    from portable_math.h in the last bit on ~1 % of arguments, and BP amplifies that, so the bar is SURVEY.md Appendix B
     item 5, written out here:
 
       * "clean" shots -- final LLRs finite on BOTH sides, smallest gap between distinct LLR values > 1e-9 and smallest
@@ -942,6 +963,16 @@ def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
     same = ((r["converged"] == ref["converged"]) & (r["iters"] == ref["iters"]) & (r["bp"] == ref["bp"]).all(axis=1) &
             (r["osd0"] == ref["osd0"]).all(axis=1) & (r["osdw"] == ref["osdw"]).all(axis=1))
     rest = ~(clean | allnan)
+    if name.endswith("_pm"):
+        assert int(g["ps_math"]) == 1
+        assert same.all(), f"{int((~same).sum())} of {B} shots differ from the portable-math oracle"
+        nonan = ~np.isnan(r["llr"]).any(axis=1)
+        assert (nonan == (g["final_has_nan"] == 0) | (g["iters"] == 0)).all()
+        got = np.ascontiguousarray(r["llr"][nonan]).view(np.uint64).sum(axis=1, dtype=np.uint64)
+        assert (got == g["llr_checksum"][nonan]).all(), "LLR bit patterns differ"
+        print(f"\n[configs[2] {name}] {B} shots identical to the oracle incl. LLR bits; converged {r['converged'].mean():.4f}, "
+              f"mean iterations {r['iters'].mean():.1f}, all-NaN shots {int(np.isnan(r['llr']).all(axis=1).sum())}")
+        return
     print(f"\n[configs[2] {name}] shots {B}: clean {int(clean.sum())} (identical {int((same & clean).sum())}), "
           f"all-NaN {int(allnan.sum())} (identical {int((same & allnan).sum())}), rest {int(rest.sum())} "
           f"(identical {int((same & rest).sum())}); oracle saturation: {int((g['first_nonfinite_iter'] > 0).sum())} shots, "
@@ -950,8 +981,10 @@ def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
     assert (same | ~clean).all(), f"{int((~same & clean).sum())} clean shots differ from the oracle"
     assert (same | ~allnan).all(), f"{int((~same & allnan).sum())} all-NaN shots differ from the oracle"
     if name == "clip20":
-        assert clean.mean() >= 0.99, clean.mean()        # with clipping nothing saturates: (almost) every shot is clean
-        assert (~same).mean() <= 0.002, (~same).mean()
+        # with clipping nothing saturates, but in this highly symmetric code most shots hold LLR pairs that are equal in
+        # exact arithmetic and differ in the last bits, so few shots are "clean"; last-bit libm differences move the
+        # iteration of convergence (or a near-tie of the final order) on ~10 % of the others (measured: 188 of 2048)
+        assert (~same).mean() <= 0.15, (~same).mean()
     else:
         assert (clean | allnan).mean() >= 0.55, (clean | allnan).mean()
         assert (~same & rest).mean() <= 0.05, (~same & rest).mean()   # ulp-level events among the saturated, converged shots
@@ -968,22 +1001,39 @@ def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
 
 
 def test_product_sum_clip_vs_oracle_live(gpu_ready, h1922, hgp400):
-    """ps_clip through the whole stack against the live oracle (LDS kernel on two codes, several clip values)."""
+    """Product-sum through the whole stack against the live oracle: bit for bit (LLR doubles included) when the oracle
+    evaluates tanh / log with portable_math.h like the kernels do (ps_math = 1), and within the libm's last-bit noise
+    when it calls the platform libm as the reference does (ps_math = 0).  Several clip values, clipping off, two codes."""
     from bp_osd_amd import BpOsdDecoder
     from oracle import OracleDecoder
 
     for H, q, B in ((h1922.hz, 0.05, 192), (hgp400.hx, 0.06, 256)):
         _, syn = _syndromes(H, q, B, 77)
-        for clip in (8.0, 20.0, 37.0):
+        for clip in (0.0, 8.0, 20.0, 37.0):
             kw = dict(error_rate=q, max_iter=40, bp_method="ps", osd_method="osd_cs", osd_order=10, ps_clip=clip)
             r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
-            ref = OracleDecoder(H, **kw).decode_batch(syn)
-            assert np.isfinite(r["llr"]).all() and np.isfinite(ref["llr"]).all()
-            same = (r["iters"] == ref["iters"]) & (r["converged"] == ref["converged"].astype(bool)) & \
-                   (r["osdw"] == ref["osdw"]).all(axis=1) & (r["osd0"] == ref["osd0"]).all(axis=1)
-            assert same.mean() >= 0.99, (clip, same.mean())
-            close = np.abs(r["llr"][same] - ref["llr"][same]) <= 1e-9 * (1 + np.abs(ref["llr"][same]))
-            assert close.mean() >= 1 - 1e-4
+            ref = OracleDecoder(H, ps_math=1, **kw).decode_batch(syn)
+            assert (np.isnan(r["llr"]) == np.isnan(ref["llr"])).all()
+            for k in ("converged", "iters", "bp"):  # BP itself: identical on every shot
+                assert (r[k] == ref[k]).all(), (k, clip)
+            # OSD on a vector that MIXES numbers and NaN (unclipped runs cut off at 40 iterations) has no defined order:
+            # the reference's comparator calls NaN equal to everything, so what its sort returns depends on the sort's
+            # internals.  Those shots must still reproduce their syndrome; every other shot is compared bit for bit.
+            mixed = np.isnan(ref["llr"]).any(axis=1) & ~np.isnan(ref["llr"]).all(axis=1)
+            assert clip == 0.0 or not mixed.any()
+            keep = ~mixed
+            nonan = keep & ~np.isnan(ref["llr"]).any(axis=1)
+            _compare_exact({k: (v[nonan] if k == "llr" else v[keep]) for k, v in r.items()},
+                           {k: (v[nonan] if k == "llr" else v[keep]) for k, v in ref.items()})
+            assert (_syndrome_of(H, r["osdw"]) == syn).all() and (_syndrome_of(H, r["osd0"]) == syn).all()
+            if clip > 0:
+                assert np.isfinite(r["llr"]).all()
+                lib = OracleDecoder(H, ps_math=0, **kw).decode_batch(syn)
+                same = (r["iters"] == lib["iters"]) & (r["converged"] == lib["converged"].astype(bool)) & \
+                       (r["osdw"] == lib["osdw"]).all(axis=1) & (r["osd0"] == lib["osd0"]).all(axis=1)
+                assert same.mean() >= 0.9, (clip, same.mean())
+                close = np.abs(r["llr"][same] - lib["llr"][same]) <= 1e-9 * (1 + np.abs(lib["llr"][same]))
+                assert close.mean() >= 0.99, close.mean()
     with pytest.raises(ValueError):
         BpOsdDecoder(h1922.hz, error_rate=0.05, bp_method="ps", ps_clip=-1.0)
 
@@ -1017,8 +1067,9 @@ def test_lanes_consecutive_device_calls_overlap_and_agree(gpu_ready, h1922):
         dec.decode_batch_device(s.data_ptr(), B, o["osdw"].data_ptr(), o["osd0"].data_ptr(), None, o["conv"].data_ptr(),
                                 o["iters"].data_ptr(), None)
         lanes.append(dec.last_lane)
-    assert lanes == [lanes[0], 1 - lanes[0]] * 2 + [lanes[0]]
-    # per-lane timing refers to the LAST call queued on that lane: calls 5 and 4
+    L = dec.num_lanes
+    assert lanes == [(lanes[0] + k) % L for k in range(5)] and len(set(lanes[:L])) == L
+    # per-lane timing refers to the LAST call queued on that lane
     t_a = dec.lane_timing(lanes[4])
     t_b = dec.lane_timing(lanes[3])
     dec.synchronize()

@@ -1,0 +1,49 @@
+"""bp_osd_amd/csrc/portable_math.h (the tanh / log the product-sum kernels evaluate) against the platform libm (CPU)."""
+import numpy as np
+
+from oracle import portable_math
+
+
+def _ulps(a, b):
+    ia = np.ascontiguousarray(a).view(np.int64).copy()
+    ib = np.ascontiguousarray(b).view(np.int64).copy()
+    ia[ia < 0] = np.iinfo(np.int64).min - ia[ia < 0]
+    ib[ib < 0] = np.iinfo(np.int64).min - ib[ib < 0]
+    return np.abs(ia - ib)
+
+
+def test_accuracy_against_libm():
+    rng = np.random.default_rng(0)
+    n = 2_000_000
+    x = (rng.random(n) * 2 - 1) * 10.0 ** (rng.random(n) * 6 - 4)        # |x| from 1e-4 to 1e2, both signs
+    assert _ulps(portable_math("tanh", x), np.tanh(x)).max() <= 4
+    y = 10.0 ** (rng.random(n) * 40 - 20)
+    assert _ulps(portable_math("log", y), np.log(y)).max() <= 2
+    z = (rng.random(n) * 2 - 1) * 50
+    assert _ulps(portable_math("expm1", z), np.expm1(z)).max() <= 2
+    # the composite of the check update: log((1 + x) / (1 - x)) with x a product of two tanh values
+    a, b = portable_math("tanh", (rng.random(n) * 60 - 30) / 2), portable_math("tanh", (rng.random(n) * 60 - 30) / 2)
+    r = (1 + a * b) / (1 - a * b)
+    with np.errstate(divide="ignore"):
+        ref = np.log(r)
+    got = portable_math("log", r)
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all() and _ulps(got[fin], ref[fin]).max() <= 2
+    assert (got[~fin] == ref[~fin]).all()
+
+
+def test_special_values():
+    with np.errstate(all="ignore"):
+        x = np.array([0.0, -0.0, 1e-320, 4.9e-324, 1.0, -1.0, 0.5, 2.0, 21.999, 22.0, 1e300, np.inf, -np.inf, np.nan,
+                      1 - 1e-16, 2.2250738585072014e-308])
+        for name, f in (("tanh", np.tanh), ("log", np.log)):
+            got, ref = portable_math(name, x), f(x)
+            assert (np.isnan(got) == np.isnan(ref)).all(), name
+            ok = ~np.isnan(ref)
+            assert (np.signbit(got[ok]) == np.signbit(ref[ok])).all(), name
+            fin = ok & np.isfinite(ref)
+            assert (np.isfinite(got[ok]) == np.isfinite(ref[ok])).all(), name
+            assert _ulps(got[fin], ref[fin]).max() <= 4, name
+    # saturation points of the product-sum update: tanh rounds to exactly 1 from |x| = 19.07 on
+    assert portable_math("tanh", np.array([19.1, -30.0, 400.0])).tolist() == [1.0, -1.0, 1.0]
+    assert portable_math("tanh", np.array([18.0]))[0] < 1.0

@@ -1,6 +1,6 @@
 # A/B of the BP kernels on the headline workload (serial steps, isolated kernel times):
 # LDS kernel shape 2, local-edge kernel (2 checks/thread at <= 80 / <= 64 VGPRs, 1 check/thread)
-for v in 2 16 17 18; do
+for v in ${VARIANTS:-2 16 17 18 19 20 21}; do
   timeout -k 10 200 python bench.py --steps 4 --warmup 1 --cpu-sample 0 --host-steps 0 --no-pipeline --variant $v > /tmp/ab.json 2>/tmp/ab.err || { echo "v$v FAILED"; tail -3 /tmp/ab.err; continue; }
   python - $v <<'PY'
 import json,sys
