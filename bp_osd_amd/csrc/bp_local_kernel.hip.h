@@ -219,7 +219,7 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
 #pragma unroll
                     for (int j = 0; j < CPT; ++j) {
                         const int p = tid + j * NT;
-                        mis |= ((diffw[p >> 5] >> (p & 31)) & 1u) != 0;
+                        mis |= ((diffw[p >> 5] >> (p & 31)) & 1u) != 0;  // (padding positions never raise their bits)
                     }
                     const unsigned long long anym = __ballot(mis);
                     if (lane == 0 && anym) sh[fi] = 1;

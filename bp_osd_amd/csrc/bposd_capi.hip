@@ -1000,12 +1000,16 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     Q.mrl = OSDL_NT * RPT;
     Q.synd = P.synd; Q.rp = P.rp; Q.ci = P.ci; Q.llr_ws = P.llr_ws; Q.osd_list = P.osd_list; Q.counters = P.counters;
     Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.rank_out = d_rank_out; Q.dbg = P.dbg;
+    // fp64 index-order candidate weights (non-uniform channel) -- only OSD-E / OSD-CS rank candidates
+    const bool fpw = P.cost != nullptr && Q.osd_method >= BPOSD_OSD_E && Q.osd_order > 0;
+    Q.cost = fpw ? P.cost : nullptr; Q.sel = fpw ? P.sel : nullptr; Q.cost_alt = P.cost_alt;
+    Q.wdn = std::max(64 * Q.W, 1 << OSDL_MAXSPAN);
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
     auto a256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // every sub-array is [grid][count], laid out back to back in one allocation
     const size_t g = (size_t)grid;
-    const size_t sizes[10] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
+    const size_t sizes[13] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
                              g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
                              g * sizeof(int) * (size_t)Q.nsort,                    // kidx
                              g * sizeof(int) * (size_t)h->n,                       // inv
@@ -1014,16 +1018,22 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
                              g * sizeof(int) * (size_t)64 * Q.W,                   // wt
                              g * (size_t)h->n,                                     // xout
                              g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.mrl,        // tmo
-                             g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.W * 64};    // pro
+                             g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.W * 64,     // pro
+                             fpw ? g * sizeof(double) * (size_t)h->n : 0,                    // costs_ws
+                             fpw ? g * sizeof(double) * (size_t)Q.wdn : 0,                   // wd_ws
+                             fpw ? g * sizeof(unsigned short) * (size_t)Q.mrl : 0};          // am_ws
     size_t total = 0;
     for (size_t b : sizes) total += a256(b);
     int rc = ensure(h, h->cur->osdl_ws, total);
     if (rc) return rc;
-    unsigned char* ptrs[10];
+    unsigned char* ptrs[13];
     {
         unsigned char* base = (unsigned char*)h->cur->osdl_ws.p;
-        for (int i = 0; i < 10; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
+        for (int i = 0; i < 13; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
     }
+    Q.costs_ws = (double*)ptrs[10];
+    Q.wd_ws = (double*)ptrs[11];
+    Q.am_ws = (unsigned short*)ptrs[12];
     Q.mat = (unsigned long long*)ptrs[0];
     Q.keys = (unsigned long long*)ptrs[1];
     Q.kidx = (int*)ptrs[2];
@@ -1034,7 +1044,7 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     Q.xout = (uint8_t*)ptrs[7];
     Q.tmo = (unsigned long long*)ptrs[8];
     Q.pro = (unsigned long long*)ptrs[9];
-    const size_t lds = osd_large_lds_bytes(Q.W, RPT);
+    const size_t lds = osd_large_lds_bytes(Q.W, RPT, fpw ? h->n : 0);
     if (lds > h->lds_per_cu) return fail(h, BPOSD_ERR_UNSUPPORTED, "large OSD kernel needs %zu bytes of LDS", lds);
 #define OSDL_LAUNCH(R)                                                                                      \
     case R: {                                                                                               \
@@ -1504,10 +1514,6 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             Q.dbg = h->cur->d_osd_dbg;
         }
         if (h->large) {
-            if (Q.cost && Q.osd_method >= BPOSD_OSD_E)
-                return fail(h, BPOSD_ERR_UNSUPPORTED,
-                            "the HBM-resident OSD kernel ranks candidates by Hamming weight only: a non-uniform channel with "
-                            "weight_fn=0 needs osd_0 or weight_fn=1 for codes beyond m=1024 / n=2047");
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
             if (Q.dbg) {
                 long long st[13];

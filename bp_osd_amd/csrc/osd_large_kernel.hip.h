@@ -25,7 +25,10 @@
 // column, so the reduced columns the sweep reads are final as soon as their word is stored.
 // Sort: bitonic network over a global key array (n up to 32767).  Sweep: per-wave ballots over the
 // finished words re-read from M; singles' weights accumulate in a global int array.
-// Limits: m <= 16384, n <= 32767, osd_cs / osd_e order <= 16, uniform channel (Hamming weights).
+// Non-uniform channel (P.cost != null: channel_probs vector, update_channel_probs, per-shot two-valued channel): candidate
+// weights are fp64 sums of log(1/p_i) over the candidate's set bits accumulated in ASCENDING ORIGINAL BIT INDEX -- the
+// reference's order -- one candidate per lane, exactly as in osd_kernel.hip.h; see the "fp64 weights" block of the sweep.
+// Limits: m <= 16384, n <= 32767, osd_cs / osd_e order <= 16.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,23 +71,35 @@ struct OsdLargeParams {
     uint8_t* __restrict__ xout;             // [grid][n]
     long long* __restrict__ dbg;            // nullable: phase clocks of list slot 0 (s_memtime ticks)
     int* __restrict__ rank_out;             // nullable: [0] = pivots found for list slot 0 (ctor-time rank probe)
+    // fp64 candidate weights (non-uniform channel); all null / unused when the channel is uniform
+    const double* __restrict__ cost;        // [n] log(1/p_i), nullable
+    const uint8_t* __restrict__ sel;        // [B, n] nullable: per-syndrome choice between cost and cost_alt
+    const double* __restrict__ cost_alt;    // [n]
+    double* __restrict__ costs_ws;          // [grid][n]   this syndrome's per-bit costs
+    double* __restrict__ wd_ws;             // [grid][wdn] weights of the single candidates / of the osd_e patterns
+    unsigned short* __restrict__ am_ws;     // [grid][mrl] per row: its entries in the first <= 16 non-pivot columns
+    int wdn;                                // max(64 * W, 2^16)
 };
 
-__host__ __device__ inline size_t osd_large_union_bytes(int W, int RPT) {
+constexpr int OSDL_MAXPAIRS = OSDL_MAXSPAN * (OSDL_MAXSPAN - 1) / 2;
+
+// n_fp: block length when fp64 candidate weights are needed (adds the per-bit info words of that path), else 0
+__host__ __device__ inline size_t osd_large_union_bytes(int W, int RPT, int n_fp = 0) {
     size_t e3 = (size_t)OSDL_NW * (OSDL_K - 1) * 256 * 8;   // wave-private tables of E3
     size_t ap = (size_t)OSDL_K * OSDL_G5 * OSDL_CW * 32 * 8;  // apply-pass tables (5-bit; covers E1's OSDL_K * 256 entries)
     size_t sw = (size_t)OSDL_MAXSPAN * RPT * OSDL_NW * 8 + (size_t)RPT * OSDL_NW * 8 + (size_t)W * 8 + 64 * 4;
+    if (n_fp > 0) sw += ((size_t)n_fp * 4 + 7) / 8 * 8 + (size_t)OSDL_MAXPAIRS * 8;
     size_t b = e3 > ap ? e3 : ap;
     return b > sw ? b : sw;
 }
 
-__host__ __device__ inline size_t osd_large_lds_bytes(int W, int RPT) {
+__host__ __device__ inline size_t osd_large_lds_bytes(int W, int RPT, int n_fp = 0) {
     size_t b = 0;
     b += (size_t)2 * OSDL_NW * 2 * 8;            // pbuf
     b += (size_t)2 * OSDL_NW * 4;                // pcol
     b += (size_t)OSDL_K * 64 * 4 + OSDL_K * 4;   // grow, gnp
     b += 2 * 8 + 16 * 4;                         // best64, misc
-    b += osd_large_union_bytes(W, RPT);
+    b += osd_large_union_bytes(W, RPT, n_fp);
     return b + 64;
 }
 
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
     unsigned char* p = smem;
     unsigned long long* pbuf = (unsigned long long*)p; p += (size_t)2 * OSDL_NW * 2 * 8;
     unsigned long long* best64 = (unsigned long long*)p; p += 2 * 8;
-    unsigned long long* U = (unsigned long long*)p; p += osd_large_union_bytes(W, RPT);  // phase-dependent (see header)
+    unsigned long long* U = (unsigned long long*)p; p += osd_large_union_bytes(W, RPT, P.cost ? n : 0);  // phase-dependent (see header)
     unsigned int* pcol = (unsigned int*)p; p += (size_t)2 * OSDL_NW * 4;
     int* grow = (int*)p; p += OSDL_K * 64 * 4;
     int* gnp = (int*)p; p += OSDL_K * 4;
@@ -178,6 +193,9 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         for (int i = tid; i < 64 * W; i += NT) { pivrow[i] = -1; wt[i] = 1; }
         for (int i = tid; i < MRL; i += NT) rowpos[i] = -1;
         for (int i = tid; i < n; i += NT) xout[i] = 0;
+        unsigned short* am = P.cost ? P.am_ws + (size_t)blockIdx.x * MRL : nullptr;
+        if (am)
+            for (int i = tid; i < MRL; i += NT) am[i] = 0;
         __syncthreads();
         for (int k = 2; k <= NS; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -625,6 +643,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         if (tcount < wspan) {
                             const unsigned long long cb = __ballot(usedk && bitv);
                             if (lane == 0) colvec[tcount * NCV + k * OSDL_NW + wave] = cb;
+                            if (am && usedk && bitv) am[tid + k * NT] |= (unsigned short)(1u << tcount);  // only the row's owner
                         }
                     }
                     if (lane == b) acc += cnt;
@@ -634,7 +653,119 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 if (P.osd_method == 3 && acc) atomicAdd(&wt[w * 64 + lane], acc);
             }
             __syncthreads();
-            if (P.osd_method == 3) {
+            if (P.cost) {
+                // ================= fp64 weights (non-uniform channel): sum of log(1/p_i) over the candidate's set bits in
+                // ascending ORIGINAL bit index, one candidate per lane (bit-identical to the CPU's sums, hence the same
+                // strict-< winner).  Per original bit i one LDS word: bits 0-15 its entries in the first wspan non-pivot
+                // columns (for a pivot bit: of its pivot row; for one of those columns itself: its own bit), bits 16-29
+                // its pivot row, bit 30 "is a pivot", bit 31 its OSD-0 value.
+                const int ntc = tcount < wspan ? tcount : wspan;
+                unsigned int* info = (unsigned int*)(tpos + 64);
+                double* pairw = (double*)(info + ((n + 1) & ~1));
+                double* costs = P.costs_ws + (size_t)blockIdx.x * n;
+                double* wd = P.wd_ws + (size_t)blockIdx.x * P.wdn;
+                OSDL_FRESH_TID();
+                for (int i = tid; i < n; i += NT) {
+                    double ci = P.cost[i];
+                    if (P.sel) {  // per-syndrome two-valued channel (css_decode_sim.py:207-248)
+                        const double ca = P.cost_alt[i];
+                        if (P.sel[(size_t)s * n + i] != 0) ci = ca;
+                    }
+                    costs[i] = ci;
+                    const int pos = inv[i];
+                    const int pr = pivrow[pos];
+                    unsigned int e = (unsigned int)xout[i] << 31;
+                    if (pr >= 0) e |= (1u << 30) | ((unsigned int)pr << 16) | am[pr];
+                    else
+                        for (int a = 0; a < ntc; ++a)
+                            if (tpos[a] == pos) e |= 1u << a;
+                    info[i] = e;
+                }
+                int* besti = misc + 2;
+                if (tid == 0) { besti[0] = 0x7fffffff; besti[1] = 0x7fffffff; }
+                __syncthreads();
+                double w0d = 0.0;  // weight of OSD-0 (every lane, uniform reads)
+                for (int i = 0; i < n; ++i)
+                    if (info[i] >> 31) w0d += costs[i];
+                if (P.osd_method == 3) {
+                    // ---- singles: lane c of the wave that owns word w evaluates the column at sorted position 64 w + c
+                    for (int w = wave; w < W; w += OSDL_NW) {
+                        const int j = w * 64 + lane;
+                        const int own = j < n ? kidx[j] : -1;  // the candidate's own (non-pivot) bit
+                        const unsigned long long* Mw = M + (size_t)w * MRL;
+                        double acc = 0.0;
+#pragma unroll 4
+                        for (int i = 0; i < n; ++i) {
+                            const unsigned int e = info[i];
+                            bool xi;
+                            if (e & (1u << 30)) {  // uniform: pivot bit, its row's word w is the same for the whole wave
+                                const unsigned long long word = Mw[(e >> 16) & 0x3fffu];
+                                xi = (((unsigned int)(word >> lane) ^ (e >> 31)) & 1u) != 0u;
+                            } else {
+                                xi = (i == own);
+                            }
+                            if (xi) acc += costs[i];
+                        }
+                        if (j < 64 * W) wd[j] = acc;
+                        if (j < n && pivrow[j] < 0) atomicMin(&best64[0], (unsigned long long)__double_as_longlong(acc));
+                    }
+                    // ---- pairs (a < b < wspan)
+                    const int npairs = ntc * (ntc - 1) / 2;
+                    for (int pidx = tid; pidx < npairs; pidx += NT) {
+                        int a = 0, rem = pidx;
+                        while (rem >= ntc - 1 - a) { rem -= ntc - 1 - a; ++a; }
+                        const unsigned int pat = (1u << a) | (1u << (a + 1 + rem));
+                        double acc = 0.0;
+                        for (int i = 0; i < n; ++i) {
+                            const unsigned int e = info[i];
+                            if (((e >> 31) ^ (unsigned int)__popc(e & pat)) & 1u) acc += costs[i];
+                        }
+                        pairw[pidx] = acc;
+                        atomicMin(&best64[1], (unsigned long long)__double_as_longlong(acc));
+                    }
+                    __syncthreads();
+                    const unsigned long long ms = best64[0], mp = best64[1];
+                    for (int j = tid; j < n; j += NT)
+                        if (pivrow[j] < 0 && (unsigned long long)__double_as_longlong(wd[j]) == ms) atomicMin(&besti[0], j);
+                    for (int pidx = tid; pidx < npairs; pidx += NT)
+                        if ((unsigned long long)__double_as_longlong(pairw[pidx]) == mp) atomicMin(&besti[1], pidx);
+                    __syncthreads();
+                    double best = w0d;
+                    if (ms != ~0ull && __longlong_as_double((long long)ms) < best) {
+                        best = __longlong_as_double((long long)ms);
+                        sel_a = besti[0];
+                        sel_b = -1;
+                    }
+                    if (mp != ~0ull && __longlong_as_double((long long)mp) < best) {
+                        best = __longlong_as_double((long long)mp);
+                        int pidx = besti[1], a = 0, rem = pidx;
+                        while (rem >= ntc - 1 - a) { rem -= ntc - 1 - a; ++a; }
+                        sel_a = tpos[a];
+                        sel_b = tpos[a + 1 + rem];
+                    }
+                } else {
+                    // ---- osd_e: patterns 1 .. 2^w - 1 on the first w non-pivot columns
+                    const unsigned int npat = (1u << ntc) - 1u;
+                    for (unsigned int pat = tid + 1; pat <= npat; pat += NT) {
+                        double acc = 0.0;
+                        for (int i = 0; i < n; ++i) {
+                            const unsigned int e = info[i];
+                            if (((e >> 31) ^ (unsigned int)__popc(e & pat)) & 1u) acc += costs[i];
+                        }
+                        wd[pat] = acc;
+                        atomicMin(&best64[0], (unsigned long long)__double_as_longlong(acc));
+                    }
+                    __syncthreads();
+                    const unsigned long long ms = best64[0];
+                    for (unsigned int pat = tid + 1; pat <= npat; pat += NT)
+                        if ((unsigned long long)__double_as_longlong(wd[pat]) == ms) atomicMin(&besti[0], (int)pat);
+                    __syncthreads();
+                    if (ms != ~0ull && __longlong_as_double((long long)ms) < w0d) {
+                        sel_a = -2;
+                        sel_b = besti[0];
+                    }
+                }
+            } else if (P.osd_method == 3) {
                 for (int j = tid; j < n; j += NT)
                     if (pivrow[j] < 0) atomicMin(&best64[0], ((unsigned long long)wt[j] << 32) | (unsigned)j);
                 const int npairs = wspan * (wspan - 1) / 2;

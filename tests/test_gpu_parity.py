@@ -606,7 +606,9 @@ def test_l29k_golden(gpu_ready, name):
 
 
 def test_large_code_limits_and_nonuniform_channel(gpu_ready, hgp4050):
-    """What the HBM-resident path refuses (loudly) and what it still does with a non-uniform channel."""
+    """The HBM-resident path with a non-uniform channel: candidate weights are fp64 sums of log(1/p_i) in ascending bit
+    index, as on the small path (a11) -- OSD-E and OSD-CS, a channel_probs vector, update_channel_probs, and the per-shot
+    two-valued channel the reference harness's default channel_update="x->z" produces (css_decode_sim.py:207-248)."""
     from bp_osd_amd import BpOsdDecoder
     from oracle import OracleDecoder
 
@@ -617,18 +619,32 @@ def test_large_code_limits_and_nonuniform_channel(gpu_ready, hgp4050):
     rng = np.random.default_rng(7)
     probs = rng.uniform(0.03, 0.09, n)
     _, syn = _syndromes(H, 0.07, 6, 31)
-    # OSD-0 needs no candidate weights: a per-bit channel is fine and exact (priors drive BP and the column order)
-    kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_0", osd_order=0)
+    for method, order in (("osd_0", 0), ("osd_e", 4), ("osd_e", 9), ("osd_cs", 2), ("osd_cs", 7), ("osd_cs", 16)):
+        for weight_fn in (0, 1):
+            kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method=method,
+                      osd_order=order, weight_fn=weight_fn)
+            g = BpOsdDecoder(H, **kw)
+            _compare_exact(_gpu_decode(g, syn), OracleDecoder(H, **kw).decode_batch(syn))
+    # update_channel_probs, then decode again with the same handle
+    kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=5)
+    g, o = BpOsdDecoder(H, **kw), OracleDecoder(H, **kw)
+    p2 = rng.uniform(0.02, 0.12, n)
+    g.update_channel_probs(p2)
+    o.update_channel_probs(p2)
+    _compare_exact(_gpu_decode(g, syn), o.decode_batch(syn))
+    # per-shot two-valued channel (prior_select): every shot has its own probabilities, BP priors and OSD weights alike
+    sel = (rng.random((len(syn), n)) < 0.2).astype(np.uint8)
+    alt = np.full(n, 0.21)
+    base = np.full(n, 0.04)
+    kw = dict(channel_probs=base, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=2)
     g = BpOsdDecoder(H, **kw)
-    _compare_exact(_gpu_decode(g, syn), OracleDecoder(H, **kw).decode_batch(syn))
-    # OSD-E with fp64 index-order weights is not built for this path: refused at decode time, never approximated
-    g = BpOsdDecoder(H, channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=4)
-    with pytest.raises(ValueError):
-        g.decode_batch(syn)
-    # ... unless the caller asks for Hamming weights, which is what this path computes
-    kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=4, weight_fn=1)
-    g = BpOsdDecoder(H, **kw)
-    _compare_exact(_gpu_decode(g, syn), OracleDecoder(H, **kw).decode_batch(syn))
+    got = g.decode_batch(syn, prior_select=sel, alt_channel_probs=alt, want_llr=True)
+    o = OracleDecoder(H, **kw)
+    for b in range(len(syn)):
+        o.update_channel_probs(np.where(sel[b] != 0, alt, base))
+        r = o.decode(syn[b])
+        assert (got[b] == r["osdw"]).all() and (g.batch_osd0[b] == r["osd0"]).all(), b
+        assert (g.batch_llr[b].view(np.uint64) == r["llr"].view(np.uint64)).all(), b
 
 
 @pytest.mark.parametrize("side", ["hz", "hx"])
