@@ -1009,7 +1009,7 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     auto a256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // every sub-array is [grid][count], laid out back to back in one allocation
     const size_t g = (size_t)grid;
-    const size_t sizes[13] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
+    const size_t sizes[14] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
                              g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
                              g * sizeof(int) * (size_t)Q.nsort,                    // kidx
                              g * sizeof(int) * (size_t)h->n,                       // inv
@@ -1021,16 +1021,18 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
                              g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.W * 64,     // pro
                              fpw ? g * sizeof(double) * (size_t)h->n : 0,                    // costs_ws
                              fpw ? g * sizeof(double) * (size_t)Q.wdn : 0,                   // wd_ws
-                             fpw ? g * sizeof(unsigned short) * (size_t)Q.mrl : 0};          // am_ws
+                             fpw ? g * sizeof(unsigned short) * (size_t)Q.mrl : 0,           // am_ws
+                             g * sizeof(int) * (size_t)Q.mrl};                               // alist
     size_t total = 0;
     for (size_t b : sizes) total += a256(b);
     int rc = ensure(h, h->cur->osdl_ws, total);
     if (rc) return rc;
-    unsigned char* ptrs[13];
+    unsigned char* ptrs[14];
     {
         unsigned char* base = (unsigned char*)h->cur->osdl_ws.p;
-        for (int i = 0; i < 13; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
+        for (int i = 0; i < 14; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
     }
+    Q.alist = (int*)ptrs[13];
     Q.costs_ws = (double*)ptrs[10];
     Q.wd_ws = (double*)ptrs[11];
     Q.am_ws = (unsigned short*)ptrs[12];

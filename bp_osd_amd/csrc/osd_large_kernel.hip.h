@@ -21,6 +21,14 @@
 //       private table, no block barriers);
 //   AP  when OSDL_K groups are open, ONE pass over the remaining matrix applies all of them
 //       (tables for OSDL_CW words at a time) -> HBM traffic / OSDL_K (+ the masks re-read per chunk).
+// OSD-0 / OSD-E need only wspan + 1 reduced columns (the first wspan non-pivot columns and the syndrome), so for them
+// the elimination is GAUSSIAN with a back-substitution at the end instead of Gauss-Jordan ("gauss" below): a pivot row
+// is FROZEN by the first apply pass after it became a pivot (that pass still brings it up to date with every open group,
+// so the stored row is a complete linear combination); E1, the panel phase and all later apply passes leave frozen rows
+// alone.  The apply pass walks a compacted list of the rows that are not frozen, so its work shrinks with the number of
+// unused rows -- on average half the row updates of Gauss-Jordan -- and the wspan + 1 columns are then solved against
+// the (partly reduced) pivot rows from the last pivot word to the first.
+// OSD-CS weighs all k' single candidates, i.e. needs every non-pivot column reduced: it keeps Gauss-Jordan.
 // Earlier words never change: a row that becomes a pivot later has zeros in every earlier non-pivot
 // column, so the reduced columns the sweep reads are final as soon as their word is stored.
 // Sort: bitonic network over a global key array (n up to 32767).  Sweep: per-wave ballots over the
@@ -68,6 +76,7 @@ struct OsdLargeParams {
     int* __restrict__ wt;                   // [grid][64 * W]  weights of the single candidates
     unsigned long long* __restrict__ tmo;   // [grid][OSDL_K * mrl]     masks of the open groups
     unsigned long long* __restrict__ pro;   // [grid][OSDL_K * W * 64]  pivot rows of the open groups, [g][word][q]
+    int* __restrict__ alist;                // [grid][mrl]     rows the apply pass still updates (compacted, ascending)
     uint8_t* __restrict__ xout;             // [grid][n]
     long long* __restrict__ dbg;            // nullable: phase clocks of list slot 0 (s_memtime ticks)
     int* __restrict__ rank_out;             // nullable: [0] = pivots found for list slot 0 (ctor-time rank probe)
@@ -88,7 +97,11 @@ __host__ __device__ inline size_t osd_large_union_bytes(int W, int RPT, int n_fp
     size_t e3 = (size_t)OSDL_NW * (OSDL_K - 1) * 256 * 8;   // wave-private tables of E3
     size_t ap = (size_t)OSDL_K * OSDL_G5 * OSDL_CW * 32 * 8;  // apply-pass tables (5-bit; covers E1's OSDL_K * 256 entries)
     size_t sw = (size_t)OSDL_MAXSPAN * RPT * OSDL_NW * 8 + (size_t)RPT * OSDL_NW * 8 + (size_t)W * 8 + 64 * 4;
-    if (n_fp > 0) sw += ((size_t)n_fp * 4 + 7) / 8 * 8 + (size_t)OSDL_MAXPAIRS * 8;
+    // region R behind them: the wspan + 1 solution vectors of the back-substitution, later the per-bit info words of the
+    // fp64-weight path
+    const size_t zb = (size_t)(OSDL_MAXSPAN + 1) * (W + 1) * 8;
+    const size_t fb = n_fp > 0 ? ((size_t)n_fp * 4 + 7) / 8 * 8 + (size_t)OSDL_MAXPAIRS * 8 : 0;
+    sw += zb > fb ? zb : fb;
     size_t b = e3 > ap ? e3 : ap;
     return b > sw ? b : sw;
 }
@@ -141,6 +154,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
     unsigned long long* yvec = colvec + (size_t)OSDL_MAXSPAN * NCV;
     unsigned long long* npmask = yvec + NCV;
     int* tpos = (int*)(npmask + W);
+    unsigned long long* R = (unsigned long long*)(tpos + 64);  // back-substitution vectors, then fp64-weight info words
 
     unsigned long long* M = P.mat + (size_t)blockIdx.x * W * MRL;
     unsigned long long* keys = P.keys + (size_t)blockIdx.x * NS;
@@ -152,6 +166,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
     uint8_t* xout = P.xout + (size_t)blockIdx.x * n;
     unsigned long long* TmO = P.tmo + (size_t)blockIdx.x * OSDL_K * MRL;
     unsigned long long* PRO = P.pro + (size_t)blockIdx.x * OSDL_K * W * 64;
+    int* alist = P.alist + (size_t)blockIdx.x * MRL;
 
     for (;;) {
         OSDL_FRESH_TID();
@@ -246,6 +261,13 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         OSDL_TICK(1);
         // ------------------------------------------------------- a9: blocked Gauss-Jordan, lazy groups
         unsigned int usedmask = 0u;  // bit k: my k-th row is a pivot row
+        const bool gauss = P.osd_method != 3;  // OSD-0 / OSD-E: Gaussian elimination + back-substitution (see header)
+        unsigned int frozenmask = 0u;  // bit k: my k-th row takes no more updates (padding row, or a pivot row that an
+                                       // apply pass has brought up to date -- gauss mode only)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if ((int)threadIdx.x + k * NT >= m) frozenmask |= 1u << k;
+        const unsigned int padmask = frozenmask;
         int nrank = 0;
         int par = 0;
         int ng = 0;                  // open groups
@@ -254,14 +276,42 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 
         // AP: apply the ng open groups to words [xlo, W) of every row
         auto apply_open = [&](int xlo) {
-            for (int x0 = xlo; x0 < W; x0 += OSDL_CW) {
+            // ---- the rows this pass updates: everything that is not frozen, compacted in ascending row order
+            __syncthreads();  // U is free (the tables of the previous phase are no longer read)
+            int* cnt = (int*)U;  // [RPT * NW + 1]
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const unsigned long long bal = __ballot(((frozenmask >> k) & 1u) == 0u);
+                if (lane == 0) cnt[k * OSDL_NW + wave] = __popcll(bal);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int run = 0;
+                for (int i = 0; i < RPT * OSDL_NW; ++i) {
+                    const int c = cnt[i];
+                    cnt[i] = run;
+                    run += c;
+                }
+                cnt[RPT * OSDL_NW] = run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const bool act = ((frozenmask >> k) & 1u) == 0u;
+                const unsigned long long bal = __ballot(act);
+                if (act) alist[cnt[k * OSDL_NW + wave] + __popcll(bal & ((1ull << lane) - 1ull))] = (int)threadIdx.x + k * NT;
+            }
+            const int nact = cnt[RPT * OSDL_NW];
+            const int nk = (nact + NT - 1) / NT;  // list entries per thread (the last round may be partial)
+            __syncthreads();
+            for (int x0 = xlo; x0 < W && nact > 0; x0 += OSDL_CW) {
                 OSDL_FRESH_TID();
                 const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
                 __syncthreads();  // the previous tables are no longer read
                 OSDL_TICK(5);
 #ifdef BPOSD_OSD_DIAG
-                for (int g = 0; g < ng; ++g) OSDL_ADD(10, (long long)RPT * cw * ((gnp[g] + 4) / 5 > 8 ? 13 : ((gnp[g] + 4) / 5 > 4 ? 8 : 4)));
-                OSDL_ADD(11, (long long)RPT * cw);
+                for (int g = 0; g < ng; ++g) OSDL_ADD(10, (long long)nk * cw * ((gnp[g] + 4) / 5 > 8 ? 13 : ((gnp[g] + 4) / 5 > 4 ? 8 : 4)));
+                OSDL_ADD(11, (long long)nk * cw);
 #endif
                 // 32-entry tables, one per 5 pivots (a 256-byte table is as fast to look up as a 128-byte one --
                 // tools/microbench/lds_probe -- and needs 13 instead of 16 look-ups per 64 pivots).  One thread
@@ -303,8 +353,12 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 // the look-ups of row k start (one wave keeps 2 x 4.5 KB in flight), otherwise the pass is bound by
                 // the latency of its own global loads rather than by the LDS.
                 unsigned long long vn[OSDL_CW], mkn[OSDL_K];
+                // list entry of round k: position tid + k * NT; lanes beyond the list's end work on its first row and
+                // do not store
+                int rown = alist[tid < nact ? tid : 0];
+                int rown2 = alist[tid + NT < nact ? tid + NT : 0];
                 {
-                    const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
+                    const unsigned int ro = osdl_opaque((unsigned int)rown * 8u);
 #pragma unroll
                     for (int xx = 0; xx < OSDL_CW; ++xx)
                         vn[xx] = (xx < cw) ? OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) : 0ull;
@@ -312,18 +366,20 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     for (int g = 0; g < OSDL_K; ++g)
                         mkn[g] = (g < ng) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro) : 0ull;
                 }
-                // rows >= m are padding (all-zero rows with zero masks): a wave whose rows are all padding skips them
-                const int kmax = (m - (int)(threadIdx.x & ~63u) + NT - 1) / NT;  // wave-uniform: rows tid + k * NT < m for some lane
 #pragma clang loop unroll(disable)
-                for (int k = 0; k < RPT && k < kmax; ++k) {
-                    const unsigned int ro = osdl_opaque((unsigned int)(tid + k * NT) * 8u);
+                for (int k = 0; k < nk; ++k) {
+                    const bool live = tid + k * NT < nact;
+                    const unsigned int ro = osdl_opaque((unsigned int)rown * 8u);
                     unsigned long long v[OSDL_CW], mks[OSDL_K];
 #pragma unroll
                     for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] = vn[xx];
 #pragma unroll
                     for (int g = 0; g < OSDL_K; ++g) mks[g] = mkn[g];
-                    if (k + 1 < RPT && k + 1 < kmax) {
-                        const unsigned int rn = ro + NT * 8;
+                    if (k + 1 < nk) {
+                        rown = rown2;
+                        const int p2 = tid + (k + 2) * NT;
+                        rown2 = alist[p2 < nact ? p2 : 0];
+                        const unsigned int rn = osdl_opaque((unsigned int)rown * 8u);
 #pragma unroll
                         for (int xx = 0; xx < OSDL_CW; ++xx)
                             vn[xx] = (xx < cw) ? OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, rn) : 0ull;
@@ -364,11 +420,12 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     }
 #pragma unroll
                     for (int xx = 0; xx < OSDL_CW; ++xx)
-                        if (xx < cw) OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) = v[xx];
+                        if (xx < cw && live) OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) = v[xx];
                 }
             }
             __syncthreads();
             ng = 0;
+            if (gauss) frozenmask = padmask | usedmask;  // no group is open now: every pivot row found so far is complete
         };
 
 #pragma clang loop unroll(disable)
@@ -379,7 +436,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             {
                 const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) { pw[k] = OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8); t[k] = 0ull; }
+                for (int k = 0; k < RPT; ++k) {
+                    pw[k] = ((frozenmask >> k) & 1u) ? 0ull : OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8);
+                    t[k] = 0ull;
+                }
             }
             // ---------------- E1: bring word w up to date with the open groups
             if (ng > 0) {
@@ -403,7 +463,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
                         for (int k = 0; k < RPT; ++k) {
-                            const unsigned long long mk = OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + k * NT * 8);
+                            // (a frozen row's mask slots are stale: treat them as empty)
+                            const unsigned long long mk = ((frozenmask >> k) & 1u) ? 0ull : OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + k * NT * 8);
                             for (int grp = 0; grp < ngrp; ++grp)
                                 pw[k] ^= U[(g * 16 + grp) * 16 + (int)((mk >> (4 * grp)) & 15ull)];
                         }
@@ -436,7 +497,6 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     const unsigned long long z = __ballot(((lb >> bitp) & 1) == 0) & act;
                     if (z) act = z; else col |= (1 << bitp);
                 }
-                const int first = __ffsll((long long)act) - 1;
                 // the proposing lane's row: any unused row of its with a one in column lb (the pivot set does not
                 // depend on which row is taken)
                 int kb = 0;
@@ -445,6 +505,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     const bool hit = (((pw[k] >> (lb & 63)) & 1ull) != 0ull) && (((usedmask >> k) & 1u) == 0u);
                     kb = hit ? k : kb;
                 }
+                const int first = __ffsll((long long)act) - 1;
                 if (lane == first) {
                     unsigned long long a = 0ull, c = 0ull;
 #pragma unroll
@@ -493,7 +554,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             {
                 const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8) = pw[k];
+                for (int k = 0; k < RPT; ++k)
+                    if (((frozenmask >> k) & 1u) == 0u) OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8) = pw[k];
             }
             OSDL_TICK(3);
             OSDL_COUNT(7);
@@ -502,7 +564,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 {
                     const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-                    for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = t[k];
+                    for (int k = 0; k < RPT; ++k)
+                        if (((frozenmask >> k) & 1u) == 0u) OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = t[k];
                 }
                 if (tid == 0) gnp[ng] = npiv;
                 __syncthreads();  // grow / gnp / TmO of the new group are visible
@@ -591,21 +654,96 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 
         OSDL_FRESH_TID();
         // --------------------------------------------------------------- OSD-0 solution
-        bool y[RPT];
-        const unsigned int ro_y = osdl_opaque((unsigned int)tid * 8u);
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            y[k] = ((OSDL_AT(unsigned long long, M + (size_t)(W - 1) * MRL, ro_y + k * NT * 8) >> 63) & 1ull) != 0ull;
-            const bool usedk = (usedmask >> k) & 1u;
-            const unsigned long long yb = __ballot(usedk && y[k]);
-            if (lane == 0) yvec[k * OSDL_NW + wave] = yb;
-            if (usedk && y[k]) xout[kidx[rowpos[tid + k * NT]]] = 1;
-        }
         if (tid == 0) { best64[0] = ~0ull; best64[1] = ~0ull; }
         for (int w = wave; w < W; w += OSDL_NW) {
             const int j = w * 64 + lane;
             const unsigned long long np = __ballot(j < n && pivrow[j] < 0);
             if (lane == 0) npmask[w] = np;
+        }
+        __syncthreads();
+        bool y[RPT];
+        int ntc_g = 0;  // gauss mode: reduced non-pivot columns available in colvec
+        if (gauss) {
+            // ---- back-substitution.  Right-hand sides: the first wspan non-pivot columns (unit vectors e_t) and the
+            // syndrome column (index MAXSPAN); z_c holds, per sorted column position, the solution found so far plus the
+            // right-hand side's own bit.  A pivot row p (pivot column c_p) is e_{c_p} + entries to the right of c_p (it is
+            // zero in every earlier column and in the other pivot columns of its own panel), so x_c[c_p] = <row_p, z_c>.
+            // Pivot words are solved from the last to the first; the <= 64 pivots of a word are independent.
+            const int wspan_g = (P.osd_method >= 2 && P.osd_order > 0) ? (P.osd_order < OSDL_MAXSPAN ? P.osd_order : OSDL_MAXSPAN) : 0;
+            if (tid == 0) {
+                int a = 0;
+                for (int w = 0; w < W && a < wspan_g; ++w) {
+                    unsigned long long npm = npmask[w];
+                    while (npm && a < wspan_g) {
+                        tpos[a++] = w * 64 + (__ffsll((long long)npm) - 1);
+                        npm &= npm - 1;
+                    }
+                }
+                misc[1] = a;
+            }
+            constexpr int NR = OSDL_MAXSPAN + 1;
+            unsigned long long* zv = R;            // [NR][W]
+            unsigned long long* resw = zv + (size_t)NR * W;  // [NR]
+            for (int i = tid; i < NR * W; i += NT) zv[i] = 0ull;
+            if (tid < NR) resw[tid] = 0ull;
+            __syncthreads();
+            ntc_g = misc[1];
+            if (tid < ntc_g) zv[(size_t)tid * W + (tpos[tid] >> 6)] = 1ull << (tpos[tid] & 63);
+            if (tid == 0) zv[(size_t)OSDL_MAXSPAN * W + (W - 1)] = 1ull << 63;
+            __syncthreads();
+#pragma clang loop unroll(disable)
+            for (int w = wlast; w >= 0; --w) {
+                const int prow = pivrow[w * 64 + lane];  // lane q: the pivot at sorted position 64 w + q, if any
+                unsigned long long acc[NR];
+#pragma unroll
+                for (int c = 0; c < NR; ++c) acc[c] = 0ull;
+                if (prow >= 0) {
+                    for (int x = w + wave; x < W; x += OSDL_NW) {  // the 16 waves split the words to the right
+                        const unsigned long long v = M[(size_t)x * MRL + prow];
+#pragma unroll
+                        for (int c = 0; c < NR; ++c) acc[c] ^= v & zv[(size_t)c * W + x];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    if (c < ntc_g || c == OSDL_MAXSPAN) {  // uniform
+                        const unsigned long long bits = __ballot(prow >= 0 && (__popcll(acc[c]) & 1));
+                        if (lane == 0 && bits) atomicXor(&resw[c], bits);
+                    }
+                }
+                __syncthreads();
+                if (tid < NR) {
+                    zv[(size_t)tid * W + w] ^= resw[tid];
+                    resw[tid] = 0ull;
+                }
+                __syncthreads();
+            }
+            // reduced columns and reduced syndrome as bit vectors over the pivot ROWS (the layout the sweep below uses)
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const bool usedk = (usedmask >> k) & 1u;
+                const int r = tid + k * NT;
+                const int j = usedk ? rowpos[r] : 0;
+                for (int a = 0; a < ntc_g; ++a) {
+                    const bool bit = usedk && ((zv[(size_t)a * W + (j >> 6)] >> (j & 63)) & 1ull);
+                    const unsigned long long cb = __ballot(bit);
+                    if (lane == 0) colvec[a * NCV + k * OSDL_NW + wave] = cb;
+                    if (am && bit) am[r] |= (unsigned short)(1u << a);
+                }
+                y[k] = usedk && ((zv[(size_t)OSDL_MAXSPAN * W + (j >> 6)] >> (j & 63)) & 1ull);
+            }
+        } else {
+            const unsigned int ro_y = osdl_opaque((unsigned int)tid * 8u);
+#pragma unroll
+            for (int k = 0; k < RPT; ++k)
+                y[k] = ((OSDL_AT(unsigned long long, M + (size_t)(W - 1) * MRL, ro_y + k * NT * 8) >> 63) & 1ull) != 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const bool usedk = (usedmask >> k) & 1u;
+            const unsigned long long yb = __ballot(usedk && y[k]);
+            if (lane == 0) yvec[k * OSDL_NW + wave] = yb;
+            if (usedk && y[k]) xout[kidx[rowpos[tid + k * NT]]] = 1;
         }
         __syncthreads();
         if (P.out_osd0)
@@ -616,9 +754,9 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         int sel_a = -1, sel_b = -1;
         if (P.osd_method >= 2 && P.osd_order > 0) {
             const int wspan = P.osd_order < OSDL_MAXSPAN ? P.osd_order : OSDL_MAXSPAN;
-            int tcount = 0;
+            int tcount = gauss ? ntc_g : 0;  // gauss mode: colvec / tpos / am come from the back-substitution
 #pragma clang loop unroll(disable)
-            for (int w = 0; w < W; ++w) {
+            for (int w = gauss ? W : 0; w < W; ++w) {
                 unsigned long long npm = npmask[w];
                 npm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(npm >> 32)) << 32) |
                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)npm);
@@ -660,7 +798,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 // columns (for a pivot bit: of its pivot row; for one of those columns itself: its own bit), bits 16-29
                 // its pivot row, bit 30 "is a pivot", bit 31 its OSD-0 value.
                 const int ntc = tcount < wspan ? tcount : wspan;
-                unsigned int* info = (unsigned int*)(tpos + 64);
+                unsigned int* info = (unsigned int*)R;  // (the back-substitution vectors are dead by now)
                 double* pairw = (double*)(info + ((n + 1) & ~1));
                 double* costs = P.costs_ws + (size_t)blockIdx.x * n;
                 double* wd = P.wd_ws + (size_t)blockIdx.x * P.wdn;
@@ -832,7 +970,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         const int bq = __ffs((int)pp) - 1;
                         pp &= pp - 1;
                         const int pos = tpos[bq];
-                        xs ^= ((OSDL_AT(unsigned long long, M + (size_t)(pos >> 6) * MRL, ro) >> (pos & 63)) & 1ull) != 0ull;
+                        if (gauss) xs ^= ((colvec[bq * NCV + k * OSDL_NW + wave] >> lane) & 1ull) != 0ull;  // M is not reduced
+                        else xs ^= ((OSDL_AT(unsigned long long, M + (size_t)(pos >> 6) * MRL, ro) >> (pos & 63)) & 1ull) != 0ull;
                     }
                 }
                 if (((usedmask >> k) & 1u) && xs) xout[kidx[rowpos[rr]]] = 1;
