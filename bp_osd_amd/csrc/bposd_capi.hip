@@ -44,10 +44,17 @@ struct DevBuf {
 // chunks of one host-pointer call) run on different HIP streams with their own workspaces, so the persistent
 // workgroups of call k + 1 pick up the CUs that call k's last max_iter stragglers and its OSD kernel leave idle.
 constexpr int BPOSD_LANES = 4;  // large codes (HBM-resident workspaces of several GB per lane) use two of them
-constexpr int BPOSD_MAX_CHUNKS = 8;  // chunks of one host-pointer call (bposd_decode_batch)
+constexpr int BPOSD_MAX_CHUNKS = 16;  // chunks of one host-pointer call (bposd_decode_batch)
 
 struct Lane {
     hipStream_t stream = nullptr;
+    // The OSD kernel of a call runs on a stream of its own at the highest priority (ordered behind the call's BP kernel
+    // and in front of whatever follows on `stream` by events): its few, fat workgroups otherwise queue behind the full
+    // grid of the NEXT call's BP kernel for every CU that frees up and take many times their own run time.
+    hipStream_t osd_stream = nullptr;
+    hipEvent_t ev_bp = nullptr, ev_osd = nullptr;
+    hipEvent_t ev_up = nullptr;  // host-pointer calls: this lane's chunk has been uploaded (uploads go one at a time, in
+                                 // chunk order: the first chunk's kernels then start after one chunk's copy time)
     DevBuf bpl_msg, bpl_llr;  // large BP workspaces (bpl_llr also serves the local-edge kernel: LLRs of the current syndrome)
     DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
     DevBuf osd_rows_ws;       // OSD kernel's per-workgroup spill area for finished row words
@@ -152,8 +159,10 @@ struct DeviceGuard {
 };
 
 int sync_all_lanes(bposd_handle* h) {
-    for (auto& l : h->lanes)
+    for (auto& l : h->lanes) {
         if (l.stream) HIP_TRY(h, hipStreamSynchronize(l.stream));
+        if (l.osd_stream) HIP_TRY(h, hipStreamSynchronize(l.osd_stream));
+    }
     return 0;
 }
 
@@ -957,7 +966,7 @@ int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
     Q.rows_ws = (unsigned long long*)h->cur->osd_rows_ws.p;
     auto k = osd_kernel<W>;
     HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, Q);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->osd_stream, Q);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
@@ -1052,7 +1061,7 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     case R: {                                                                                               \
         auto k = osd_large_kernel<R>;                                                                       \
         HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(OSDL_NT), lds, h->cur->stream, Q);                      \
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(OSDL_NT), lds, h->cur->osd_stream, Q);                  \
     } break;
     switch (RPT) {
         OSDL_LAUNCH(2)
@@ -1083,10 +1092,12 @@ int probe_rank_large(bposd_handle* h, int* rank) {
     P.synd = b + off_synd; P.rp = h->d_rp; P.ci = h->d_ci; P.llr_ws = (const double*)(b + off_llr);
     P.osd_list = (const int*)(b + off_cnt) + 4; P.counters = (int*)(b + off_cnt);
     P.out_osd0 = nullptr; P.out_osdw = b + off_out;
+    HIP_TRY(h, hipEventRecord(h->cur->ev_bp, h->cur->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->cur->osd_stream, h->cur->ev_bp, 0));
     rc = launch_osd_large(h, P, 1, (int*)(b + off_cnt) + 5);
     if (!rc) {
         int got[8];
-        hipError_t e = hipStreamSynchronize(h->cur->stream);
+        hipError_t e = hipStreamSynchronize(h->cur->osd_stream);
         if (e == hipSuccess) e = hipMemcpy(got, b + off_cnt, sizeof(got), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(h, BPOSD_ERR_HIP, "rank probe failed: %s", hipGetErrorString(e));
         else if (got[5] < 0 || got[5] > std::min(h->m, h->n)) rc = fail(h, BPOSD_ERR_HIP, "rank probe returned %d", got[5]);
@@ -1144,6 +1155,11 @@ void bposd_destroy(bposd_handle* h) {
             release(*b);
         for (void* p : {(void*)l.d_counters, (void*)l.d_iter_total, (void*)l.d_osd_dbg})
             if (p) (void)hipFree(p);
+        if (l.osd_stream) (void)hipStreamSynchronize(l.osd_stream);
+        if (l.ev_bp) (void)hipEventDestroy(l.ev_bp);
+        if (l.ev_osd) (void)hipEventDestroy(l.ev_osd);
+        if (l.ev_up) (void)hipEventDestroy(l.ev_up);
+        if (l.osd_stream) (void)hipStreamDestroy(l.osd_stream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
@@ -1231,8 +1247,14 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(hipGetDeviceProperties(&prop, h->device));
     h->num_cu = prop.multiProcessorCount;
     if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+    int prio_least = 0, prio_greatest = 0;
+    CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     for (auto& l : h->lanes) {
         CREATE_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        CREATE_TRY(hipStreamCreateWithPriority(&l.osd_stream, hipStreamNonBlocking, prio_greatest));
+        CREATE_TRY(hipEventCreateWithFlags(&l.ev_bp, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&l.ev_osd, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&l.ev_up, hipEventDisableTiming));
         CREATE_TRY(hipMalloc((void**)&l.d_counters, sizeof(int) * 4));
         CREATE_TRY(hipMalloc((void**)&l.d_iter_total, sizeof(unsigned long long)));
     }
@@ -1490,6 +1512,8 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     HIP_TRY(h, hipEventRecord(h->currec->ev[1], h->cur->stream));
     h->currec->ran_osd = false;
     if (osd_on) {
+        HIP_TRY(h, hipEventRecord(h->cur->ev_bp, h->cur->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->cur->osd_stream, h->cur->ev_bp, 0));
         OsdParams Q{};
         Q.m = h->m;
         Q.n = h->n;
@@ -1512,14 +1536,14 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         const char* dbg_env = getenv("BPOSD_OSD_DEBUG");
         if (dbg_env && dbg_env[0] == '1') {
             if (!h->cur->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->cur->d_osd_dbg, 2048 * sizeof(long long)));
-            HIP_TRY(h, hipMemsetAsync(h->cur->d_osd_dbg, 0, 2048 * sizeof(long long), h->cur->stream));
+            HIP_TRY(h, hipMemsetAsync(h->cur->d_osd_dbg, 0, 2048 * sizeof(long long), h->cur->osd_stream));
             Q.dbg = h->cur->d_osd_dbg;
         }
         if (h->large) {
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
             if (Q.dbg) {
                 long long st[13];
-                HIP_TRY(h, hipStreamSynchronize(h->cur->stream));
+                HIP_TRY(h, hipStreamSynchronize(h->cur->osd_stream));
                 HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[bposd large osd, s_memtime ticks, list slot 0] sort %lld  build %lld  E1 %lld  E2 %lld  E3 %lld  apply %lld  "
                         "sweep %lld | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld apply table builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12]);
@@ -1529,7 +1553,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         h->currec->ran_osd = true;
         if (Q.dbg) {
             static long long st[2048];
-            HIP_TRY(h, hipStreamSynchronize(h->cur->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->cur->osd_stream));
             HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
             if (const char* dump = getenv("BPOSD_OSD_DUMP")) {
                 if (FILE* f = fopen(dump, "wb")) { fwrite(st, sizeof(long long), 2048, f); fclose(f); }
@@ -1538,6 +1562,10 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
                     st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5]);
             fprintf(stderr, "[bposd osd elimination] panel phase %lld  trailing phase %lld  pivots %lld\n", st[1190], st[1191], st[1192]);
         }
+    }
+    if (osd_on) {  // whatever follows on the lane's stream comes after the OSD kernel
+        HIP_TRY(h, hipEventRecord(h->cur->ev_osd, h->cur->osd_stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->cur->stream, h->cur->ev_osd, 0));
     }
     HIP_TRY(h, hipEventRecord(h->currec->ev[2], h->cur->stream));
     HIP_TRY(h, hipMemcpyAsync(h->currec->h_counters, h->cur->d_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->cur->stream));
@@ -1618,11 +1646,12 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     HIP_TRY(h, dev_guard.err);
     // the records and lanes are about to be reused: earlier asynchronous calls must have drained
     { int rcs = sync_all_lanes(h); if (rcs) return rcs; }
-    // chunk size: at least 4 resident grids' worth of syndromes (so that a chunk's own tail stays small against its
-    // body), at most BPOSD_MAX_CHUNKS chunks
-    long long min_chunk = 16384;
-    if (const char* e = getenv("BPOSD_HOST_CHUNK")) min_chunk = std::max(1LL, atoll(e));
-    int nchunks = (int)std::min<long long>(BPOSD_MAX_CHUNKS, std::max<long long>(1, B / min_chunk));
+    // Chunks of ~32768 syndromes (measured on the headline workload, 131072 syndromes: 4 chunks on the 4 lanes 31.9 ms,
+    // 8 chunks 35.6 ms -- a lane's next chunk waits for the previous one's OSD kernel and download, and every chunk pays
+    // its own straggler tail -- 2 chunks 33.0 ms), at most BPOSD_MAX_CHUNKS; BPOSD_HOST_CHUNK overrides the target size.
+    long long target = 32768;
+    if (const char* e = getenv("BPOSD_HOST_CHUNK")) target = std::max(1LL, atoll(e));
+    int nchunks = (int)std::min<long long>(BPOSD_MAX_CHUNKS, std::max<long long>(1, (B + target / 2) / target));
     if (h->large) nchunks = (int)std::min<long long>(nchunks, std::max<long long>(1, B / (4LL * h->num_cu)));
     const long long CH = (B + nchunks - 1) / nchunks;
     nchunks = (int)((B + CH - 1) / CH);
@@ -1641,11 +1670,13 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         if (conv && (rc = ensure(h, L.io_conv, (size_t)CH))) return rc;
         if (iters && (rc = ensure(h, L.io_iters, sizeof(int) * (size_t)CH))) return rc;
         if (llr && (rc = ensure(h, L.io_llr, sizeof(double) * (size_t)CH * n))) return rc;
+        if (c > 0) HIP_TRY(h, hipStreamWaitEvent(L.stream, h->lanes[(c - 1) % h->nlanes].ev_up, 0));
         HIP_TRY(h, hipMemcpyAsync(L.io_synd.p, synd + (size_t)lo * m, bm, hipMemcpyHostToDevice, L.stream));
         if (sel) {
             if ((rc = ensure(h, L.io_sel, (size_t)CH * n))) return rc;
             HIP_TRY(h, hipMemcpyAsync(L.io_sel.p, sel + (size_t)lo * n, bn, hipMemcpyHostToDevice, L.stream));
         }
+        HIP_TRY(h, hipEventRecord(L.ev_up, L.stream));
         rc = decode_device_impl(h, (const uint8_t*)L.io_synd.p, cnt, sel ? (const uint8_t*)L.io_sel.p : nullptr,
                                 (uint8_t*)L.io_osdw.p, osd0 ? (uint8_t*)L.io_osd0.p : nullptr,
                                 bp ? (uint8_t*)L.io_bp.p : nullptr, conv ? (uint8_t*)L.io_conv.p : nullptr,

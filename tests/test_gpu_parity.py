@@ -1114,7 +1114,7 @@ def test_chunked_host_api_equals_single_chunk(gpu_ready, h1922, monkeypatch):
     one = _gpu_decode(dec, syn)
     one = {k: np.array(v, copy=True) for k, v in one.items()}
     t_one = dec.last_timing()
-    monkeypatch.setenv("BPOSD_HOST_CHUNK", "100")  # -> 8 chunks of 155 (the last one 152)
+    monkeypatch.setenv("BPOSD_HOST_CHUNK", "100")  # -> 12 chunks of 104 (the last one 93), three rounds of the lanes
     many = _gpu_decode(dec, syn)
     _compare_exact(many, one)
     t_many = dec.last_timing()
