@@ -55,7 +55,7 @@ class BposdConfig(C.Structure):
         ("osd_order", C.c_int32),
         ("sort_tie_policy", C.c_int32),
         ("weight_fn", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("schedule", C.c_int32),
         ("ps_clip", C.c_double),
         ("reserved", C.c_int32 * 2),
     ]

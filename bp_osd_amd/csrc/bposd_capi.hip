@@ -24,6 +24,7 @@
 #include "bp_kernel.hip.h"
 #include "bp_large_kernel.hip.h"
 #include "bp_local_kernel.hip.h"
+#include "bp_serial_kernel.hip.h"
 #include "osd_large_kernel.hip.h"
 #include "osd_kernel.hip.h"
 
@@ -53,6 +54,8 @@ struct Lane {
     // grid of the NEXT call's BP kernel for every CU that frees up and take many times their own run time.
     hipStream_t osd_stream = nullptr;
     hipEvent_t ev_bp = nullptr, ev_osd = nullptr;
+    void* h_stage = nullptr;     // page-locked, device-visible staging for small host-pointer calls (zero-copy path)
+    size_t h_stage_bytes = 0;
     hipEvent_t ev_up = nullptr;  // host-pointer calls: this lane's chunk has been uploaded (uploads go one at a time, in
                                  // chunk order: the first chunk's kernels then start after one chunk's copy time)
     DevBuf bpl_msg, bpl_llr;  // large BP workspaces (bpl_llr also serves the local-edge kernel: LLRs of the current syndrome)
@@ -61,7 +64,6 @@ struct Lane {
     DevBuf llr_ws, osd_list, io_synd, io_osdw, io_osd0, io_bp, io_conv, io_iters, io_llr, io_sel;
     long long* d_osd_dbg = nullptr;  // diagnostics (BPOSD_OSD_DEBUG=1): phase timestamps
     int* d_counters = nullptr;       // 4 ints
-    unsigned long long* d_iter_total = nullptr;
 };
 
 // What bposd_last_timing reports: one record per kernel pair launched by the last call (one per chunk for a
@@ -116,6 +118,9 @@ struct bposd_handle {
     double* d_cost = nullptr;  // log(1/p_i): OSD-W weights of the ldpc-v2 weight function
     double *d_llr0_alt = nullptr, *d_cost_alt = nullptr;  // alternative channel of the two-valued per-shot form
     bool fp_weights = false;   // non-uniform (or degenerate) channel: candidate weights need the fp64 sums
+    // serial schedule (cfg.schedule == 1): CSC view and level lists
+    int *d_cp = nullptr, *d_ce = nullptr, *d_erow = nullptr, *d_lvl_ptr = nullptr, *d_lvl_bits = nullptr;
+    int nlevels = 0;
     int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
     bool have_timing = false;
     std::string err;
@@ -951,6 +956,72 @@ int launch_bp_large(bposd_handle* h, BpLargeParams& P) {
     return fail(h, BPOSD_ERR_UNSUPPORTED, "check degree %d / bit degree %d exceed the built kernels (16 / 8)", h->dc_max, h->dv_max);
 }
 
+// ------------------------------------------------------------------ serial-schedule BP: tables + launch
+int build_tables_serial(bposd_handle* h) {
+    const int m = h->m, n = h->n, E = h->E;
+    std::vector<int> cp(n + 1, 0), ce(E), erow(E), fill(n, 0);
+    for (int e = 0; e < E; ++e) cp[h->ci[e] + 1]++;
+    for (int i = 0; i < n; ++i) cp[i + 1] += cp[i];
+    for (int c = 0; c < m; ++c)
+        for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
+            erow[e] = c;
+            ce[cp[h->ci[e]] + fill[h->ci[e]]++] = e;  // ascending row within a column
+        }
+    // level(j) = 1 + the highest level among the earlier bits that share a check with j
+    std::vector<int> last(m, 0), level(n, 0);
+    int nlev = 0;
+    for (int i = 0; i < n; ++i) {
+        int lv = 0;
+        for (int k = cp[i]; k < cp[i + 1]; ++k) lv = std::max(lv, last[erow[ce[k]]]);
+        level[i] = lv + 1;
+        for (int k = cp[i]; k < cp[i + 1]; ++k) last[erow[ce[k]]] = lv + 1;
+        nlev = std::max(nlev, lv + 1);
+    }
+    std::vector<int> lptr(nlev + 1, 0), lbits(n);
+    for (int i = 0; i < n; ++i) lptr[level[i]]++;  // level l (1-based) counted into slot l
+    for (int l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
+    {
+        std::vector<int> pos(lptr.begin(), lptr.end() - 1);
+        for (int i = 0; i < n; ++i) lbits[pos[level[i] - 1]++] = i;  // ascending bit index inside a level
+    }
+    auto up = [&](int** dst, const std::vector<int>& v) -> int {
+        HIP_TRY(h, hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1)));
+        HIP_TRY(h, hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc;
+    if ((rc = up(&h->d_cp, cp))) return rc;
+    if ((rc = up(&h->d_ce, ce))) return rc;
+    if ((rc = up(&h->d_erow, erow))) return rc;
+    if ((rc = up(&h->d_lvl_ptr, lptr))) return rc;
+    if ((rc = up(&h->d_lvl_bits, lbits))) return rc;
+    h->nlevels = nlev;
+    return 0;
+}
+
+int launch_bp_serial(bposd_handle* h, const BpParams& P) {
+    BpSerialParams S{};
+    S.m = P.m; S.n = P.n; S.E = h->E; S.B = P.B; S.max_iter = P.max_iter; S.bp_method = h->cfg.bp_method;
+    S.ms_scaling = P.ms_scaling; S.ps_clip = P.ps_clip; S.osd_enabled = P.osd_enabled; S.nlevels = h->nlevels;
+    S.synd = P.synd; S.llr0 = P.llr0; S.sel = P.sel; S.llr0_alt = P.llr0_alt;
+    S.rp = h->d_rp; S.ci = h->d_ci; S.cp = h->d_cp; S.ce = h->d_ce; S.erow = h->d_erow;
+    S.lvl_ptr = h->d_lvl_ptr; S.lvl_bits = h->d_lvl_bits;
+    S.out_bp = P.out_bp; S.out_osd0 = P.out_osd0; S.out_osdw = P.out_osdw; S.out_conv = P.out_conv; S.out_iters = P.out_iters;
+    S.out_llr = P.out_llr; S.llr_ws = P.llr_ws; S.osd_list = P.osd_list; S.counters = P.counters; S.iter_total = P.iter_total;
+    const size_t lds = bp_serial_lds_bytes(h->n);
+    const int wg_per_cu = std::max<int>(1, std::min<size_t>(8, h->lds_per_cu / std::max<size_t>(lds, 1)));
+    const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
+    int rc;
+    if ((rc = ensure(h, h->cur->bpl_msg, sizeof(double) * (size_t)grid * h->E))) return rc;
+    if ((rc = ensure(h, h->cur->bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
+    S.msg_ws = (double*)h->cur->bpl_msg.p;
+    S.llr_tmp = (double*)h->cur->bpl_llr.p;
+    HIP_TRY(h, hipFuncSetAttribute((const void*)bp_serial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(bp_serial_kernel, dim3((unsigned)grid), dim3(BPS_NT), lds, h->cur->stream, S);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
 // ----------------------------------------------------------------------------- OSD launch
 template <int W>
 int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
@@ -1153,9 +1224,10 @@ void bposd_destroy(bposd_handle* h) {
         for (DevBuf* b : {&l.bpl_msg, &l.bpl_llr, &l.osdl_ws, &l.io_sel, &l.osd_rows_ws, &l.llr_ws, &l.osd_list, &l.io_synd, &l.io_osdw,
                           &l.io_osd0, &l.io_bp, &l.io_conv, &l.io_iters, &l.io_llr})
             release(*b);
-        for (void* p : {(void*)l.d_counters, (void*)l.d_iter_total, (void*)l.d_osd_dbg})
+        for (void* p : {(void*)l.d_counters, (void*)l.d_osd_dbg})  // (d_iter_total lives inside the d_counters block)
             if (p) (void)hipFree(p);
         if (l.osd_stream) (void)hipStreamSynchronize(l.osd_stream);
+        if (l.h_stage) (void)hipHostFree(l.h_stage);
         if (l.ev_bp) (void)hipEventDestroy(l.ev_bp);
         if (l.ev_osd) (void)hipEventDestroy(l.ev_osd);
         if (l.ev_up) (void)hipEventDestroy(l.ev_up);
@@ -1165,12 +1237,12 @@ void bposd_destroy(bposd_handle* h) {
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
                     (void*)h->d_var_pos, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt,
                     (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
-                    (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl})
+                    (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl,
+                    (void*)h->d_cp, (void*)h->d_ce, (void*)h->d_erow, (void*)h->d_lvl_ptr, (void*)h->d_lvl_bits})
         if (p) (void)hipFree(p);
     for (CallRecord* rs : {h->rec, h->lane_rec})
         for (int k = 0; k < (rs == h->rec ? BPOSD_MAX_CHUNKS : BPOSD_LANES); ++k) {
             if (rs[k].h_counters) (void)hipHostFree(rs[k].h_counters);
-            if (rs[k].h_iter_total) (void)hipHostFree(rs[k].h_iter_total);
             for (auto& e : rs[k].ev)
                 if (e) (void)hipEventDestroy(e);
         }
@@ -1190,8 +1262,9 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     if (cfg->max_iter < 0 || cfg->osd_order < 0) return fail(nullptr, BPOSD_ERR_INVALID, "negative max_iter / osd_order");
     if (cfg->sort_tie_policy < 0 || cfg->sort_tie_policy > 1 || cfg->weight_fn < 0 || cfg->weight_fn > 1)
         return fail(nullptr, BPOSD_ERR_INVALID, "sort_tie_policy / weight_fn out of range");
-    if (cfg->reserved0 != 0 || cfg->reserved[0] != 0 || cfg->reserved[1] != 0)
+    if (cfg->reserved[0] != 0 || cfg->reserved[1] != 0)
         return fail(nullptr, BPOSD_ERR_INVALID, "reserved config fields must be 0");
+    if (cfg->schedule != 0 && cfg->schedule != 1) return fail(nullptr, BPOSD_ERR_INVALID, "schedule must be 0 (parallel) or 1 (serial)");
     if (!(cfg->ps_clip >= 0.0) || std::isinf(cfg->ps_clip)) return fail(nullptr, BPOSD_ERR_INVALID, "ps_clip must be 0 (off) or a finite positive bound");
     if (indptr[0] != 0) return fail(nullptr, BPOSD_ERR_INVALID, "csr_indptr[0] must be 0");
     for (int c = 0; c < m; ++c) {
@@ -1255,14 +1328,13 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_bp, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_osd, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_up, hipEventDisableTiming));
-        CREATE_TRY(hipMalloc((void**)&l.d_counters, sizeof(int) * 4));
-        CREATE_TRY(hipMalloc((void**)&l.d_iter_total, sizeof(unsigned long long)));
+        CREATE_TRY(hipMalloc((void**)&l.d_counters, 32));  // 4 counters + the 64-bit iteration total: one memset, one copy
     }
     for (CallRecord* rs : {h->rec, h->lane_rec})
         for (int k = 0; k < (rs == h->rec ? BPOSD_MAX_CHUNKS : BPOSD_LANES); ++k) {
             for (auto& e : rs[k].ev) CREATE_TRY(hipEventCreate(&e));
-            CREATE_TRY(hipHostMalloc((void**)&rs[k].h_counters, sizeof(int) * 4));
-            CREATE_TRY(hipHostMalloc((void**)&rs[k].h_iter_total, sizeof(unsigned long long)));
+            CREATE_TRY(hipHostMalloc((void**)&rs[k].h_counters, 32));
+            rs[k].h_iter_total = (unsigned long long*)(rs[k].h_counters + 4);
             rs[k].h_counters[0] = rs[k].h_counters[1] = 0;
             *rs[k].h_iter_total = 0;
         }
@@ -1357,6 +1429,13 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     if (h->bp_hbm) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
     else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, shp) * shape_cpt(shp), shape_threads(h, shp), 2 * shape_cpt(shp)));
     if (!h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
+    if (cfg->schedule == 1) {
+        if (h->dv_max > BPS_MAXDV) {
+            fail(h, BPOSD_ERR_UNSUPPORTED, "serial schedule: bit degree %d exceeds %d", h->dv_max, BPS_MAXDV);
+            CREATE_RC(BPOSD_ERR_UNSUPPORTED);
+        }
+        CREATE_RC(build_tables_serial(h));
+    }
     CREATE_RC(upload_priors(h));
     if (h->large) {
         CREATE_RC(probe_rank_large(h, &h->rank));
@@ -1465,8 +1544,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         if ((rc = ensure(h, h->cur->llr_ws, sizeof(double) * (size_t)B * h->n))) return rc;
         if ((rc = ensure(h, h->cur->osd_list, sizeof(int) * (size_t)B))) return rc;
     }
-    HIP_TRY(h, hipMemsetAsync(h->cur->d_counters, 0, sizeof(int) * 4, h->cur->stream));
-    HIP_TRY(h, hipMemsetAsync(h->cur->d_iter_total, 0, sizeof(unsigned long long), h->cur->stream));
+    HIP_TRY(h, hipMemsetAsync(h->cur->d_counters, 0, 32, h->cur->stream));
 
     BpParams P{};
     P.m = h->m;
@@ -1493,10 +1571,12 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.llr_ws = (double*)h->cur->llr_ws.p;
     P.osd_list = (int*)h->cur->osd_list.p;
     P.counters = h->cur->d_counters;
-    P.iter_total = h->cur->d_iter_total;
+    P.iter_total = (unsigned long long*)(h->cur->d_counters + 4);
 
     HIP_TRY(h, hipEventRecord(h->currec->ev[0], h->cur->stream));
-    if (h->bp_hbm) {
+    if (h->cfg.schedule == 1) {
+        if ((rc = launch_bp_serial(h, P))) return rc;
+    } else if (h->bp_hbm) {
         BpLargeParams L{};
         L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling; L.ps_clip = P.ps_clip;
         L.osd_enabled = P.osd_enabled; L.mp = h->tab_mp;
@@ -1568,9 +1648,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         HIP_TRY(h, hipStreamWaitEvent(h->cur->stream, h->cur->ev_osd, 0));
     }
     HIP_TRY(h, hipEventRecord(h->currec->ev[2], h->cur->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->currec->h_counters, h->cur->d_counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->cur->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->currec->h_iter_total, h->cur->d_iter_total, sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, h->cur->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->currec->h_counters, h->cur->d_counters, 32, hipMemcpyDeviceToHost, h->cur->stream));
     h->currec->recorded = true;
     h->have_timing = true;
     return BPOSD_OK;
@@ -1646,6 +1724,47 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     HIP_TRY(h, dev_guard.err);
     // the records and lanes are about to be reused: earlier asynchronous calls must have drained
     { int rcs = sync_all_lanes(h); if (rcs) return rcs; }
+    // ---- small calls (the reference's one-syndrome `.decode()`): no copy commands at all.  The kernels read the
+    // syndromes from, and write every result to, a page-locked staging area that the device addresses directly; the call
+    // costs two host memcpys, the launches and one stream synchronisation.
+    {
+        static const bool zero_copy = !(getenv("BPOSD_ZERO_COPY") && getenv("BPOSD_ZERO_COPY")[0] == '0');
+        const size_t n8 = (size_t)h->n, m8 = (size_t)h->m, b8 = (size_t)B;
+        auto a64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        const size_t o_syn = 0, o_sel = o_syn + a64(b8 * m8), o_osdw = o_sel + (sel ? a64(b8 * n8) : 0),
+                     o_osd0 = o_osdw + a64(b8 * n8), o_bp = o_osd0 + (osd0 ? a64(b8 * n8) : 0),
+                     o_conv = o_bp + (bp ? a64(b8 * n8) : 0), o_it = o_conv + a64(b8), o_llr = o_it + a64(b8 * 4),
+                     total = o_llr + (llr ? a64(b8 * n8 * 8) : 0);
+        if (zero_copy && total <= (size_t)1 << 20) {
+            Lane& L = h->lanes[0];
+            h->cur = &L;
+            if (L.h_stage_bytes < total) {
+                if (L.h_stage) (void)hipHostFree(L.h_stage);
+                L.h_stage = nullptr;
+                L.h_stage_bytes = 0;
+                const size_t want = std::max<size_t>(total, (size_t)1 << 16);
+                HIP_TRY(h, hipHostMalloc(&L.h_stage, want, hipHostMallocMapped));
+                L.h_stage_bytes = want;
+            }
+            unsigned char* st = (unsigned char*)L.h_stage;
+            memcpy(st + o_syn, synd, b8 * m8);
+            if (sel) memcpy(st + o_sel, sel, b8 * n8);
+            int rcz = decode_device_impl(h, st + o_syn, B, sel ? st + o_sel : nullptr, st + o_osdw, osd0 ? st + o_osd0 : nullptr,
+                                         bp ? st + o_bp : nullptr, st + o_conv, (int32_t*)(st + o_it),
+                                         llr ? (double*)(st + o_llr) : nullptr, 0, 0);
+            if (rcz) { (void)sync_all_lanes(h); return rcz; }
+            h->nrec = 1;
+            rcz = sync_all_lanes(h);
+            if (rcz) return rcz;
+            memcpy(osdw, st + o_osdw, b8 * n8);
+            if (osd0) memcpy(osd0, st + o_osd0, b8 * n8);
+            if (bp) memcpy(bp, st + o_bp, b8 * n8);
+            if (conv) memcpy(conv, st + o_conv, b8);
+            if (iters) memcpy(iters, st + o_it, b8 * 4);
+            if (llr) memcpy(llr, st + o_llr, b8 * n8 * 8);
+            return BPOSD_OK;
+        }
+    }
     // Chunks of ~32768 syndromes (measured on the headline workload, 131072 syndromes: 4 chunks on the 4 lanes 31.9 ms,
     // 8 chunks 35.6 ms -- a lane's next chunk waits for the previous one's OSD kernel and download, and every chunk pays
     // its own straggler tail -- 2 chunks 33.0 ms), at most BPOSD_MAX_CHUNKS; BPOSD_HOST_CHUNK overrides the target size.

@@ -70,11 +70,15 @@ class BpOsdDecoder:
                  sort_tie_policy=0, weight_fn=0, ps_clip=0.0, **kwargs):
         if kwargs:
             raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
-        if str(schedule).lower() != "parallel":
-            raise ValueError("only the parallel (flooding) BP schedule is implemented on MI355X")
-        ivt = str(input_vector_type).lower()
-        if ivt not in ("syndrome", "auto", "-1", "0"):
-            raise ValueError("input_vector_type must be 'syndrome' (received-vector decoding is not on this path)")
+        sched = str(schedule).lower()
+        if sched not in ("parallel", "serial"):
+            raise ValueError(f"schedule='{schedule}' is invalid. Valid options: ['parallel', 'serial']")
+        self._schedule = sched
+        ivt = {"-1": "auto", "0": "syndrome", "1": "received_vector"}.get(str(input_vector_type).lower(), str(input_vector_type).lower())
+        if ivt not in ("syndrome", "received_vector", "auto"):
+            raise ValueError(f"input_vector_type='{input_vector_type}' is invalid. Valid options: ['syndrome', 'received_vector', 'auto']")
+        self._input_vector_type = ivt
+        self.omp_thread_count = int(omp_thread_count)  # accepted for API compatibility; the batch is the unit of parallelism here
 
         if sp.issparse(pcm):
             h = sp.csr_matrix(pcm)
@@ -93,6 +97,7 @@ class BpOsdDecoder:
             raise ValueError("The parity check matrix is empty")
         self._indptr = np.ascontiguousarray(h.indptr, dtype=np.int32)
         self._indices = np.ascontiguousarray(h.indices, dtype=np.int32)
+        self._pcm = h.astype(np.int32)  # host copy: syndromes of received vectors (input_vector_type="received_vector")
 
         probs = error_channel if error_channel is not None else channel_probs
         if probs is not None and len(probs) == 1 and probs[0] is None:  # channel_probs=[None] (README.md:181)
@@ -134,6 +139,7 @@ class BpOsdDecoder:
         cfg.osd_order = osd_order
         cfg.sort_tie_policy = int(sort_tie_policy)
         cfg.weight_fn = int(weight_fn)
+        cfg.schedule = 1 if sched == "serial" else 0
         cfg.ps_clip = float(ps_clip)
         if not (cfg.ps_clip >= 0.0 and np.isfinite(cfg.ps_clip)):
             raise ValueError("ps_clip must be 0 (no clipping) or a finite positive bound")
@@ -154,6 +160,7 @@ class BpOsdDecoder:
         self._llr = np.zeros(self.n, dtype=np.float64)
         # batch results of the last decode_batch call
         self.batch_converge = None
+        self.batch_osdw = None
         self.batch_iter = None
         self.batch_osd0 = None
         self.batch_bp = None
@@ -181,6 +188,14 @@ class BpOsdDecoder:
         set and the decoder's ``channel_probs[i]`` elsewhere -- the batched form of the per-shot
         ``update_channel_probs`` of css_decode_sim.py:207-248."""
         s = np.asarray(syndromes)
+        received = None
+        if s.ndim == 2 and self._is_received(s.shape[1]):
+            # received-vector input (ldpc's input_vector_type="received_vector"): decode the syndromes H r and hand back
+            # r + correction; the batch_* arrays and the attributes keep the error estimates
+            if s.shape[1] != self.n:
+                raise ValueError(f"The received vectors must have shape (B, {self.n}). Not {s.shape}.")
+            received = np.ascontiguousarray(s.astype(np.int64) & 1, dtype=np.uint8)
+            s = np.ascontiguousarray((np.asarray(self._pcm @ received.T.astype(np.int32)) & 1).T, dtype=np.uint8)
         if s.ndim != 2 or s.shape[1] != self.m:
             raise ValueError(f"The syndromes must have shape (B, {self.m}). Not {s.shape}.")
         # uint8 input goes to the device as it is (the kernels look at bit 0 only); other dtypes are reduced mod 2
@@ -188,7 +203,7 @@ class BpOsdDecoder:
             else np.ascontiguousarray(s)
         B = s8.shape[0]
         # drop last call's arrays first: their buffers can then be reused (unless the caller kept them)
-        self.batch_osd0 = self.batch_bp = self.batch_llr = None
+        self.batch_osd0 = self.batch_bp = self.batch_llr = self.batch_osdw = None
         osdw = self._out_array((B, self.n), np.uint8)
         osd0 = self._out_array((B, self.n), np.uint8) if want_osd0 else None
         bp = self._out_array((B, self.n), np.uint8) if want_bp else None
@@ -217,7 +232,14 @@ class BpOsdDecoder:
         self.batch_converge = conv.astype(bool)
         self.batch_iter = iters
         self.batch_osd0, self.batch_bp, self.batch_llr = osd0, bp, llr
-        return osdw
+        self.batch_osdw = osdw
+        return osdw if received is None else (osdw ^ received)
+
+    def _is_received(self, length):
+        """Does an input of this length hold received vectors (n bits) rather than syndromes (m bits)?"""
+        if self._input_vector_type == "received_vector":
+            return True
+        return self._input_vector_type == "auto" and length == self.n and self.n != self.m
 
     # ------------------------------------------------------------------ recycled output buffers
     _POOL_MIN_BYTES = 1 << 20   # below this a fresh numpy array costs nothing
@@ -256,9 +278,12 @@ class BpOsdDecoder:
         """Decode one syndrome; returns the correction with the syndrome's dtype
         (README.md:197; css_decode_sim.py:174-202).  Result attributes are updated."""
         s = np.asarray(syndrome)
-        if s.ndim != 1 or len(s) != self.m:
-            raise ValueError(f"The syndrome must have length {self.m}. Not {len(s) if s.ndim else 0}.")
-        osdw = self.decode_batch(s[None, :], want_osd0=True, want_bp=True, want_llr=True)
+        want = self.n if (s.ndim == 1 and self._is_received(len(s))) else self.m
+        if s.ndim != 1 or len(s) != want:
+            raise ValueError(f"The {'received vector' if want == self.n and want != self.m else 'syndrome'} must have length {want}. "
+                             f"Not {len(s) if s.ndim else 0}.")
+        out = self.decode_batch(s[None, :], want_osd0=True, want_bp=True, want_llr=True)
+        osdw = self.batch_osdw
         self._osdw = osdw[0].astype(int)
         self._osd0 = self.batch_osd0[0].astype(int)
         self._bp = self.batch_bp[0].astype(int)
@@ -266,7 +291,7 @@ class BpOsdDecoder:
         self._iter = int(self.batch_iter[0])
         self._llr = self.batch_llr[0].copy()
         dtype = s.dtype if np.issubdtype(s.dtype, np.number) else int
-        return osdw[0].astype(dtype)
+        return out[0].astype(dtype)
 
     def decode_batch_device(self, d_syndromes, B, d_osdw, d_osd0=None, d_bp=None, d_converged=None,
                             d_iters=None, d_llr=None, d_prior_select=None, alt_channel_probs=None):
@@ -421,6 +446,14 @@ class BpOsdDecoder:
         return self._max_iter
 
     @property
+    def schedule(self):
+        return self._schedule
+
+    @property
+    def input_vector_type(self):
+        return self._input_vector_type
+
+    @property
     def bp_method(self):
         return _BP_NAMES[self._bp_method]
 
@@ -453,10 +486,10 @@ class bposd_decoder(BpOsdDecoder):
                  channel_probs=[None], input_vector_type=-1, osd_order=-1, osd_method=0, **kwargs):
         if isinstance(osd_method, (int, np.integer)):
             osd_method = {0: "osd_0", 1: "osd_e", 2: "osd_cs"}.get(int(osd_method), osd_method)
-        if isinstance(input_vector_type, (int, np.integer)):
-            if int(input_vector_type) not in (-1, 0):
-                raise ValueError("only syndrome input is supported on this path")
-            input_vector_type = "syndrome"
+        if isinstance(input_vector_type, (int, np.integer)):  # ldpc v1: -1 auto (by length), 0 syndrome, 1 received vector
+            if int(input_vector_type) not in (-1, 0, 1):
+                raise ValueError("input_vector_type must be -1 (auto), 0 (syndrome) or 1 (received vector)")
+            input_vector_type = {-1: "auto", 0: "syndrome", 1: "received_vector"}[int(input_vector_type)]
         super().__init__(parity_check_matrix, error_rate=error_rate, max_iter=max_iter, bp_method=bp_method,
                          ms_scaling_factor=ms_scaling_factor, channel_probs=channel_probs,
                          osd_method=osd_method, osd_order=osd_order, input_vector_type=input_vector_type,

@@ -56,7 +56,9 @@ typedef struct {
     int32_t osd_order;         /* osd_e: patterns on the first w non-pivots; osd_cs: pair span */
     int32_t sort_tie_policy;   /* 0 = stable ascending index among equal LLRs, 1 = descending */
     int32_t weight_fn;         /* 0 = sum log(1/p_i) (ldpc v2), 1 = Hamming weight (ldpc v1)  */
-    int32_t reserved0;         /* must be 0                                                  */
+    int32_t schedule;          /* 0 = parallel (flooding) BP schedule -- what the reference runs; 1 = ldpc's
+                                  "serial" schedule (bits in ascending index).  Was a reserved
+                                  word: a zero-filled old config means parallel                */
     double ps_clip;            /* product-sum only.  0 = upstream behaviour: no clipping, so check->bit messages
                                   reach +-inf once tanh rounds to 1 and NaN follows;
                                   C > 0 = every check->bit message is clamped to [-C, C] (build-owned switch,

@@ -266,6 +266,82 @@ int oracle_last_bp_diag(const oracle_decoder *d, int32_t *first_nonfinite_iter, 
 }
 
 /* ---------------------------------------------------------------------------------
+ * BP, serial schedule  (f4: ldpc v2 `schedule="serial"`, never used by the reference; restated from memory)
+ * Per iteration the bits are visited in ascending index.  For bit i: LLR := prior; for each of its checks, top to
+ * bottom: the check->bit message is recomputed from the CURRENT bit->check messages of the check's other edges
+ * (min-sum: alpha * (-1)^(syndrome + #{others <= 0}) * min |others|; product-sum: (-1)^syndrome *
+ * log((1 + prod)/(1 - prod)), prod over the others of tanh(b2c / 2) in row order), the edge's bit->check message
+ * becomes the running LLR (prefix), the LLR takes the new message; decision = (LLR <= 0); then, bottom to top, the
+ * suffix sums are added to the bit->check messages.  Convergence is tested after every full sweep.
+ * ------------------------------------------------------------------------------- */
+static void bp_decode_serial(oracle_decoder *d, const uint8_t *syn, uint8_t *converged, int32_t *iters) {
+    const int m = d->m, n = d->n;
+    int conv = 0, it_done = 0;
+    d->diag_first_nonfinite = d->diag_has_inf = d->diag_has_nan = 0;
+    const int pm = d->cfg.ps_math == 1;
+    for (int i = 0; i < n; i++)
+        for (int k = d->cp[i]; k < d->cp[i + 1]; k++) d->b2c[d->ce[k]] = d->llr0[i];
+    for (int it = 1; it <= d->max_iter; it++) {
+        double alpha;
+        if (d->cfg.ms_scaling_factor == 0.0) alpha = 1.0 - pow(2.0, -1.0 * it);
+        else alpha = d->cfg.ms_scaling_factor;
+        for (int i = 0; i < n; i++) {
+            double llr = d->llr0[i];
+            for (int k = d->cp[i]; k < d->cp[i + 1]; k++) {
+                const int e = d->ce[k], c = d->erow[e];
+                double msg;
+                if (d->cfg.bp_method == 0) {
+                    double prod = 1.0;
+                    for (int g = d->rp[c]; g < d->rp[c + 1]; g++)
+                        if (g != e) prod *= pm ? pm_tanh(d->b2c[g] / 2) : tanh(d->b2c[g] / 2);
+                    const double ratio = (1 + prod) / (1 - prod);
+                    msg = (syn[c] ? -1 : 1) * (pm ? pm_log(ratio) : log(ratio));
+                    if (d->cfg.ps_clip > 0) {
+                        if (msg > d->cfg.ps_clip) msg = d->cfg.ps_clip;
+                        if (msg < -d->cfg.ps_clip) msg = -d->cfg.ps_clip;
+                    }
+                } else {
+                    int sgn = syn[c];
+                    double temp = DBL_MAX;
+                    for (int g = d->rp[c]; g < d->rp[c + 1]; g++) {
+                        if (g == e) continue;
+                        const double a = fabs(d->b2c[g]);
+                        if (a < temp) temp = a;
+                        if (d->b2c[g] <= 0) sgn += 1;
+                    }
+                    const double message_sign = (sgn % 2 == 0) ? 1.0 : -1.0;
+                    msg = alpha * message_sign * temp;
+                }
+                d->c2b[e] = msg;
+                d->b2c[e] = llr;
+                llr += msg;
+            }
+            d->llr[i] = llr;
+            d->dec[i] = (llr <= 0) ? 1 : 0;
+            double temp = 0;
+            for (int k = d->cp[i + 1] - 1; k >= d->cp[i]; k--) {
+                const int e = d->ce[k];
+                d->b2c[e] += temp;
+                temp += d->c2b[e];
+            }
+        }
+        memset(d->cand, 0, (size_t)m);
+        for (int i = 0; i < n; i++)
+            if (d->dec[i])
+                for (int k = d->cp[i]; k < d->cp[i + 1]; k++) d->cand[d->erow[d->ce[k]]] ^= 1;
+        conv = memcmp(d->cand, syn, m) == 0;
+        it_done = it;
+        if (conv) break;
+    }
+    for (int i = 0; i < n && it_done > 0; i++) {
+        if (isnan(d->llr[i])) d->diag_has_nan = 1;
+        else if (isinf(d->llr[i])) d->diag_has_inf = 1;
+    }
+    *converged = (uint8_t)conv;
+    *iters = it_done;
+}
+
+/* ---------------------------------------------------------------------------------
  * OSD  (a8-a11; Appendix A.4)
  * ------------------------------------------------------------------------------- */
 
@@ -473,7 +549,8 @@ int oracle_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *osdw, uint8_t 
     }
     uint8_t conv;
     int32_t its;
-    bp_decode(d, syn, &conv, &its);
+    if (d->cfg.schedule == 1) bp_decode_serial(d, syn, &conv, &its);
+    else bp_decode(d, syn, &conv, &its);
     if (bp) memcpy(bp, d->dec, n);
     if (converged) *converged = conv;
     if (iters) *iters = its;

@@ -39,6 +39,10 @@ typedef struct {
     int32_t weight_fn;
     double ps_clip;           /* product-sum only: 0 = none (upstream: no clipping, messages reach +-inf and
                                  NaN); C > 0 = every check->bit message is clamped to [-C, C] (build-owned switch) */
+    int32_t schedule;         /* 0 = parallel (flooding) schedule -- the only one the reference uses
+                                 (css_decode_sim.py:444-463 never passes `schedule`); 1 = serial schedule of ldpc v2
+                                 (bits in ascending index, each bit's check->bit messages recomputed from the latest
+                                 bit->check messages; SURVEY.md §8 f4, restated from memory like Appendix A) */
     int32_t ps_math;          /* product-sum only: 0 = tanh / log of the platform libm (what the reference calls);
                                  1 = the bit-reproducible routines of bp_osd_amd/csrc/portable_math.h, which is what the
                                  GPU kernels evaluate -- with 1 the oracle and the GPU agree bit for bit, with 0 they

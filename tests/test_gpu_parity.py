@@ -1140,3 +1140,71 @@ def test_chunked_host_api_equals_single_chunk(gpu_ready, h1922, monkeypatch):
     monkeypatch.setenv("BPOSD_HOST_CHUNK", "1000000")
     b = dec.decode_batch(syn, prior_select=sel, alt_channel_probs=alt)
     assert (a == b).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# f4: the ldpc options the reference never passes -- serial schedule, received-vector input, omp_thread_count
+@pytest.mark.parametrize("bp_method", ["ms", "ps"])
+def test_serial_schedule_vs_oracle(gpu_ready, surface13, hgp400, h1922, bp_method):
+    """schedule="serial" (bits visited in ascending index inside an iteration; levels of check-disjoint bits run in
+    parallel on the GPU) against the oracle's sequential sweep: bit for bit, LLRs included, min-sum and product-sum
+    (the oracle in its portable-math mode), small and large OSD paths, with a per-bit channel."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import circulant, hgp
+    from oracle import OracleDecoder
+
+    big = hgp(circulant(45, (0, 2, 5)), compute_logicals=False).hz  # 2025 x 4050: HBM-resident OSD
+    rng = np.random.default_rng(3)
+    for H, q, B, kw in (
+        (surface13.hz, 0.1, 64, dict(max_iter=5, osd_method="osd_cs", osd_order=4)),
+        (hgp400.hx, 0.07, 300, dict(max_iter=6, osd_method="osd_e", osd_order=6)),
+        (h1922.hz, 0.06, 400, dict(max_iter=0, osd_method="osd_cs", osd_order=7)),
+        (h1922.hz, 0.09, 200, dict(max_iter=3, osd_method="osd_cs", osd_order=10)),
+        (big, 0.07, 12, dict(max_iter=4, osd_method="osd_e", osd_order=5)),
+    ):
+        _, syn = _syndromes(H, q, B, 11)
+        syn[0] = 0  # the zero-syndrome shortcut
+        probs = rng.uniform(0.5 * q, 1.5 * q, H.shape[1])
+        for channel in (dict(error_rate=q), dict(channel_probs=probs)):
+            full = dict(bp_method=bp_method, ms_scaling_factor=0.0, schedule="serial", ps_clip=15.0 if bp_method == "ps" else 0.0,
+                        **kw, **channel)
+            g = BpOsdDecoder(H, **full)
+            assert g.schedule == "serial"
+            r = _gpu_decode(g, syn)
+            ref = OracleDecoder(H, ps_math=1, **full).decode_batch(syn)
+            _compare_exact(r, ref)
+            assert r["iters"][0] == 0 and r["converged"][0]
+    # the serial schedule is a different decoder: far fewer sweeps than flooding on the same syndromes
+    _, syn = _syndromes(h1922.hz, 0.05, 256, 2)
+    base = dict(error_rate=0.05, max_iter=0, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_cs", osd_order=7)
+    a = _gpu_decode(BpOsdDecoder(h1922.hz, schedule="serial", **base), syn, want_llr=False)
+    b = _gpu_decode(BpOsdDecoder(h1922.hz, schedule="parallel", **base), syn, want_llr=False)
+    assert a["iters"].mean() < 0.5 * b["iters"].mean()
+
+
+def test_received_vector_input(gpu_ready, hgp400, surface13):
+    """input_vector_type="received_vector" (ldpc's classical-decoding mode; "auto" decides by length): the decoder is
+    handed r, decodes the syndrome H r and returns r + correction; attributes keep the error estimate."""
+    from bp_osd_amd import BpOsdDecoder, bposd_decoder
+
+    H = hgp400.hx
+    m, n = H.shape
+    kw = dict(error_rate=0.06, max_iter=8, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_cs", osd_order=5)
+    err, syn = _syndromes(H, 0.06, 64, 9)
+    ref = BpOsdDecoder(H, **kw)
+    want = ref.decode_batch(syn).copy()
+    for ivt in ("received_vector", "auto"):
+        dec = BpOsdDecoder(H, input_vector_type=ivt, omp_thread_count=4, **kw)
+        assert dec.input_vector_type == ivt and dec.omp_thread_count == 4
+        got = dec.decode_batch(err)                  # the error pattern itself is a received vector of the zero codeword
+        assert (got == (err ^ want)).all() and (dec.batch_osdw == want).all()
+        assert (_syndrome_of(H, got) == 0).all()     # what comes back is a codeword
+        one = dec.decode(err[3].astype(np.int64))
+        assert one.dtype == np.int64 and (one == (err[3] ^ want[3])).all() and (dec.osdw_decoding == want[3]).all()
+    # "auto" with a syndrome-length input stays syndrome decoding; the legacy class takes the ldpc v1 integer codes
+    assert (BpOsdDecoder(H, input_vector_type="auto", **kw).decode_batch(syn) == want).all()
+    leg = bposd_decoder(H, input_vector_type=1, osd_method="osd_cs", osd_order=5, error_rate=0.06, max_iter=8, bp_method="ms",
+                        ms_scaling_factor=0.0)
+    assert (leg.decode(err[5]) == (err[5] ^ want[5])).all()
+    with pytest.raises(ValueError):
+        BpOsdDecoder(H, input_vector_type="received_vector", **kw).decode(syn[0])   # wrong length for a received vector

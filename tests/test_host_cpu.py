@@ -63,7 +63,8 @@ def test_product_path_never_imports_oracle():
     (dict(error_rate=0.05, osd_method="osd_x"), ValueError),
     (dict(), ValueError),  # neither error_rate nor channel_probs
     (dict(channel_probs=[0.1, 0.2]), ValueError),  # wrong length
-    (dict(error_rate=0.05, schedule="serial"), ValueError),
+    (dict(error_rate=0.05, schedule="layered"), ValueError),
+    (dict(error_rate=0.05, input_vector_type="codeword"), ValueError),
     (dict(error_rate=0.05, max_iter=-1), ValueError),
     (dict(error_rate=1.5), ValueError),
     (dict(error_rate=0.05, bogus=1), TypeError),
