@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "bposd_info",
     "bposd_layout_info",
     "bposd_set_bp_variant",
+    "bposd_debug_local_layout",
     "bposd_last_error",
     "bposd_destroy",
 )
@@ -115,6 +116,8 @@ def load():
     lib.bposd_info.restype = C.c_int
     lib.bposd_layout_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.bposd_layout_info.restype = C.c_int
+    lib.bposd_debug_local_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
+    lib.bposd_debug_local_layout.restype = C.c_int
     lib.bposd_set_bp_variant.argtypes = [vp, C.c_int32]
     lib.bposd_set_bp_variant.restype = C.c_int
     lib.bposd_last_error.argtypes = [vp]

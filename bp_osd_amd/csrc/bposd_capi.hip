@@ -672,6 +672,107 @@ void class_sorted(const Graph& g, Layout& L) {
         for (int c : left[k]) { L.pos_chk[p] = c; L.pos_of[c] = p; ++p; }
 }
 
+
+// Class rebalancing.  A check's class is the pair (rank of the check among its first owned bit's three checks, the same
+// for the second), sorted: six classes.  A 64-position group runs select-free code only if all its checks share one
+// class, so the number of groups a layout needs is  sum over classes of ceil(size / 64);  whatever does not fit ends up
+// in "mixed" groups, and the waves of mixed groups are the ones every barrier waits for.  The assignment (which check
+// owns which two of its six bits) has plenty of freedom: this search moves bits between checks along short alternating
+// cycles (bit i: c -> c', a bit of c' moves on, ... until a bit arrives at c) and keeps a move when the group count does
+// not grow, until the classes pack into the available groups.
+inline int groups_needed(const int cnt[9]) {
+    int g = 0;
+    for (int k = 0; k < 9; ++k) g += (cnt[k] + 63) / 64;
+    return g;
+}
+
+inline bool rebalance_classes(const Graph& g, Layout& L, int G, int max_moves, bool sideways) {
+    const int m = g.m;
+    auto key = [&](int c) {
+        int a = g.rank_of(L.load[2 * c], c), b = g.rank_of(L.load[2 * c + 1], c);
+        if (a > b) std::swap(a, b);
+        return a * 3 + b;
+    };
+    int cnt[9] = {0};
+    for (int c = 0; c < m; ++c) cnt[key(c)]++;
+    int F = groups_needed(cnt);
+    unsigned long long rs = 0x2545F4914F6CDD1Dull;
+    auto rnd = [&](int mod) {
+        rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17;
+        return (int)((rs >> 11) % (unsigned long long)mod);
+    };
+    auto replace_bit = [&](int c, int oldb, int newb) {
+        if (L.load[2 * c] == oldb) L.load[2 * c] = newb; else L.load[2 * c + 1] = newb;
+    };
+    // secondary objective (ties of F): fewer checks outside the two largest classes -> keeps the search moving
+    auto slack = [&]() {
+        int s2 = 0;
+        for (int k = 0; k < 9; ++k) s2 += cnt[k] % 64 == 0 ? 0 : 64 - cnt[k] % 64;
+        return s2;
+    };
+    int S = slack();
+    std::vector<int> path_chk, path_bit;
+    for (int mv = 0; mv < max_moves && F > G; ++mv) {
+        // alternating cycle c0 -b0-> c1 -b1-> ... -> c0 : bit b_t leaves c_t for c_{t+1}
+        const int c0 = rnd(m);
+        path_chk.assign(1, c0);
+        path_bit.clear();
+        bool closed = false;
+        int cur = c0;
+        for (int depth = 0; depth < 6 && !closed; ++depth) {
+            const int b = L.load[2 * cur + rnd(2)];
+            if (std::find(path_bit.begin(), path_bit.end(), b) != path_bit.end()) break;
+            // b goes to one of its other checks; prefer closing the cycle
+            int o[2];
+            g.others(b, cur, o);
+            int nxt = -1;
+            if (depth > 0 && (o[0] == c0 || o[1] == c0)) nxt = c0;
+            else nxt = o[rnd(2)];
+            if (nxt != c0 && std::find(path_chk.begin(), path_chk.end(), nxt) != path_chk.end()) break;
+            path_bit.push_back(b);
+            if (nxt == c0) closed = true;
+            else { path_chk.push_back(nxt); cur = nxt; }
+        }
+        if (!closed || path_bit.size() < 2) continue;
+        const size_t len = path_bit.size();  // checks path_chk[0..len-1], bit t moves path_chk[t] -> path_chk[(t+1) % len]
+        int before[8], after_[8];
+        for (size_t t = 0; t < len; ++t) before[t] = key(path_chk[t]);
+        for (size_t t = 0; t < len; ++t) {
+            const int from = path_chk[t], to = path_chk[(t + 1) % len];
+            // `to` receives path_bit[t] in place of the bit it gives away (path_bit[(t+1) % len])
+            replace_bit(to, path_bit[(t + 1) % len], -2 - (int)t);  // placeholder keeps slots distinct
+            (void)from;
+        }
+        for (size_t t = 0; t < len; ++t) {
+            const int to = path_chk[(t + 1) % len];
+            replace_bit(to, -2 - (int)t, path_bit[t]);
+            L.owner[path_bit[t]] = to;
+        }
+        for (size_t t = 0; t < len; ++t) { after_[t] = key(path_chk[t]); cnt[before[t]]--; }
+        for (size_t t = 0; t < len; ++t) cnt[after_[t]]++;
+        const int F2 = groups_needed(cnt), S2 = slack();
+        if (F2 < F || (F2 == F && (S2 < S || (sideways && (S2 == S || rnd(8) == 0))))) { F = F2; S = S2; continue; }
+        // undo
+        for (size_t t = 0; t < len; ++t) { cnt[after_[t]]--; }
+        for (size_t t = 0; t < len; ++t) { cnt[before[t]]++; }
+        for (size_t t = 0; t < len; ++t) {
+            const int to = path_chk[(t + 1) % len];
+            replace_bit(to, path_bit[t], -2 - (int)t);
+        }
+        for (size_t t = 0; t < len; ++t) {
+            const int to = path_chk[(t + 1) % len];
+            replace_bit(to, -2 - (int)t, path_bit[(t + 1) % len]);
+            L.owner[path_bit[(t + 1) % len]] = to;
+        }
+    }
+    if (getenv("BPOSD_DEBUG_OCC")) {
+        fprintf(stderr, "[bposd] class rebalancing: groups needed %d (available %d), classes", F, G);
+        for (int k = 0; k < 9; ++k) fprintf(stderr, " %d", cnt[k]);
+        fprintf(stderr, "\n");
+    }
+    return F <= G;
+}
+
 }  // namespace local_layout
 
 // Every check owns two of its six bits; positions are chosen so that (a) as many 64-position groups as possible
@@ -681,21 +782,18 @@ void class_sorted(const Graph& g, Layout& L) {
 // layout (simulated passes + 5 * mixed (group, slot) pairs) is then searched under the uniformity constraint.
 // (A row layout of the circulant grid is conflict-free -- 128 passes for 128 accesses -- but the wrap-around makes
 // every group mixed, and measured on the GPU a mixed pair costs as much as five extra passes: 36.3 ms against 29.8.)
-int build_tables_local(bposd_handle* h) {
+// Host-only part: ownership assignment + positions for a (3,6)-regular code with n = 2m (rp / ci: CSR of the pcm).
+// Returns false when no perfect assignment exists.
+static bool local_layout_host(const std::vector<int>& rp, const std::vector<int>& ci, int m, int n, int MP,
+                              local_layout::Graph& g, local_layout::Layout& best) {
     using namespace local_layout;
-    h->local_ok = false;
-    const int m = h->m, n = h->n;
-    if (!(h->regular && h->dc_max == 6 && h->dv_max == 3 && n == 2 * m)) return 0;
-    const int MP = m <= 1024 ? 1024 : 2048;  // the kernels are compiled for 1024 (H1922: 961 checks) and 2048 positions
-    if (m > MP) return 0;
-    Graph g;
     g.m = m; g.n = n; g.MP = MP;
     g.cols.assign(3 * (size_t)n, 0);
     {
         std::vector<int> fill(n, 0);
         for (int c = 0; c < m; ++c)
-            for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
-                const int i = h->ci[e];
+            for (int e = rp[c]; e < rp[c + 1]; ++e) {
+                const int i = ci[e];
                 g.cols[3 * (size_t)i + fill[i]++] = c;
             }
     }
@@ -728,15 +826,15 @@ int build_tables_local(bposd_handle* h) {
             return false;
         };
         for (int i = 0; i < n; ++i)
-            if (!place(i, i)) return 0;  // no perfect assignment: the LDS kernel is used
+            if (!place(i, i)) return false;  // no perfect assignment: the LDS kernel is used
         for (int c = 0; c < m; ++c)
-            if (cnt(c) != 2) return 0;
+            if (cnt(c) != 2) return false;
         cands.push_back(L);
     }
     bool two_block = true;
     for (int c = 0; c < m && two_block; ++c) {
         int lo = 0;
-        for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) lo += h->ci[e] < n / 2;
+        for (int e = rp[c]; e < rp[c + 1]; ++e) lo += ci[e] < n / 2;
         two_block = (lo == 3);
     }
     // ---- (2) rank-preference block matchings
@@ -773,18 +871,52 @@ int build_tables_local(bposd_handle* h) {
                 cands.push_back(L);
             }
     }
-    // class-sorted start for (1) and (2); rank them by a short search and finish the best
-    Layout best;
+    // every candidate also in a class-rebalanced version (all groups uniform, if the classes can be made to pack)
     {
-        int bi = -1;
+        const size_t n0 = cands.size();
+        for (size_t k = 0; k < n0; ++k)
+            for (int sideways = 0; sideways < 2; ++sideways) {  // strictly improving moves first: they disturb the structure least
+                Layout R = cands[k];
+                if (rebalance_classes(g, R, MP / 64, 100000, sideways != 0)) { cands.push_back(R); break; }
+            }
+    }
+    // class-sorted start for every candidate; rank them by the cost of the start layout -- simulated passes + MIXW per
+    // mixed (group, slot) pair -- and finish the best three with the full position search
+    {
+        double mixw = 5.0;  // exchange rate passes <-> mixed pairs (measured, DESIGN.md "BP kernels"); BPOSD_MIXW overrides
+        if (const char* e = getenv("BPOSD_MIXW")) mixw = atof(e);
+        auto total = [&](const Layout& L) { return (double)L.passes + mixw * (L.cost - (double)L.passes) / 5.0; };
+        std::vector<std::pair<double, size_t>> rank;
         for (size_t k = 0; k < cands.size(); ++k) {
             class_sorted(g, cands[k]);
             search(g, cands[k], true, 0);  // cost of the start layout
-            if (bi < 0 || cands[k].cost < cands[bi].cost) bi = (int)k;
+            rank.push_back({total(cands[k]), k});
         }
-        best = cands[bi];
-        search(g, best, true, 400000);
+        std::sort(rank.begin(), rank.end());
+        bool have = false;
+        const size_t nfinish = getenv("BPOSD_LAYOUT_ALL") ? rank.size() : 3;
+        for (size_t q = 0; q < rank.size() && q < nfinish; ++q) {
+            Layout L = cands[rank[q].second];
+            search(g, L, true, getenv("BPOSD_LAYOUT_ITERS") ? atoi(getenv("BPOSD_LAYOUT_ITERS")) : 400000);
+            if (getenv("BPOSD_DEBUG_OCC"))
+                fprintf(stderr, "[bposd] candidate %zu: %lld passes, %d mixed pairs\n", rank[q].second, L.passes,
+                        (int)((L.cost - (double)L.passes) / 5.0 + 0.5));
+            if (!have || total(L) < total(best)) { best = L; have = true; }
+        }
     }
+    return true;
+}
+
+int build_tables_local(bposd_handle* h) {
+    using namespace local_layout;
+    h->local_ok = false;
+    const int m = h->m, n = h->n;
+    if (!(h->regular && h->dc_max == 6 && h->dv_max == 3 && n == 2 * m)) return 0;
+    const int MP = m <= 1024 ? 1024 : 2048;  // the kernels are compiled for 1024 (H1922: 961 checks) and 2048 positions
+    if (m > MP) return 0;
+    Graph g;
+    Layout best;
+    if (!local_layout_host(h->rp, h->ci, m, n, MP, g, best)) return 0;
     if (getenv("BPOSD_DEBUG_OCC"))
         fprintf(stderr, "[bposd] local-edge layout: %lld simulated LDS passes for %d accesses, cost %.1f, %d uniform positions\n",
                 best.passes, 4 * (MP / 32), best.cost, best.nfull);
@@ -897,6 +1029,8 @@ int launch_bp_local(bposd_handle* h, const BpParams& P) {
     if ((h->bp_variant == 22 || h->bp_variant == 0) && uprior) return launch_bp_local_t<2, 1024, 8, false, true>(h, L);  // <= 64 VGPRs: 4 workgroups per CU
     if (h->bp_variant == 23 && uprior) return launch_bp_local_t<2, 1024, 6, true, true>(h, L);
     if (h->bp_variant == 24 && uprior) return launch_bp_local_t<2, 1024, 6, false, true>(h, L);
+    if (h->bp_variant == 25 && uprior) return launch_bp_local_t<2, 1024, 8, true, true>(h, L);   // 22 with early check-pass loads
+    if (h->bp_variant == 26 && uprior) return launch_bp_local_t<1, 1024, 8, false, true>(h, L);  // 18 with the scalar prior
     return launch_bp_local_t<2, 1024, 6, false>(h, L);                            // 512 threads, <= 80 VGPRs: 3 workgroups per CU
 }
 
@@ -1467,8 +1601,8 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 24))
-        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes) or 16 .. 24 (local-edge kernel)");
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26))
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes) or 16 .. 26 (local-edge kernel)");
     if (variant >= 16 && !(h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM))
         return fail(h, BPOSD_ERR_UNSUPPORTED, "the local-edge BP kernel needs a (3,6)-regular code with n = 2m and min-sum");
     h->bp_variant = variant;
@@ -1873,6 +2007,48 @@ int bposd_lane_timing(bposd_handle* h, int32_t lane, double* bp_ms, double* osd_
     HIP_TRY(h, dev_guard.err);
     HIP_TRY(h, hipStreamSynchronize(h->lanes[lane].stream));
     return record_timing(h, &h->lane_rec[lane], 1, bp_ms, osd_ms, bp_iterations, osd_invocations);
+}
+
+int bposd_debug_local_layout(const int32_t* indptr, const int32_t* indices, int32_t m, int32_t n, int64_t* out) {
+    // host-only: the ownership / position layout the local-edge BP kernel would use for this pcm.
+    // out[0] simulated LDS passes, out[1] ideal passes, out[2] positions in uniform groups, out[3] mixed (group, slot) pairs,
+    // out[4] positions MP, out[5..13] class sizes
+    if (!indptr || !indices || !out || n != 2 * m) return BPOSD_ERR_INVALID;
+    std::vector<int> rp(indptr, indptr + m + 1), ci(indices, indices + indptr[m]);
+    const int MP = m <= 1024 ? 1024 : 2048;
+    if (m > MP) return BPOSD_ERR_UNSUPPORTED;
+    for (int c = 0; c < m; ++c)
+        if (rp[c + 1] - rp[c] != 6) return BPOSD_ERR_UNSUPPORTED;
+    std::vector<int> deg(n, 0);
+    for (int e : ci) {
+        if (e < 0 || e >= n) return BPOSD_ERR_INVALID;
+        deg[e]++;
+    }
+    for (int i = 0; i < n; ++i)
+        if (deg[i] != 3) return BPOSD_ERR_UNSUPPORTED;
+    local_layout::Graph g;
+    local_layout::Layout best;
+    if (!local_layout_host(rp, ci, m, n, MP, g, best)) return BPOSD_ERR_UNSUPPORTED;
+    int mixed = 0;
+    for (int gq = 0; gq < MP / 64; ++gq)
+        for (int b = 0; b < 2; ++b) {
+            int code = -1;
+            for (int p = 64 * gq; p < 64 * gq + 64; ++p) {
+                const int c = best.pos_chk[p];
+                if (c < 0) continue;
+                const int d = g.rank_of(best.load[2 * c + b], c);
+                code = (code < 0 || code == d) ? d : 3;
+            }
+            mixed += code == 3;
+        }
+    out[0] = best.passes; out[1] = 4 * (MP / 32); out[2] = best.nfull; out[3] = mixed; out[4] = MP;
+    for (int k = 0; k < 9; ++k) out[5 + k] = 0;
+    for (int c = 0; c < m; ++c) {
+        int a = g.rank_of(best.load[2 * c], c), b = g.rank_of(best.load[2 * c + 1], c);
+        if (a > b) std::swap(a, b);
+        out[5 + a * 3 + b]++;
+    }
+    return BPOSD_OK;
 }
 
 void* bposd_host_alloc(size_t bytes) {
