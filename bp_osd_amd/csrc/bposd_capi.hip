@@ -184,6 +184,17 @@ int ensure(bposd_handle* h, DevBuf& b, size_t bytes) {
     return 0;
 }
 
+// Workspaces are per lane; when one has to grow, the same buffer of every lane this handle cycles through grows with it,
+// so that the allocation (and the page mapping behind it) is paid by the first call of a size class, not by the first
+// call that happens to land on each lane.
+int ensure_lanes(bposd_handle* h, DevBuf Lane::*member, size_t bytes) {
+    for (int l = 0; l < h->nlanes; ++l) {
+        int rc = ensure(h, h->lanes[l].*member, bytes);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 void release(DevBuf& b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
@@ -1000,7 +1011,7 @@ int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
     wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
     long long grid = std::min<long long>(L.B, (long long)h->num_cu * wg_per_cu);
     if (grid < 1) grid = 1;
-    int rc = ensure(h, h->cur->bpl_llr, sizeof(double) * (size_t)grid * h->n);
+    int rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n);
     if (rc) return rc;
     BpLocalParams Lq = L;
     Lq.llr_tmp = (double*)h->cur->bpl_llr.p;
@@ -1067,8 +1078,8 @@ int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
     const int wg_per_cu = std::max<int>(1, std::min<size_t>(4, h->lds_per_cu / lds));
     const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
     int rc;
-    if ((rc = ensure(h, h->cur->bpl_msg, sizeof(double) * (size_t)grid * DC * P.mp))) return rc;
-    if ((rc = ensure(h, h->cur->bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
+    if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * DC * P.mp))) return rc;
+    if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
     P.msg_ws = (double*)h->cur->bpl_msg.p;
     P.llr_tmp = (double*)h->cur->bpl_llr.p;
     if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
@@ -1146,8 +1157,8 @@ int launch_bp_serial(bposd_handle* h, const BpParams& P) {
     const int wg_per_cu = std::max<int>(1, std::min<size_t>(8, h->lds_per_cu / std::max<size_t>(lds, 1)));
     const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
     int rc;
-    if ((rc = ensure(h, h->cur->bpl_msg, sizeof(double) * (size_t)grid * h->E))) return rc;
-    if ((rc = ensure(h, h->cur->bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
+    if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * h->E))) return rc;
+    if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
     S.msg_ws = (double*)h->cur->bpl_msg.p;
     S.llr_tmp = (double*)h->cur->bpl_llr.p;
     HIP_TRY(h, hipFuncSetAttribute((const void*)bp_serial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1165,7 +1176,7 @@ int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
     const size_t lds = osd_lds_bytes(W, NT * OSD_RPT);
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
-    int rc = ensure(h, h->cur->osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
+    int rc = ensure_lanes(h, &Lane::osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
     if (rc) return rc;
     OsdParams Q = P;
     Q.rows_ws = (unsigned long long*)h->cur->osd_rows_ws.p;
@@ -1239,7 +1250,7 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
                              g * sizeof(int) * (size_t)Q.mrl};                               // alist
     size_t total = 0;
     for (size_t b : sizes) total += a256(b);
-    int rc = ensure(h, h->cur->osdl_ws, total);
+    int rc = ensure_lanes(h, &Lane::osdl_ws, total);
     if (rc) return rc;
     unsigned char* ptrs[14];
     {
@@ -1675,8 +1686,8 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF;
     int rc;
     if (osd_on) {
-        if ((rc = ensure(h, h->cur->llr_ws, sizeof(double) * (size_t)B * h->n))) return rc;
-        if ((rc = ensure(h, h->cur->osd_list, sizeof(int) * (size_t)B))) return rc;
+        if ((rc = ensure_lanes(h, &Lane::llr_ws, sizeof(double) * (size_t)B * h->n))) return rc;
+        if ((rc = ensure_lanes(h, &Lane::osd_list, sizeof(int) * (size_t)B))) return rc;
     }
     HIP_TRY(h, hipMemsetAsync(h->cur->d_counters, 0, 32, h->cur->stream));
 
