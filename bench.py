@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gather")
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (no overlap of consecutive steps)")
     ap.add_argument("--max-iter", type=int, default=-1, help="override max_iter (diagnostics; -1 = the config's)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal where only one GPU exists: every rank decodes on device 0 and the gather runs over "
+                         "gloo on host copies of the packed rows (same StepPipeline, same JSON; not a measurement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -185,10 +188,15 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from bp_osd_amd import BpOsdDecoder
     from bp_osd_amd.sharding import StepPipeline
@@ -209,6 +217,8 @@ def main():
     wpr = (n + 63) // 64
     do_gather = world > 1 and not args.no_gather
     d_packed = [torch.empty((B, wpr), dtype=torch.int64, device=dev) for _ in range(2)] if do_gather else None
+    # (rehearsal on one GPU: gloo moves host tensors, so the packed rows are copied to the host before the gather)
+    x_packed = [torch.empty((B, wpr), dtype=torch.int64) for _ in range(2)] if (do_gather and args.rehearse_on_one_gpu) else d_packed
     stats = {"bp_ms": [], "osd_ms": [], "iters": 0, "osd": 0}
     lane_of_slot = {}
 
@@ -225,6 +235,8 @@ def main():
         dec.synchronize(lane_of_slot[slot])
 
     def on_finalised(k, timed):
+        if do_gather and args.rehearse_on_one_gpu:
+            x_packed[k & 1].copy_(d_packed[k & 1])
         if timed:
             t = dec.lane_timing(lane_of_slot[k % nslots])  # HIP events on the lane's own stream
             stats["bp_ms"].append(t["bp_ms"])
@@ -232,7 +244,7 @@ def main():
             stats["iters"] += t["bp_iterations"]
             stats["osd"] += t["osd_invocations"]
 
-    pipe = StepPipeline(nslots, launch, wait, pack=pack, packed=d_packed, rows=B, gather=do_gather, on_finalised=on_finalised)
+    pipe = StepPipeline(nslots, launch, wait, pack=pack, packed=x_packed, rows=B, gather=do_gather, on_finalised=on_finalised)
     for k in range(args.warmup):
         pipe.step(k, False)
     pipe.fence()
@@ -244,7 +256,7 @@ def main():
     bp_ms, osd_ms, iters_tot, osd_tot = stats["bp_ms"], stats["osd_ms"], stats["iters"], stats["osd"]
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
