@@ -20,9 +20,9 @@
 //          LLR, bit index) -- a strict total order, so the result equals a stable sort.
 //   2. a9  blocked Gauss-Jordan, panels of 64 columns (one register word):
 //          (i) panel phase, one barrier per PIVOT: every wave proposes its lowest column
-//          that still has a candidate row (wave-min by ballot binary search) together with
-//          that row's panel word and combination mask; after the barrier the lowest
-//          proposal wins (skipped columns are non-pivot); every row with a 1 in the column XORs the
+//          that still has a candidate row (wave-min of a (column, row) key on the DPP path) together
+//          with that row's panel word and combination mask; after the barrier the lowest
+//          key wins (skipped columns are non-pivot); every row with a 1 in the column XORs the
 //          pivot's panel word and records the pivot in its own 64-bit combination mask t
 //          (row = row_at_panel_start ^ XOR_{q in t} pivot_q_at_panel_start);
 //          (ii) trailing phase, once per panel: the <= 64 pivot rows publish their
@@ -56,6 +56,7 @@ constexpr int OSD_MAXW = 8;     // max waves per workgroup (512 threads)
 #define OSD_CHUNK 8
 #endif
 constexpr int OSD_MAXCV = 16;   // max ballot words per column vector (RPT * waves)
+static_assert(OSD_RPT <= 2 && OSD_MAXW <= 8, "panel keys carry one bit of row slot and nine bits of thread id");
 
 struct OsdParams {
     int m, n;
@@ -100,11 +101,38 @@ __device__ __forceinline__ unsigned long long llr_sort_key(double x) {
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
+// Minimum of a 32-bit value over the 64 lanes of a wave, returned wave-uniform: an xor / rotate butterfly inside each row
+// of 16 lanes on the DPP path (every source lane is valid, so no identity value is involved), then the four row results
+// through SGPRs.
+__device__ __forceinline__ unsigned int osd_wave_min_u32(unsigned int v) {
+    // (s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states)
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
+    const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 0);
+    const unsigned int r1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned int r2 = (unsigned int)__builtin_amdgcn_readlane((int)v, 32);
+    const unsigned int r3 = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned int a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+
+// Lowest set bit of a 64-bit word, 64 if there is none: v_ffbl_b32 returns ~0 for a zero input, the saturating add keeps
+// that above 64, one v_min3 finishes.
+__device__ __forceinline__ unsigned int osd_ffs64_or_64(unsigned long long x) {
+    unsigned int lo, hi;
+    asm("v_ffbl_b32 %0, %1" : "=v"(lo) : "v"((unsigned int)x));
+    asm("v_ffbl_b32 %0, %1" : "=v"(hi) : "v"((unsigned int)(x >> 32)));
+    asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(hi) : "v"(hi));
+    return min(min(lo, hi), 64u);
+}
+
 // LDS carve-up, all offsets 8-byte aligned
 struct OsdLds {
     unsigned long long* keys;     // [nsort]; after the sort: first 128 B reused as T-index -> position
     unsigned long long* pbuf;     // [2][OSD_MAXW][2]  (panel word, mask) of each wave's proposed pivot row
-    unsigned int* pcol;           // [2][OSD_MAXW]     proposed pivot column of each wave (64 = none)
+    unsigned int* pcol;           // [2][OSD_MAXW]     key (column << 10 | row slot << 9 | thread) of each wave's proposal
     unsigned long long* prow;     // [64][W]   trailing words of this panel's pivots
     unsigned long long* tab;      // [16][W][16] XOR combinations of 4 pivots
     unsigned long long* colvec;   // [64][OSD_MAXCV]
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         L.tab = L.prow + (size_t)64 * W;
         L.colvec = L.tab + (size_t)16 * W * 16;
     }
-    if (tid < 2 * OSD_MAXW) L.pcol[tid] = 64u;  // slots of waves that do not exist never propose
+    if (tid < 2 * OSD_MAXW) L.pcol[tid] = ~0u;  // slots of waves that do not exist never propose
     for (;;) {
         if (tid == 0) L.misc[0] = atomicAdd(&P.counters[2], 1);
         __syncthreads();
@@ -268,12 +296,13 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         // ------------------------------------------------------- a9: blocked Gauss-Jordan
         const int MR = NT * RPT;  // padded row count of the spill layout
         unsigned long long* ws = P.rows_ws + (size_t)blockIdx.x * W * MR;  // [W][MR], word-major: coalesced
-        bool used[RPT];
-        int mypos[RPT];
+        // per-row pivot state during the elimination, one register each: ukey = 0 while the row is unused and the
+        // "no candidate" key once it is a pivot row; pinfo = -1, or (sorted position << 6) | pivot index in its panel
+        unsigned int ukey[RPT], kbase[RPT];
+        int pinfo[RPT];
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) { used[k] = false; mypos[k] = -1; }
+        for (int k = 0; k < RPT; ++k) { ukey[k] = 0u; pinfo[k] = -1; kbase[k] = ((unsigned int)k << 9) | (unsigned int)tid; }
         int nrank = 0;
-        int par = 0;  // pbuf double buffer
         bool done = false;
 #ifdef BPOSD_OSD_DIAG
         long long diag_panel = 0, diag_trail = 0, diag_t0 = 0;
@@ -289,81 +318,84 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             diag_t0 = OSD_TICK();
 #endif
             // ---------------- (i) panel phase on the current word row[k][0]: one barrier per PIVOT.
-            // Every wave proposes its lowest column that still has a candidate (an unused row with a 1);
-            // the lowest proposal over all waves is the next pivot column -- the columns skipped in
-            // between have no candidate anywhere, i.e. they are non-pivot.  Unused rows are zero in
-            // every column already passed, so no "columns >= b" masking is needed, only "columns < n".
+            // Every thread forms a key (lowest candidate column, row slot) for each of its rows -- a candidate is an
+            // unused row with a 1 -- and the wave takes the minimum key with four DPP steps; the lane that owns it
+            // publishes the key and the row's (panel word, mask).  After the barrier the lowest of the <= 8 wave keys
+            // is the next pivot: the columns skipped in between have no candidate anywhere, i.e. they are non-pivot.
+            // Unused rows are zero in every column already passed, so no "columns >= b" masking is needed, only
+            // "columns < n".  The loop control is scalar (keys travel through SGPRs).
             unsigned long long t[RPT];
-            int myq[RPT];
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) { t[k] = 0ull; myq[k] = -1; }
+            for (int k = 0; k < RPT; ++k) t[k] = 0ull;
             int npiv = 0;  // pivots found in this panel (uniform)
-            const int nb = n - w * 64;  // valid columns in this panel
-            const unsigned long long vmask = nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
+            const int nb = n - w * 64;            // valid columns in this panel; the syndrome bit (bit 63 of the last
+            const int nbc = nb < 64 ? nb : 64;    // word) lies beyond them, so "lowest candidate >= nbc" ends the panel
             if (nb <= 0) done = true;
+            // One pivot step; PAR (the proposal double buffer) is a literal so that every LDS address is an immediate.
+#define OSD_PIVOT_STEP(PAR)                                                                                             \
+    {                                                                                                                   \
+        if (nrank >= P.rank) { done = true; goto panel_done; }                                                          \
+        unsigned int key[RPT];                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < RPT; ++k) {                                                               \
+            const unsigned int l = osd_ffs64_or_64(row[k][0]);                                                          \
+            const unsigned int lk = (l << 10) | kbase[k];                                                               \
+            key[k] = lk > ukey[k] ? lk : ukey[k]; /* a pivot row never proposes */                                      \
+        }                                                                                                               \
+        unsigned int mk = key[0];                                                                                       \
+        _Pragma("unroll") for (int k = 1; k < RPT; ++k) mk = key[k] < mk ? key[k] : mk;                                 \
+        const unsigned int wk = osd_wave_min_u32(mk); /* wave-uniform */                                                \
+        if (mk == wk) { /* exactly one lane: keys are distinct */                                                       \
+            unsigned long long pw = 0ull, pt = 0ull;                                                                    \
+            _Pragma("unroll") for (int k = 0; k < RPT; ++k) if (key[k] == wk) { pw = row[k][0]; pt = t[k]; }            \
+            pkw[(PAR) * OSD_MAXW] = wk;                                                                                 \
+            pbw[(PAR) * OSD_MAXW] = make_ulonglong2(pw, pt);                                                            \
+        }                                                                                                               \
+        __syncthreads();                                                                                                \
+        unsigned int g; /* lowest of the <= 8 wave keys (slots of absent waves hold ~0) */                              \
+        {                                                                                                               \
+            const uint4 ka = *reinterpret_cast<const uint4*>(&L.pcol[(PAR) * OSD_MAXW]);                                \
+            const uint4 kb = *reinterpret_cast<const uint4*>(&L.pcol[(PAR) * OSD_MAXW + 4]);                            \
+            const unsigned int g0 = min(min(ka.x, ka.y), min(ka.z, ka.w));                                              \
+            const unsigned int g1 = min(min(kb.x, kb.y), min(kb.z, kb.w));                                              \
+            g = (unsigned int)__builtin_amdgcn_readfirstlane((int)min(g0, g1));                                         \
+        }                                                                                                               \
+        const int mincol = (int)(g >> 10);                                                                              \
+        if (mincol >= nbc) goto panel_done; /* panel exhausted (uniform) */                                             \
+        const ulonglong2 pp = reinterpret_cast<const ulonglong2*>(L.pbuf)[(PAR) * OSD_MAXW + (int)((g >> 6) & 7u)];     \
+        const unsigned int pw_lo = (unsigned int)pp.x, pw_hi = (unsigned int)(pp.x >> 32);                              \
+        const unsigned long long tq = pp.y ^ (1ull << npiv);                                                            \
+        const unsigned int tq_lo = (unsigned int)tq, tq_hi = (unsigned int)(tq >> 32);                                  \
+        const int pj = ((w * 64 + mincol) << 6) | npiv;                                                                 \
+        _Pragma("unroll") for (int k = 0; k < RPT; ++k) {                                                               \
+            const bool is_pivot = key[k] == g;                                                                          \
+            const bool hit = ((row[k][0] >> mincol) & 1ull) != 0ull;                                                    \
+            unsigned int msk = (hit && !is_pivot) ? ~0u : 0u;                                                           \
+            asm volatile("" : "+v"(msk)); /* keep it a register mask: row ^= pivot & msk is one v_bitop3 per half */    \
+            unsigned int rlo = (unsigned int)row[k][0], rhi = (unsigned int)(row[k][0] >> 32);                          \
+            unsigned int tlo = (unsigned int)t[k], thi = (unsigned int)(t[k] >> 32);                                    \
+            rlo ^= pw_lo & msk; rhi ^= pw_hi & msk;                                                                     \
+            tlo ^= tq_lo & msk; thi ^= tq_hi & msk;                                                                     \
+            row[k][0] = ((unsigned long long)rhi << 32) | rlo;                                                          \
+            t[k] = ((unsigned long long)thi << 32) | tlo;                                                               \
+            ukey[k] = is_pivot ? ((64u << 10) | kbase[k]) : ukey[k];                                                    \
+            pinfo[k] = is_pivot ? pj : pinfo[k];                                                                        \
+        }                                                                                                               \
+        ++npiv;                                                                                                         \
+        ++nrank;                                                                                                        \
+    }
+            {
+                unsigned int* const pkw = L.pcol + wave;
+                ulonglong2* const pbw = reinterpret_cast<ulonglong2*>(L.pbuf) + wave;
 #pragma clang loop unroll(disable)
-            for (;;) {
-                if (nrank >= P.rank) { done = true; break; }
-                // my lowest candidate column (64 = none) and the slot it lives in
-                int lb = 64, kb = 0;
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    const unsigned long long cw = used[k] ? 0ull : (row[k][0] & vmask);
-                    const int l = cw ? (__ffsll((long long)cw) - 1) : 64;
-                    if (l < lb) { lb = l; kb = k; }
+                for (;;) {
+                    OSD_PIVOT_STEP(0)
+                    OSD_PIVOT_STEP(1)
                 }
-                // wave minimum of lb by a 7-step ballot binary search (values 0..64)
-                unsigned long long act = ~0ull;
-                int col = 0;
-#pragma unroll
-                for (int bitp = 6; bitp >= 0; --bitp) {
-                    const unsigned long long z = __ballot(((lb >> bitp) & 1) == 0) & act;
-                    if (z) act = z; else col |= (1 << bitp);
-                }
-                const int first = __ffsll((long long)act) - 1;  // lowest lane that attains the minimum
-                if (lane == first) {
-                    unsigned long long pw = 0ull, pt = 0ull;
-#pragma unroll
-                    for (int k = 0; k < RPT; ++k)
-                        if (k == kb) { pw = row[k][0]; pt = t[k]; }
-                    L.pcol[par * OSD_MAXW + wave] = (unsigned int)col;
-                    L.pbuf[(size_t)(par * OSD_MAXW + wave) * 2 + 0] = pw;
-                    L.pbuf[(size_t)(par * OSD_MAXW + wave) * 2 + 1] = pt;
-                }
-                __syncthreads();
-                // all proposals (static unroll over OSD_MAXW; absent waves hold 64), lowest wave wins ties
-                int mincol = 64, wv = 0;
-                {
-                    unsigned int pc[OSD_MAXW];
-#pragma unroll
-                    for (int q = 0; q < OSD_MAXW; ++q) pc[q] = L.pcol[par * OSD_MAXW + q];
-#pragma unroll
-                    for (int q = OSD_MAXW - 1; q >= 0; --q)
-                        if ((int)pc[q] <= mincol) { mincol = (int)pc[q]; wv = q; }
-                }
-                if (mincol >= 64) { par ^= 1; break; }  // panel exhausted (uniform)
-                const unsigned long long pw_p = L.pbuf[(size_t)(par * OSD_MAXW + wv) * 2 + 0];
-                const unsigned long long t_p = L.pbuf[(size_t)(par * OSD_MAXW + wv) * 2 + 1];
-                const unsigned long long bmask = 1ull << mincol;
-                const unsigned long long qbit = 1ull << npiv;
-                const int j = w * 64 + mincol;
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    const bool is_pivot = (wave == wv) && (lane == first) && (k == kb) && (col == mincol);
-                    if (is_pivot) {
-                        used[k] = true;
-                        mypos[k] = j;
-                        myq[k] = npiv;
-                        L.pivrow[j] = (short)(tid + k * NT);
-                    } else if (row[k][0] & bmask) {
-                        row[k][0] ^= pw_p;
-                        t[k] ^= t_p ^ qbit;
-                    }
-                }
-                ++npiv;
-                ++nrank;
-                par ^= 1;
             }
+        panel_done:
+#undef OSD_PIVOT_STEP
+            // every panel starts on proposal buffer 0: nobody may still be reading this panel's last proposals
+            __syncthreads();
 #ifdef BPOSD_OSD_DIAG
             { const long long t1 = OSD_TICK(); diag_panel += t1 - diag_t0; diag_t0 = t1; }
 #endif
@@ -371,10 +403,11 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             if (nvalid > 0 && npiv > 0) {
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) {
-                    if (myq[k] >= 0) {
+                    if (pinfo[k] >= 0 && (pinfo[k] >> 12) == w) {  // became a pivot row in this panel
+                        const int myq = pinfo[k] & 63;
 #pragma unroll
                         for (int x = 1; x < W; ++x)
-                            if (x <= nvalid) L.prow[myq[k] * W + x] = row[k][x];
+                            if (x <= nvalid) L.prow[myq * W + x] = row[k][x];
                     }
                 }
                 __syncthreads();
@@ -427,6 +460,10 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
 #ifdef BPOSD_OSD_DIAG
         if (P.dbg && tid == 0 && slot_id == 0) { P.dbg[1190] = diag_panel; P.dbg[1191] = diag_trail; P.dbg[1192] = nrank; }
 #endif
+        bool used[RPT];
+        int mypos[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { used[k] = pinfo[k] >= 0; mypos[k] = pinfo[k] >> 6; }
         bool y[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) y[k] = ((ws[(unsigned)((W - 1) * MR + tid + k * NT)] >> 63) & 1ull) != 0ull;
@@ -439,6 +476,9 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             if (lane == 0) L.yvec[k * nwaves + wave] = yb;
         }
         if (tid == 0) { L.best64[0] = ~0ull; L.best64[1] = ~0ull; }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (used[k]) L.pivrow[mypos[k]] = (short)(tid + k * NT);
         __syncthreads();  // also makes every pivrow[] write visible
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
