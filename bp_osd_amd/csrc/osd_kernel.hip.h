@@ -128,6 +128,33 @@ __device__ __forceinline__ unsigned int osd_ffs64_or_64(unsigned long long x) {
     return min(min(lo, hi), 64u);
 }
 
+// A 64-bit value every lane holds alike, moved into SGPRs so that loops over its bits are scalar (readfirstlane returns
+// int: go through unsigned before widening, a set bit 31 must not sign-extend into the high word).
+__device__ __forceinline__ unsigned long long osd_uniform64(unsigned long long x) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32)) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+}
+
+// Bit-sliced addition across lanes: c[0 .. NB-1] are the bits of 32 independent counters (one per bit position); the
+// partner lane's counters arrive through DPP control CTRL (every source lane valid) and the sum has NB + 1 bits.
+template <int CTRL, int NB>
+__device__ __forceinline__ void osd_bs_add(unsigned int (&c)[6]) {
+    unsigned int carry = 0u;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const unsigned int a = c[i];
+        const unsigned int b = (unsigned int)__builtin_amdgcn_update_dpp((int)a, (int)a, CTRL, 0xF, 0xF, false);
+        if (i == 0) {
+            c[0] = a ^ b;
+            carry = a & b;
+        } else {
+            c[i] = a ^ b ^ carry;
+            carry = (a & b) | (carry & (a ^ b));
+        }
+    }
+    c[NB] = carry;
+}
+
 // LDS carve-up, all offsets 8-byte aligned
 struct OsdLds {
     unsigned long long* keys;     // [nsort]; after the sort: first 128 B reused as T-index -> position
@@ -139,7 +166,7 @@ struct OsdLds {
     unsigned long long* yvec;     // [OSD_MAXCV]
     unsigned long long* npmask;   // [W] non-pivot positions per word
     unsigned long long* best64;   // [2]
-    int* wt;                      // [64 * W] weight of the single candidate at each sorted position
+    int* wt;                      // [32 * W] 16-bit weight of the single candidate at each sorted position, two per word
     int* misc;                    // [8]
     unsigned short* kidx;         // [nsort]  -> order[j] after the sort
     short* pivrow;                // [nsort] sorted position -> pivot row, -1 if non-pivot
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             }
             L.pivrow[i] = -1;
         }
-        for (int i = tid; i < 64 * W; i += NT) L.wt[i] = 1;
+        for (int i = tid; i < 32 * W; i += NT) L.wt[i] = 0x00010001;  // 16-bit single-candidate weights, two per word: 1 each
         __syncthreads();
         for (int k = 2; k <= NS; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -506,38 +533,66 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             unsigned long long amask[RPT];  // bit a = my row's entry in the a-th non-pivot column (a < wspan)
 #pragma unroll
             for (int k = 0; k < RPT; ++k) amask[k] = 0ull;
+            if (P.osd_method == 3 && !P.cost) {
+                // ---- singles: the weight of "switch column j on" is 1 + #{pivot rows r : A[r][j] != y[r]}.  All 64
+                // columns of a word are counted at once with bit-sliced counters: a thread adds its two rows, four DPP
+                // steps add up the 16 lanes of a row (2 -> 6 counter bits), every lane unpacks four columns and the
+                // 4 rows x <= 8 waves meet in LDS (two columns per 32-bit atomic).  Pivot columns are counted too and
+                // never read.
+                unsigned short* wt16 = reinterpret_cast<unsigned short*>(L.wt);
+                const int l16 = lane & 15;
+                const unsigned int sh = (unsigned int)(l16 & 7) * 4u;
 #pragma clang loop unroll(disable)
-            for (int w = 0; w < W; ++w) {
-                unsigned long long npm = L.npmask[w];
-                // make the mask wave-uniform for the scalar loop below; readfirstlane returns int, so go
-                // through unsigned before widening (a set bit 31 must not sign-extend into the high word)
-                npm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(npm >> 32)) << 32) |
-                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)npm);
+                for (int w = 0; w < W; ++w) {
+                    unsigned long long npm = L.npmask[w];
+                    if (!osd_uniform64(npm)) continue;  // uniform
+                    unsigned long long v[RPT];
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const unsigned long long rw = ws[(unsigned)(w * MR + tid + k * NT)];  // my own words
+                        v[k] = used[k] ? (y[k] ? ~rw : rw) : 0ull;
+                    }
+                    unsigned int clo[6], chi[6];
+                    clo[0] = (unsigned int)(v[0] ^ v[1]); chi[0] = (unsigned int)((v[0] ^ v[1]) >> 32);
+                    clo[1] = (unsigned int)(v[0] & v[1]); chi[1] = (unsigned int)((v[0] & v[1]) >> 32);
+                    osd_bs_add<0xB1, 2>(clo);  osd_bs_add<0xB1, 2>(chi);    // quad_perm [1,0,3,2]
+                    osd_bs_add<0x4E, 3>(clo);  osd_bs_add<0x4E, 3>(chi);    // quad_perm [2,3,0,1]
+                    osd_bs_add<0x124, 4>(clo); osd_bs_add<0x124, 4>(chi);   // row_ror:4
+                    osd_bs_add<0x128, 5>(clo); osd_bs_add<0x128, 5>(chi);   // row_ror:8
+                    unsigned int packed = 0u;  // byte c = count of column 4 * l16 + c over this row of 16 lanes
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const unsigned int half = (l16 & 8) ? chi[i] : clo[i];
+                        const unsigned int nib = (half >> sh) & 15u;
+                        packed += ((nib * 0x204081u) & 0x01010101u) << i;
+                    }
+                    unsigned int* dst = reinterpret_cast<unsigned int*>(wt16 + w * 64 + 4 * l16);
+                    atomicAdd(dst, (packed & 0xffu) | ((packed & 0xff00u) << 8));
+                    atomicAdd(dst + 1, ((packed >> 16) & 0xffu) | ((packed >> 24) << 16));
+                }
+            }
+            // ---- the first wspan non-pivot columns ("T columns"), transposed: one ballot word per wave and row slot
+#pragma clang loop unroll(disable)
+            for (int w = 0; w < W && tcount < wspan; ++w) {
+                unsigned long long npm = osd_uniform64(L.npmask[w]);
                 if (!npm) continue;  // uniform
                 unsigned long long rw[RPT];
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) rw[k] = ws[(unsigned)(w * MR + tid + k * NT)];  // my own words
-                int acc = 0;  // lane b accumulates the weight contribution of column w*64+b
-                while (npm) {
+                while (npm && tcount < wspan) {
                     const int b = __ffsll((long long)npm) - 1;
                     npm &= npm - 1;
                     const unsigned long long bmask = 1ull << b;
-                    int cnt = 0;
 #pragma unroll
                     for (int k = 0; k < RPT; ++k) {
                         const bool bitv = (rw[k] & bmask) != 0ull;
-                        if (P.osd_method == 3) cnt += __popcll(__ballot(used[k] && (bitv != y[k])));
-                        if (tcount < wspan) {
-                            const unsigned long long cb = __ballot(used[k] && bitv);
-                            if (lane == 0) L.colvec[tcount * OSD_MAXCV + k * nwaves + wave] = cb;
-                            if (bitv) amask[k] |= 1ull << tcount;
-                        }
+                        const unsigned long long cb = __ballot(used[k] && bitv);
+                        if (lane == 0) L.colvec[tcount * OSD_MAXCV + k * nwaves + wave] = cb;
+                        if (bitv) amask[k] |= 1ull << tcount;
                     }
-                    if (lane == b) acc += cnt;
-                    if (tid == 0 && tcount < 64) tpos[tcount] = (unsigned short)(w * 64 + b);
+                    if (tid == 0) tpos[tcount] = (unsigned short)(w * 64 + b);
                     ++tcount;
                 }
-                if (P.osd_method == 3 && acc) atomicAdd(&L.wt[w * 64 + lane], acc);
             }
             __syncthreads();
 #ifdef BPOSD_OSD_DIAG
@@ -684,7 +739,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                 // singles: all k' non-pivot positions, enumeration order == position order
                 for (int j = tid; j < n; j += NT) {
                     if (L.pivrow[j] < 0) {
-                        const unsigned long long key = ((unsigned long long)L.wt[j] << 32) | (unsigned)j;
+                        const unsigned long long key = ((unsigned long long)reinterpret_cast<const unsigned short*>(L.wt)[j] << 32) | (unsigned)j;
                         atomicMin(&L.best64[0], key);
                     }
                 }
