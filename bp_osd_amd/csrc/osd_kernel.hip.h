@@ -160,8 +160,8 @@ struct OsdLds {
     unsigned long long* keys;     // [nsort]; after the sort: first 128 B reused as T-index -> position
     unsigned long long* pbuf;     // [2][OSD_MAXW][2]  (panel word, mask) of each wave's proposed pivot row
     unsigned int* pcol;           // [2][OSD_MAXW]     key (column << 10 | row slot << 9 | thread) of each wave's proposal
-    unsigned long long* prow;     // [64][W]   trailing words of this panel's pivots
-    unsigned long long* tab;      // [16][W][16] XOR combinations of 4 pivots
+    unsigned long long* prow;     // [64][W rounded up to even]   trailing words of this panel's pivots
+    unsigned long long* tab;      // [16][16][W | 1] XOR combinations of 4 pivots: [group][combination][word]
     unsigned long long* colvec;   // [64][OSD_MAXCV]
     unsigned long long* yvec;     // [OSD_MAXCV]
     unsigned long long* npmask;   // [W] non-pivot positions per word
@@ -184,10 +184,13 @@ __host__ __device__ constexpr int osd_nsort(int W) {
     return ns;
 }
 
+// Row stride (in words) of the four-Russians tables [16 groups][16 combinations][stride]: the smallest odd number >= W.
+__host__ __device__ constexpr int osd_tab_stride(int W) { return W | 1; }
+
 // Elimination-phase buffers (prow, tab, colvec) and the fp64-weight tables of the non-uniform-channel
 // path are never live at the same time: they share one union region placed last in the carve-up.
 __host__ __device__ constexpr size_t osd_union_bytes(int nsort, int W, int mr) {
-    const size_t elim = (size_t)64 * W * 8 + (size_t)16 * W * 16 * 8 + (size_t)64 * OSD_MAXCV * 8;
+    const size_t elim = (size_t)64 * ((W + 1) & ~1) * 8 + (size_t)16 * 16 * osd_tab_stride(W) * 8 + (size_t)64 * OSD_MAXCV * 8;
     const size_t fpw = (size_t)mr * 8        // am: per-row entries in the first <= 64 non-pivot columns
                      + (size_t)nsort * 8     // costs
                      + (size_t)nsort * 8     // Mi
@@ -212,8 +215,47 @@ __host__ __device__ constexpr size_t osd_lds_bytes(int W, int mr) {
     b += (size_t)nsort * 2;                     // pivrow
     b += (size_t)nsort * 2;                     // inv
     b += (size_t)nsort;                         // xout
+    b = (b + 15) & ~(size_t)15;                 // the union region is 16-byte aligned (16-byte pivot-row writes)
     b += osd_union_bytes(nsort, W, mr);         // prow | tab | colvec  /  fp64-weight tables
     return b + 64;
+}
+
+// Trailing update of one thread's rows with the four-Russians tables of a panel: for every group of 4 pivots one look-up
+// row (chosen by 4 bits of the row's combination mask) is XORed into the first NCH chunks of OSD_CHUNK trailing words.
+// One straight-line variant per chunk count: a chunk's loads are issued together and waited for one by one.  Words past
+// the live window only ever receive table words that are never read.
+template <int W, int NCH>
+__device__ __forceinline__ void osd_apply_tables(unsigned long long (&row)[OSD_RPT][W], const unsigned long long (&t)[OSD_RPT],
+                                                 const unsigned long long* tab, int ngroups) {
+    static_assert((W - 1 + OSD_CHUNK - 1) / OSD_CHUNK <= 4, "osd_apply_tables is instantiated for up to 4 chunks");
+    constexpr int WS = osd_tab_stride(W);
+    constexpr int NC = NCH < (W - 1 + OSD_CHUNK - 1) / OSD_CHUNK ? NCH : (W - 1 + OSD_CHUNK - 1) / OSD_CHUNK;
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+        for (int k = 0; k < OSD_RPT; ++k) {
+            const int idx = (int)((t[k] >> (4 * g)) & 15ull);
+            // the row's LDS address as one opaque register: every look-up below is then an immediate offset from it
+            typedef const __attribute__((address_space(3))) unsigned long long* lds_cptr;
+            unsigned int addr = (unsigned int)(size_t)(lds_cptr)(tab + (size_t)(g * 16 + idx) * WS);
+            asm volatile("" : "+v"(addr));
+            const lds_cptr tg = (lds_cptr)(size_t)addr;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int x0 = 1 + c * OSD_CHUNK;
+                unsigned long long buf[OSD_CHUNK];
+#pragma unroll
+                for (int i = 0; i < OSD_CHUNK; ++i)
+                    if (x0 + i < W) buf[i] = tg[x0 + i];
+#pragma unroll
+                for (int i = 0; i < OSD_CHUNK; ++i)
+                    if (x0 + i < W) row[k][x0 + i] ^= buf[i];
+                // keep only one chunk's table loads in flight (else all 2 x 31 loads are hoisted and the 2 x 32-word
+                // register window spills)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
 }
 
 template <int W>
@@ -222,6 +264,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
     constexpr int RPT = OSD_RPT;
     const int m = P.m, n = P.n;
     constexpr int NS = osd_nsort(W);
+    constexpr int WS = osd_tab_stride(W);
+    constexpr int PS = (W + 1) & ~1;  // even row stride of prow: pivot rows are published in 16-byte pairs
     const int NT = blockDim.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -245,9 +289,10 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         L.inv = (unsigned short*)p; p += (size_t)NS * 2;
         L.xout = p; p += (size_t)NS;
         // union region (last): elimination buffers ...
+        p = smem + (((size_t)(p - smem) + 15) & ~(size_t)15);
         L.prow = (unsigned long long*)p;
-        L.tab = L.prow + (size_t)64 * W;
-        L.colvec = L.tab + (size_t)16 * W * 16;
+        L.tab = L.prow + (size_t)64 * PS;
+        L.colvec = L.tab + (size_t)16 * 16 * WS;
     }
     if (tid < 2 * OSD_MAXW) L.pcol[tid] = ~0u;  // slots of waves that do not exist never propose
     for (;;) {
@@ -332,7 +377,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         int nrank = 0;
         bool done = false;
 #ifdef BPOSD_OSD_DIAG
-        long long diag_panel = 0, diag_trail = 0, diag_t0 = 0;
+        long long diag_panel = 0, diag_trail = 0, diag_t0 = 0, diag_pub = 0, diag_build = 0;
 #define OSD_TICK() ((long long)__builtin_amdgcn_s_memtime())
 #endif
 #pragma clang loop unroll(disable)
@@ -433,41 +478,49 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                     if (pinfo[k] >= 0 && (pinfo[k] >> 12) == w) {  // became a pivot row in this panel
                         const int myq = pinfo[k] & 63;
 #pragma unroll
-                        for (int x = 1; x < W; ++x)
-                            if (x <= nvalid) L.prow[myq * W + x] = row[k][x];
+                        for (int x = 0; x < W; x += 2)  // word pairs (word 0 rides along unused): 16-byte writes
+                            if (x <= nvalid)
+                                *reinterpret_cast<ulonglong2*>(&L.prow[myq * PS + x]) = make_ulonglong2(row[k][x], x + 1 < W ? row[k][x + 1] : 0ull);
                     }
                 }
                 __syncthreads();
+#ifdef BPOSD_OSD_DIAG
+                { const long long t1 = OSD_TICK(); diag_pub += t1 - diag_t0; diag_t0 = t1; }
+#endif
+                // Tables of the XOR combinations of 4 pivots, laid out [group][combination][word] with an odd row
+                // stride: a thread owns (group, word), reads the four pivot words once and writes all 16 combinations
+                // (lanes run along the words: conflict-free writes); the look-ups below hit <= 16 different rows at
+                // the same word offset, which the odd stride spreads over different banks.
                 const int ngroups = (npiv + 3) >> 2;
-                for (int e = tid; e < ngroups * 16 * nvalid; e += NT) {
-                    const int g = e / (16 * nvalid);
-                    const int rem = e - g * (16 * nvalid);
-                    const int x = 1 + (rem >> 4);
-                    const int idx = rem & 15;
-                    unsigned long long v = 0ull;
+                for (int e = tid; e < ngroups * 32; e += NT) {
+                    const int g = e >> 5;
+                    const int x = 1 + (e & 31);
+                    if (x <= nvalid) {
+                        unsigned long long pv[4];
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        if (((idx >> kk) & 1) && (4 * g + kk) < npiv) v ^= L.prow[(4 * g + kk) * W + x];
-                    L.tab[(g * W + x) * 16 + idx] = v;
+                        for (int kk = 0; kk < 4; ++kk) pv[kk] = (4 * g + kk) < npiv ? L.prow[(4 * g + kk) * PS + x] : 0ull;
+                        unsigned long long* tg = L.tab + (size_t)g * 16 * WS + x;
+                        unsigned long long c[16];
+                        c[0] = 0ull;
+#pragma unroll
+                        for (int idx = 1; idx < 16; ++idx) {
+                            const int low = idx & (-idx);  // lowest set bit: 1, 2, 4, 8
+                            c[idx] = c[idx ^ low] ^ pv[low == 1 ? 0 : low == 2 ? 1 : low == 4 ? 2 : 3];
+                        }
+#pragma unroll
+                        for (int idx = 0; idx < 16; ++idx) tg[idx * WS] = c[idx];
+                    }
                 }
                 __syncthreads();
-#pragma clang loop unroll(disable)
-                for (int g = 0; g < ngroups; ++g) {
-#pragma unroll
-                    for (int k = 0; k < RPT; ++k) {
-                        const int idx = (int)((t[k] >> (4 * g)) & 15ull);
-                        const unsigned long long* tg = L.tab + (size_t)g * W * 16 + idx;
-#pragma unroll
-                        for (int x0 = 1; x0 < W; x0 += OSD_CHUNK) {
-                            if (x0 <= nvalid) {  // uniform
-#pragma unroll
-                                for (int x = x0; x < x0 + OSD_CHUNK && x < W; ++x) row[k][x] ^= tg[x * 16];
-                            }
-                            // keep only one chunk's table loads in flight (else all 2 x 31 loads are
-                            // hoisted and the 2 x 32-word register window spills)
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
+#ifdef BPOSD_OSD_DIAG
+                { const long long t1 = OSD_TICK(); diag_build += t1 - diag_t0; diag_t0 = t1; }
+#endif
+                // one straight-line variant per number of live chunks (uniform), so that no branch cuts the pipeline
+                switch ((nvalid + OSD_CHUNK - 1) / OSD_CHUNK) {
+                    case 1: osd_apply_tables<W, 1>(row, t, L.tab, ngroups); break;
+                    case 2: osd_apply_tables<W, 2>(row, t, L.tab, ngroups); break;
+                    case 3: osd_apply_tables<W, 3>(row, t, L.tab, ngroups); break;
+                    default: osd_apply_tables<W, 4>(row, t, L.tab, ngroups); break;
                 }
             }
 #ifdef BPOSD_OSD_DIAG
@@ -485,7 +538,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         }
         OSD_STAMP(3);
 #ifdef BPOSD_OSD_DIAG
-        if (P.dbg && tid == 0 && slot_id == 0) { P.dbg[1190] = diag_panel; P.dbg[1191] = diag_trail; P.dbg[1192] = nrank; }
+        if (P.dbg && tid == 0 && slot_id == 0) { P.dbg[1190] = diag_panel; P.dbg[1191] = diag_trail; P.dbg[1192] = nrank; P.dbg[1193] = diag_pub; P.dbg[1194] = diag_build; }
 #endif
         bool used[RPT];
         int mypos[RPT];
