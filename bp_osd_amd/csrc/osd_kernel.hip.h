@@ -222,8 +222,9 @@ __host__ __device__ constexpr size_t osd_lds_bytes(int W, int mr) {
 
 // Trailing update of one thread's rows with the four-Russians tables of a panel: for every group of 4 pivots one look-up
 // row (chosen by 4 bits of the row's combination mask) is XORed into the first NCH chunks of OSD_CHUNK trailing words.
-// One straight-line variant per chunk count: a chunk's loads are issued together and waited for one by one.  Words past
-// the live window only ever receive table words that are never read.
+// One straight-line variant per chunk count: a chunk's loads are issued together and waited for one by one (loading a
+// chunk ahead was measured and is no faster: the pass is bound by LDS / VALU throughput, not latency).  Words past the
+// live window only ever receive table words that are never read.
 template <int W, int NCH>
 __device__ __forceinline__ void osd_apply_tables(unsigned long long (&row)[OSD_RPT][W], const unsigned long long (&t)[OSD_RPT],
                                                  const unsigned long long* tab, int ngroups) {
