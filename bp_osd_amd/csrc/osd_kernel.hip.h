@@ -237,7 +237,7 @@ __device__ __forceinline__ void osd_apply_tables(unsigned long long (&row)[OSD_R
         for (int k = 0; k < OSD_RPT; ++k) {
             const int idx = (int)((t[k] >> (4 * g)) & 15ull);
             // the row's LDS address as one opaque register: every look-up below is then an immediate offset from it
-            typedef const __attribute__((address_space(3))) unsigned long long* lds_cptr;
+            typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_cptr;
             unsigned int addr = (unsigned int)(size_t)(lds_cptr)(tab + (size_t)(g * 16 + idx) * WS);
             asm volatile("" : "+v"(addr));
             const lds_cptr tg = (lds_cptr)(size_t)addr;
