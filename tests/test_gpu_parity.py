@@ -1208,3 +1208,37 @@ def test_received_vector_input(gpu_ready, hgp400, surface13):
     assert (leg.decode(err[5]) == (err[5] ^ want[5])).all()
     with pytest.raises(ValueError):
         BpOsdDecoder(H, input_vector_type="received_vector", **kw).decode(syn[0])   # wrong length for a received vector
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,osd", [(1020, 2040, ("osd_cs", 9)), (1020, 2040, ("osd_e", 6)), (700, 1400, ("osd_cs", 12)),
+                                    (330, 1000, ("osd_e", 5)), (96, 700, ("osd_cs", 20)), (40, 120, ("osd_cs", 64))])
+def test_osd_kernel_window_and_workgroup_shapes(gpu_ready, m, n, osd):
+    """The register-resident OSD kernel is compiled per window size (W = 1, 2, 4, 8, 16, 31, 32 words) and launched with
+    64 .. 512 threads: random (<= 4, <= 8)-sparse codes that land on W = 32 with 8 waves, W = 31 with a workgroup that is
+    not a power of two (6 waves), wide short matrices (many non-pivot columns, few waves) and the largest osd_cs order;
+    BP is cut after two iterations so that nearly every shot runs the elimination.  Bit-exact against the oracle."""
+    import scipy.sparse as sp
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    rng = np.random.default_rng(m * 7 + n)
+    rows, cols = [], []
+    for j in range(n):  # every bit in 1 .. 4 checks, then thin out overfull checks
+        for c in rng.choice(m, size=int(rng.integers(1, 5)), replace=False):
+            rows.append(int(c)); cols.append(j)
+    H = sp.csr_matrix((np.ones(len(rows), dtype=np.uint8), (rows, cols)), shape=(m, n))
+    H.data[:] = 1
+    Hd = H.toarray()
+    for c in np.where(Hd.sum(axis=1) > 16)[0]:
+        on = np.where(Hd[c])[0]
+        Hd[c, on[16:]] = 0
+    H = sp.csr_matrix(Hd)
+    q = 0.06
+    _, syn = _syndromes(H, q, 96, 5)
+    kw = dict(error_rate=q, max_iter=2, bp_method="ms", ms_scaling_factor=0.8, osd_method=osd[0], osd_order=osd[1])
+    g = BpOsdDecoder(H, **kw)
+    ref = OracleDecoder(H, **kw).decode_batch(syn)
+    got = _gpu_decode(g, syn)
+    assert (~got["converged"]).mean() > 0.5, "the elimination hardly ran"
+    _compare_exact(got, ref)
