@@ -19,6 +19,8 @@
 #include <cstring>
 #include <string>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "bp_kernel.hip.h"
@@ -73,7 +75,8 @@ struct CallRecord {
     int* h_counters = nullptr;               // pinned: 4 ints
     unsigned long long* h_iter_total = nullptr;  // pinned
     bool ran_osd = false;
-    bool recorded = false;  // the events have been recorded at least once
+    bool recorded = false;  // the counters (and, when timed, the events) have been recorded at least once
+    bool timed = false;     // the three events bracket the kernels of this record (not on the lean small-call path)
 };
 
 struct bposd_handle {
@@ -123,6 +126,8 @@ struct bposd_handle {
     int nlevels = 0;
     int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
     bool have_timing = false;
+    bool async_pending = false;        // a device-pointer call may still be running on some lane
+    hipStream_t osd_now = nullptr;     // stream the OSD kernel of the call being enqueued goes to
     std::string err;
 };
 
@@ -168,6 +173,21 @@ int sync_all_lanes(bposd_handle* h) {
         if (l.stream) HIP_TRY(h, hipStreamSynchronize(l.stream));
         if (l.osd_stream) HIP_TRY(h, hipStreamSynchronize(l.osd_stream));
     }
+    h->async_pending = false;
+    return 0;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel on a device, shared by every handle: it is
+// only ever raised (a handle that needs less launches fine under a larger limit), and the API is called only when it
+// has to be -- it costs microseconds on the one-syndrome path.
+int set_max_lds(bposd_handle* h, const void* kernel, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> limit;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = limit[{h->device, kernel}];
+    if (lds <= cur) return 0;
+    HIP_TRY(h, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    cur = lds;
     return 0;
 }
 
@@ -432,11 +452,11 @@ int launch_bp_t(bposd_handle* h, const BpParams& P, int NT) {
     if (grid < 1) grid = 1;
     if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
         auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 1, MPT>;
-        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
     } else {
         auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 0, MPT>;
-        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
     }
     HIP_TRY(h, hipGetLastError());
@@ -1004,7 +1024,7 @@ int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
     auto k = bp_local_kernel<CPT, MP, MINW, EARLY, UPRIOR>;
     const int nt = MP / CPT;
     const size_t lds = bp_local_lds_bytes(L.mp);
-    HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
     int wg_per_cu = 1;
     HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void*)k, nt, lds));
     if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] local-edge BP kernel: %d threads, %zu B LDS, %d workgroups per CU\n", nt, lds, wg_per_cu);
@@ -1084,11 +1104,11 @@ int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
     P.llr_tmp = (double*)h->cur->bpl_llr.p;
     if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
         auto k = bp_large_kernel<DC, DV, 1>;
-        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->cur->stream, P);
     } else {
         auto k = bp_large_kernel<DC, DV, 0>;
-        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->cur->stream, P);
     }
     HIP_TRY(h, hipGetLastError());
@@ -1161,7 +1181,7 @@ int launch_bp_serial(bposd_handle* h, const BpParams& P) {
     if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
     S.msg_ws = (double*)h->cur->bpl_msg.p;
     S.llr_tmp = (double*)h->cur->bpl_llr.p;
-    HIP_TRY(h, hipFuncSetAttribute((const void*)bp_serial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc_lds = set_max_lds(h, (const void*)bp_serial_kernel, lds); if (rc_lds) return rc_lds; }
     hipLaunchKernelGGL(bp_serial_kernel, dim3((unsigned)grid), dim3(BPS_NT), lds, h->cur->stream, S);
     HIP_TRY(h, hipGetLastError());
     return 0;
@@ -1181,8 +1201,8 @@ int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
     OsdParams Q = P;
     Q.rows_ws = (unsigned long long*)h->cur->osd_rows_ws.p;
     auto k = osd_kernel<W>;
-    HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->osd_stream, Q);
+    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->osd_now ? h->osd_now : h->cur->osd_stream, Q);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }
@@ -1276,8 +1296,8 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
 #define OSDL_LAUNCH(R)                                                                                      \
     case R: {                                                                                               \
         auto k = osd_large_kernel<R>;                                                                       \
-        HIP_TRY(h, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(OSDL_NT), lds, h->cur->osd_stream, Q);                  \
+        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; } \
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(OSDL_NT), lds, h->osd_now ? h->osd_now : h->cur->osd_stream, Q); \
     } break;
     switch (RPT) {
         OSDL_LAUNCH(2)
@@ -1666,7 +1686,9 @@ int bposd_synchronize(bposd_handle* h) {
 // lane and is record 0 of a new "last call"; lane >= 0, rec_idx: chunk `rec_idx` of a host-pointer call on that lane.
 static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B, const uint8_t* d_sel,
                               uint8_t* d_osdw, uint8_t* d_osd0, uint8_t* d_bp, uint8_t* d_conv,
-                              int32_t* d_iters, double* d_llr, int lane = -1, int rec_idx = 0) {
+                              int32_t* d_iters, double* d_llr, int lane = -1, int rec_idx = 0, bool lean = false) {
+    // lean (the small host-pointer call): everything on the lane's own stream in program order -- no events, no second
+    // stream -- so that the call costs a memset, two launches, one 32-byte copy and one synchronisation
     if (!h) return BPOSD_ERR_INVALID;
     if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
     if (B == 0) return BPOSD_OK;
@@ -1679,10 +1701,12 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         h->last_lane = lane;
         h->nrec = 0;
         h->currec = &h->lane_rec[lane];  // stream order on the lane: its previous call has filled the record by now
+        h->async_pending = true;
     } else {
         h->currec = &h->rec[rec_idx];
     }
     h->cur = &h->lanes[lane];
+    h->osd_now = lean ? h->cur->stream : h->cur->osd_stream;
     const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF;
     int rc;
     if (osd_on) {
@@ -1718,7 +1742,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.counters = h->cur->d_counters;
     P.iter_total = (unsigned long long*)(h->cur->d_counters + 4);
 
-    HIP_TRY(h, hipEventRecord(h->currec->ev[0], h->cur->stream));
+    if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[0], h->cur->stream));
     if (h->cfg.schedule == 1) {
         if ((rc = launch_bp_serial(h, P))) return rc;
     } else if (h->bp_hbm) {
@@ -1734,11 +1758,13 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || h->bp_variant >= 16)) {
         if ((rc = launch_bp_local(h, P))) return rc;
     } else if ((rc = launch_bp(h, P))) return rc;
-    HIP_TRY(h, hipEventRecord(h->currec->ev[1], h->cur->stream));
+    if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[1], h->cur->stream));
     h->currec->ran_osd = false;
     if (osd_on) {
-        HIP_TRY(h, hipEventRecord(h->cur->ev_bp, h->cur->stream));
-        HIP_TRY(h, hipStreamWaitEvent(h->cur->osd_stream, h->cur->ev_bp, 0));
+        if (!lean) {
+            HIP_TRY(h, hipEventRecord(h->cur->ev_bp, h->cur->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->cur->osd_stream, h->cur->ev_bp, 0));
+        }
         OsdParams Q{};
         Q.m = h->m;
         Q.n = h->n;
@@ -1761,14 +1787,14 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         const char* dbg_env = getenv("BPOSD_OSD_DEBUG");
         if (dbg_env && dbg_env[0] == '1') {
             if (!h->cur->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->cur->d_osd_dbg, 2048 * sizeof(long long)));
-            HIP_TRY(h, hipMemsetAsync(h->cur->d_osd_dbg, 0, 2048 * sizeof(long long), h->cur->osd_stream));
+            HIP_TRY(h, hipMemsetAsync(h->cur->d_osd_dbg, 0, 2048 * sizeof(long long), h->osd_now));
             Q.dbg = h->cur->d_osd_dbg;
         }
         if (h->large) {
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
             if (Q.dbg) {
                 long long st[13];
-                HIP_TRY(h, hipStreamSynchronize(h->cur->osd_stream));
+                HIP_TRY(h, hipStreamSynchronize(h->osd_now));
                 HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[bposd large osd, s_memtime ticks, list slot 0] sort %lld  build %lld  E1 %lld  E2 %lld  E3 %lld  apply %lld  "
                         "sweep %lld | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld apply table builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12]);
@@ -1778,7 +1804,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         h->currec->ran_osd = true;
         if (Q.dbg) {
             static long long st[2048];
-            HIP_TRY(h, hipStreamSynchronize(h->cur->osd_stream));
+            HIP_TRY(h, hipStreamSynchronize(h->osd_now));
             HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
             if (const char* dump = getenv("BPOSD_OSD_DUMP")) {
                 if (FILE* f = fopen(dump, "wb")) { fwrite(st, sizeof(long long), 2048, f); fclose(f); }
@@ -1788,13 +1814,15 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             fprintf(stderr, "[bposd osd elimination] panel phase %lld  trailing phase %lld (publish %lld, tables %lld)  pivots %lld\n", st[1190], st[1191], st[1193], st[1194], st[1192]);
         }
     }
-    if (osd_on) {  // whatever follows on the lane's stream comes after the OSD kernel
+    if (osd_on && !lean) {  // whatever follows on the lane's stream comes after the OSD kernel
         HIP_TRY(h, hipEventRecord(h->cur->ev_osd, h->cur->osd_stream));
         HIP_TRY(h, hipStreamWaitEvent(h->cur->stream, h->cur->ev_osd, 0));
     }
-    HIP_TRY(h, hipEventRecord(h->currec->ev[2], h->cur->stream));
+    if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[2], h->cur->stream));
     HIP_TRY(h, hipMemcpyAsync(h->currec->h_counters, h->cur->d_counters, 32, hipMemcpyDeviceToHost, h->cur->stream));
+    h->osd_now = nullptr;
     h->currec->recorded = true;
+    h->currec->timed = !lean;
     h->have_timing = true;
     return BPOSD_OK;
 }
@@ -1868,7 +1896,7 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dev_guard.err);
     // the records and lanes are about to be reused: earlier asynchronous calls must have drained
-    { int rcs = sync_all_lanes(h); if (rcs) return rcs; }
+    if (h->async_pending) { int rcs = sync_all_lanes(h); if (rcs) return rcs; }
     // ---- small calls (the reference's one-syndrome `.decode()`): no copy commands at all.  The kernels read the
     // syndromes from, and write every result to, a page-locked staging area that the device addresses directly; the call
     // costs two host memcpys, the launches and one stream synchronisation.
@@ -1896,11 +1924,11 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
             if (sel) memcpy(st + o_sel, sel, b8 * n8);
             int rcz = decode_device_impl(h, st + o_syn, B, sel ? st + o_sel : nullptr, st + o_osdw, osd0 ? st + o_osd0 : nullptr,
                                          bp ? st + o_bp : nullptr, st + o_conv, (int32_t*)(st + o_it),
-                                         llr ? (double*)(st + o_llr) : nullptr, 0, 0);
+                                         llr ? (double*)(st + o_llr) : nullptr, 0, 0, /*lean=*/!getenv("BPOSD_OSD_DEBUG"));
             if (rcz) { (void)sync_all_lanes(h); return rcz; }
             h->nrec = 1;
-            rcz = sync_all_lanes(h);
-            if (rcz) return rcz;
+            if (getenv("BPOSD_OSD_DEBUG")) { rcz = sync_all_lanes(h); if (rcz) return rcz; }
+            else HIP_TRY(h, hipStreamSynchronize(L.stream));
             memcpy(osdw, st + o_osdw, b8 * n8);
             if (osd0) memcpy(osd0, st + o_osd0, b8 * n8);
             if (bp) memcpy(bp, st + o_bp, b8 * n8);
@@ -1965,8 +1993,10 @@ static int record_timing(bposd_handle* h, CallRecord* recs, int count, double* b
         CallRecord& R = recs[r];
         if (!R.recorded) continue;
         float a = 0.f, b = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&a, R.ev[0], R.ev[1]));
-        HIP_TRY(h, hipEventElapsedTime(&b, R.ev[1], R.ev[2]));
+        if (R.timed) {  // (the lean small-call path records counters only: its times read 0)
+            HIP_TRY(h, hipEventElapsedTime(&a, R.ev[0], R.ev[1]));
+            HIP_TRY(h, hipEventElapsedTime(&b, R.ev[1], R.ev[2]));
+        }
         a_sum += a;
         if (R.ran_osd) b_sum += b;
         it_sum += (int64_t)*R.h_iter_total;

@@ -170,7 +170,8 @@ void bposd_host_free(void *p);
  * Timing and work counters of the LAST decode call, measured with HIP events on the
  * stream the kernels were launched on (waits for that call to finish):
  *   bp_ms, osd_ms    kernel durations (a host-pointer call runs in chunks: the sum over its chunks, which
- *                    overlap on the device)
+ *                    overlap on the device; a host-pointer call of up to 1 MB of staging -- the one-syndrome
+ *                    decode -- runs without events and reports 0.0 for both)
  *   bp_iterations    sum over syndromes of BP iterations executed
  *   osd_invocations  syndromes that went through OSD (BP did not converge)
  * Any pointer may be NULL.
