@@ -153,11 +153,11 @@ class BpOsdDecoder:
         lib.bposd_info(self._h, C.byref(rank), C.byref(ncand), C.byref(mi), C.byref(nnz))
         self.rank, self.num_candidates, self._max_iter, self.nnz = rank.value, ncand.value, mi.value, nnz.value
 
-        zi = np.zeros(self.n, dtype=int)
-        self._osdw, self._osd0, self._bp = zi, zi.copy(), zi.copy()
-        self._converge = False
-        self._iter = 0
-        self._llr = np.zeros(self.n, dtype=np.float64)
+        # one-syndrome decode(): buffers + pointers made on first use, raw results of the last call, converted attributes
+        self._one = None
+        self._single = None
+        self._single_cache = {}
+        self._llr_probs = None
         # batch results of the last decode_batch call
         self.batch_converge = None
         self.batch_osdw = None
@@ -276,22 +276,81 @@ class BpOsdDecoder:
 
     def decode(self, syndrome):
         """Decode one syndrome; returns the correction with the syndrome's dtype
-        (README.md:197; css_decode_sim.py:174-202).  Result attributes are updated."""
+        (README.md:197; css_decode_sim.py:174-202).  Result attributes are updated.
+
+        The one-syndrome call has its own thin path: page-sized buffers and their pointers are made once per decoder, the
+        library runs the call without copy commands or events, and the result attributes are converted when read."""
         s = np.asarray(syndrome)
-        want = self.n if (s.ndim == 1 and self._is_received(len(s))) else self.m
-        if s.ndim != 1 or len(s) != want:
-            raise ValueError(f"The {'received vector' if want == self.n and want != self.m else 'syndrome'} must have length {want}. "
-                             f"Not {len(s) if s.ndim else 0}.")
-        out = self.decode_batch(s[None, :], want_osd0=True, want_bp=True, want_llr=True)
-        osdw = self.batch_osdw
-        self._osdw = osdw[0].astype(int)
-        self._osd0 = self.batch_osd0[0].astype(int)
-        self._bp = self.batch_bp[0].astype(int)
-        self._converge = bool(self.batch_converge[0])
-        self._iter = int(self.batch_iter[0])
-        self._llr = self.batch_llr[0].copy()
+        if s.ndim == 1 and self._is_received(len(s)):
+            if len(s) != self.n:
+                raise ValueError(f"The received vector must have length {self.n}. Not {len(s)}.")
+            out = self.decode_batch(s[None, :], want_osd0=True, want_bp=True, want_llr=True)
+            self._single = (self.batch_osdw, self.batch_osd0, self.batch_bp, self.batch_converge, self.batch_iter, self.batch_llr)
+            self._single_cache = {}
+            dtype = s.dtype if np.issubdtype(s.dtype, np.number) else int
+            return out[0].astype(dtype)
+        if s.ndim != 1 or len(s) != self.m:
+            raise ValueError(f"The syndrome must have length {self.m}. Not {len(s) if s.ndim else 0}.")
+        one = self._one
+        if one is None:
+            arrs = (np.empty((1, self.m), np.uint8), np.empty((1, self.n), np.uint8), np.empty((1, self.n), np.uint8),
+                    np.empty((1, self.n), np.uint8), np.empty(1, np.uint8), np.empty(1, np.int32),
+                    np.empty((1, self.n), np.float64))
+            one = self._one = (arrs, tuple(C.c_void_p(a.ctypes.data) for a in arrs))
+        (s8, osdw, osd0, bp, conv, iters, llr), ptrs = one
+        # uint8 input goes to the device as it is (the kernels look at bit 0 only); other dtypes are reduced mod 2
+        if s.dtype == np.uint8:
+            s8[0] = s
+        else:
+            s8[0] = s.astype(np.int64) & 1
+        # (no LLR pointer: with it the BP kernel stores every bit's posterior in every iteration, +30 % on this call;
+        # ``log_prob_ratios`` repeats the -- deterministic -- decode with the pointer when it is read)
+        rc = self._lib.bposd_decode_batch(self._h, ptrs[0], 1, ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], None)
+        if rc:
+            _lib.check(self._lib, self._h, rc)
+        self._single = (osdw, osd0, bp, conv, iters, None)
+        self._single_cache = {}
+        self._llr_probs = None  # the channel this call was decoded with, kept only if update_channel_probs replaces it
         dtype = s.dtype if np.issubdtype(s.dtype, np.number) else int
-        return out[0].astype(dtype)
+        return osdw[0].astype(dtype)
+
+    def _attr(self, which):
+        """Result attribute of the last ``decode()``: converted from the call's raw buffers on first access (the buffers
+        are reused by the next ``decode()``, the converted arrays are the caller's)."""
+        c = self._single_cache
+        if which not in c:
+            src = self._single
+            if src is None:
+                c[which] = {0: np.zeros(self.n, dtype=int), 1: np.zeros(self.n, dtype=int), 2: np.zeros(self.n, dtype=int),
+                            3: False, 4: 0, 5: np.zeros(self.n, dtype=np.float64)}[which]
+            elif which <= 2:
+                c[which] = src[which][0].astype(int)
+            elif which == 3:
+                c[which] = bool(src[3][0])
+            elif which == 4:
+                c[which] = int(src[4][0])
+            elif src[5] is not None:
+                c[which] = src[5][0].copy()
+            else:
+                c[which] = self._recompute_llr()
+        return c[which]
+
+    def _recompute_llr(self):
+        """Posterior LLRs of the last ``decode()``: the call is repeated with the LLR output switched on (same syndrome,
+        same channel -- also when update_channel_probs has been called since -- hence the same bits)."""
+        (s8, _, _, _, _, _, llr), ptrs = self._one
+        scratch = np.empty((1, self.n), np.uint8)
+        later = None
+        if self._llr_probs is not None:
+            later = self._probs
+            _lib.check(self._lib, self._h, self._lib.bposd_update_channel_probs(self._h, self._llr_probs.ctypes.data))
+        try:
+            rc = self._lib.bposd_decode_batch(self._h, ptrs[0], 1, scratch.ctypes.data, None, None, None, None, ptrs[6])
+            _lib.check(self._lib, self._h, rc)
+        finally:
+            if later is not None:
+                _lib.check(self._lib, self._h, self._lib.bposd_update_channel_probs(self._h, later.ctypes.data))
+        return llr[0].copy()
 
     def decode_batch_device(self, d_syndromes, B, d_osdw, d_osd0=None, d_bp=None, d_converged=None,
                             d_iters=None, d_llr=None, d_prior_select=None, alt_channel_probs=None):
@@ -407,35 +466,37 @@ class BpOsdDecoder:
             raise ValueError(f"The error channel vector must have length {self.n}, not {p.shape}")
         rc = self._lib.bposd_update_channel_probs(self._h, p.ctypes.data)
         _lib.check(self._lib, self._h, rc)
+        if self._single is not None and self._single[5] is None and 5 not in self._single_cache and self._llr_probs is None:
+            self._llr_probs = self._probs  # the last decode()'s LLRs have not been read yet: they belong to this channel
         self._probs = p.copy()
 
     @property
     def osdw_decoding(self):
-        return self._osdw
+        return self._attr(0)
 
     @property
     def osd0_decoding(self):
-        return self._osd0
+        return self._attr(1)
 
     @property
     def bp_decoding(self):
-        return self._bp
+        return self._attr(2)
 
     @property
     def decoding(self):
-        return self._osdw
+        return self._attr(0)
 
     @property
     def converge(self):
-        return self._converge
+        return self._attr(3)
 
     @property
     def iter(self):
-        return self._iter
+        return self._attr(4)
 
     @property
     def log_prob_ratios(self):
-        return self._llr
+        return self._attr(5)
 
     @property
     def channel_probs(self):

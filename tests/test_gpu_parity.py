@@ -1242,3 +1242,38 @@ def test_osd_kernel_window_and_workgroup_shapes(gpu_ready, m, n, osd):
     got = _gpu_decode(g, syn)
     assert (~got["converged"]).mean() > 0.5, "the elimination hardly ran"
     _compare_exact(got, ref)
+
+
+@pytest.mark.gpu
+def test_decode_attributes_are_lazy_but_exact(gpu_ready, hgp400):
+    """``decode()`` converts its result attributes when they are read, and obtains ``log_prob_ratios`` by repeating the
+    deterministic call with the LLR output on -- with the channel the decode ran under, also if ``update_channel_probs``
+    came in between (css_decode_sim.py:229,248 updates the channel between the two decodes of a shot)."""
+    from bp_osd_amd import BpOsdDecoder
+
+    H = hgp400.hz
+    n = H.shape[1]
+    q = 0.06
+    kw = dict(error_rate=q, max_iter=12, bp_method="ms", ms_scaling_factor=0.9, osd_method="osd_cs", osd_order=5)
+    _, syn = _syndromes(H, q, 8, 21)
+    p2 = np.random.default_rng(3).uniform(0.01, 0.2, size=n)
+    ref1 = BpOsdDecoder(H, **kw)
+    ref1.decode_batch(syn, want_llr=True)
+    llr1, osdw1, it1 = ref1.batch_llr.copy(), ref1.batch_osdw.copy(), ref1.batch_iter.copy()
+    ref2 = BpOsdDecoder(H, **{**kw, "error_rate": None, "channel_probs": p2})
+    ref2.decode_batch(syn, want_llr=True)
+    llr2 = ref2.batch_llr.copy()
+
+    d = BpOsdDecoder(H, **kw)
+    for b in range(8):
+        out = d.decode(syn[b].astype(np.int64))
+        assert out.dtype == np.int64 and (out == osdw1[b]).all()
+        kept = d.osdw_decoding
+        d.update_channel_probs(p2)             # the LLRs of the call above have not been read yet
+        assert (d.log_prob_ratios.view(np.uint64) == llr1[b].view(np.uint64)).all()
+        assert d.iter == int(it1[b]) and (d.osdw_decoding == osdw1[b]).all()
+        out2 = d.decode(syn[b])                # now under the new channel
+        assert (d.log_prob_ratios.view(np.uint64) == llr2[b].view(np.uint64)).all()
+        assert (out2 == ref2.batch_osdw[b]).all() and out2.dtype == np.uint8
+        assert (kept == osdw1[b]).all(), "an attribute array handed out earlier was overwritten"
+        d.update_channel_probs(np.full(n, q))
