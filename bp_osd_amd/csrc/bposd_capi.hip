@@ -126,6 +126,7 @@ struct bposd_handle {
     int nlevels = 0;
     int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
     bool have_timing = false;
+    long long batch_hint = 0;          // > 0 while a chunked host call is being enqueued: its whole batch size
     bool async_pending = false;        // a device-pointer call may still be running on some lane
     hipStream_t osd_now = nullptr;     // stream the OSD kernel of the call being enqueued goes to
     std::string err;
@@ -1057,6 +1058,13 @@ int launch_bp_local(bposd_handle* h, const BpParams& P) {
     if (h->bp_variant == 21) return launch_bp_local_t<4, 1024, 3, true>(h, L);    // 256 threads, <= 168 VGPRs: 3 workgroups per CU
     // one finite positive prior for every bit: it can live in scalar registers (positive: the padding positions share it)
     const bool uprior = h->probs_uniform && !L.sel && h->probs[0] > 0.0 && h->probs[0] < 0.5;
+    // Small calls are latency-bound (a max_iter straggler runs ~2000 dependent iterations, a lone syndrome ~60): one check
+    // per thread (16 waves per syndrome) iterates 25-30 % faster per syndrome, two checks per thread (4 workgroups per
+    // CU) have the higher throughput.  Measured crossover on the [[1922,50]] code: 32768 syndromes per call (2048: 2.5
+    // against 3.3 ms, 8192: 4.1 / 5.1, 32768: 9.6 / 10.0, 131072: 31.0 / 28.2).  A chunked host call counts as a whole.
+    const long long work = h->batch_hint > 0 ? h->batch_hint : L.B;
+    const bool small_call = h->bp_variant == 0 && work <= 40000;
+    if (small_call) return uprior ? launch_bp_local_t<1, 1024, 8, false, true>(h, L) : launch_bp_local_t<1, 1024, 8, false>(h, L);
     if ((h->bp_variant == 22 || h->bp_variant == 0) && uprior) return launch_bp_local_t<2, 1024, 8, false, true>(h, L);  // <= 64 VGPRs: 4 workgroups per CU
     if (h->bp_variant == 23 && uprior) return launch_bp_local_t<2, 1024, 6, true, true>(h, L);
     if (h->bp_variant == 24 && uprior) return launch_bp_local_t<2, 1024, 6, false, true>(h, L);
@@ -1947,6 +1955,8 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     if (h->large) nchunks = (int)std::min<long long>(nchunks, std::max<long long>(1, B / (4LL * h->num_cu)));
     const long long CH = (B + nchunks - 1) / nchunks;
     nchunks = (int)((B + CH - 1) / CH);
+    struct HintScope { bposd_handle* h; ~HintScope() { h->batch_hint = 0; } } hint_scope{h};
+    h->batch_hint = B;  // kernel variants are chosen for the call, not for a chunk
     const size_t n = (size_t)h->n, m = (size_t)h->m;
     int rc;
     for (int c = 0; c < nchunks; ++c) {

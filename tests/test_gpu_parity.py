@@ -663,7 +663,9 @@ def test_local_edge_kernel_equals_lds_kernel(gpu_ready, h1922, side):
     b.set_bp_variant(2)                  # LDS kernel, 512 threads
     ra, rb = _gpu_decode(a, syn), _gpu_decode(b, syn)
     others = [rb]
-    for variant in (16, 17, 18, 19, 20, 21, 24):  # the local-edge kernel's other shapes: 1 / 2 / 4 checks per thread, early loads, prior in VGPRs / SGPRs
+    # the local-edge kernel's other shapes: 1 / 2 / 4 checks per thread, early loads, prior in VGPRs / SGPRs (auto picks
+    # 26 for a call of this size and 22 for calls beyond 40000 syndromes)
+    for variant in (16, 17, 18, 19, 20, 21, 22, 24, 26):
         c = BpOsdDecoder(H, **kw)
         c.set_bp_variant(variant)
         others.append({k: (np.array(v, copy=True) if v is not None else None) for k, v in _gpu_decode(c, syn).items()})
