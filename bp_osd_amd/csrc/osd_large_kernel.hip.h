@@ -276,12 +276,29 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 
         // AP: apply the ng open groups to words [xlo, W) of every row
         auto apply_open = [&](int xlo) {
-            // ---- the rows this pass updates: everything that is not frozen, compacted in ascending row order
+            // ---- the rows this pass updates, compacted in ascending row order: everything that is not frozen AND has a
+            // non-zero combination mask in some open group.  While the matrix is sparse most rows are untouched by the
+            // <= 256 pivots of a pass (a row meets a given 64-column word with probability ~1 %): they are neither
+            // read nor written, and their masks are read here once instead of once per chunk.
             __syncthreads();  // U is free (the tables of the previous phase are no longer read)
             int* cnt = (int*)U;  // [RPT * NW + 1]
+            unsigned int touched = 0u;  // bit k: my k-th row takes part in this pass
+            {
+                const unsigned int ro = osdl_opaque((unsigned int)threadIdx.x * 8u);
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    unsigned long long any = 0ull;
+                    if (((frozenmask >> k) & 1u) == 0u) {
+#pragma unroll
+                        for (int g = 0; g < OSDL_K; ++g)
+                            if (g < ng) any |= OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + k * NT * 8);
+                    }
+                    if (any) touched |= 1u << k;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                const unsigned long long bal = __ballot(((frozenmask >> k) & 1u) == 0u);
+                const unsigned long long bal = __ballot(((touched >> k) & 1u) != 0u);
                 if (lane == 0) cnt[k * OSDL_NW + wave] = __popcll(bal);
             }
             __syncthreads();
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
-                const bool act = ((frozenmask >> k) & 1u) == 0u;
+                const bool act = ((touched >> k) & 1u) != 0u;
                 const unsigned long long bal = __ballot(act);
                 if (act) alist[cnt[k * OSDL_NW + wave] + __popcll(bal & ((1ull << lane) - 1ull))] = (int)threadIdx.x + k * NT;
             }
@@ -402,9 +419,23 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         // into ds_read2_b64, which issues at half rate on gfx950 -- same finding as bp_kernel.hip.h;
                         // measured here: 855 -> 677 ms per 254 L29k eliminations)
                         osdl_lds_ptr tb = (osdl_lds_ptr)(U + (size_t)g * OSDL_G5 * TS);
+                        // Zero fields need no look-up.  A row of the 14520 x 29524 code starts with 6 ones in 462 words, so
+                        // while the matrix is sparse nearly every 5-bit field of nearly every listed row is zero, and later
+                        // a group of few pivots still leaves most of its fields empty: a whole group, or a block of 4-5
+                        // fields, that is zero in all 64 lanes is skipped by a wave-uniform test (~8 instructions per
+                        // block against ~100 for its look-ups; measured faster over the whole elimination, also in
+                        // its dense second half: 226 -> 206 ms per 254 eliminations against probing only while it pays).
+                        if (__ballot(mk != 0ull) == 0ull) continue;
 #pragma unroll
                         for (int qb = 0; qb < 3; ++qb) {
                             if (qb * 4 < ngrp) {  // tables of the fields beyond the group's pivots are zero
+                                {
+                                    // fields of this block: grp in the block for the straight lanes, (grp + 6) mod 13 for the skewed ones
+                                    constexpr unsigned long long LO[3] = {0x00000000000FFFFFull, 0x000000FFFFF00000ull, 0xFFFFFF0000000000ull};
+                                    constexpr unsigned long long HI[3] = {0x0003FFFFC0000000ull, 0xFFFC00000000001Full, 0x000000003FFFFFE0ull};
+                                    const unsigned long long bm = skew ? HI[qb] : LO[qb];
+                                    if (__ballot((mk & bm) != 0ull) == 0ull) continue;
+                                }
 #pragma unroll
                                 for (int grp = qb * 4; grp < (qb == 2 ? OSDL_G5 : qb * 4 + 4); ++grp) {
                                     const int grp2 = grp < 7 ? grp + 6 : grp - 7;  // the skewed lanes' field
