@@ -156,22 +156,21 @@ PM_FN double pm_expm1(double x) {
     return pm_from_bits(pm_bits(y) + ((uint64_t)k << 52));
 }
 
-/* hyperbolic tangent */
+/* hyperbolic tangent.  One expm1 evaluation and one division serve both ranges (lanes of a GPU wave that fall on
+ * different sides of |x| = 1 would otherwise run the expm1 code twice); per argument the operations and their order are
+ * exactly those of the two-branch form:  |x| >= 1: 1 - 2 / (expm1(2|x|) + 2),  below: -t / (t + 2) with t = expm1(-2|x|). */
 PM_FN double pm_tanh(double x) {
     if (x != x) return x;
     const uint64_t u = pm_bits(x);
     const uint64_t a = u & 0x7fffffffffffffffull;
     const double ax = pm_from_bits(a);
-    double z;
-    if (a >= 0x7ff0000000000000ull) z = 1.0;      /* +-inf */
-    else if (ax >= 22.0) z = 1.0;                 /* 1 - tiny rounds to 1 */
-    else if (a < 0x3c80000000000000ull) return x; /* |x| < 2^-55 (also +-0) */
-    else if (ax >= 1.0) {
-        const double t = pm_expm1(2.0 * ax);
-        z = 1.0 - 2.0 / (t + 2.0);
-    } else {
-        const double t = pm_expm1(-2.0 * ax);
-        z = -t / (t + 2.0);
+    if (a < 0x3c80000000000000ull) return x; /* |x| < 2^-55 (also +-0) */
+    double z = 1.0;                          /* +-inf, and |x| >= 22: 1 - tiny rounds to 1 */
+    if (ax < 22.0) {
+        const int big = ax >= 1.0;
+        const double t = pm_expm1(big ? 2.0 * ax : -2.0 * ax);
+        const double q = (big ? 2.0 : t) / (t + 2.0);
+        z = big ? 1.0 - q : -q;
     }
     return (u >> 63) ? -z : z;
 }
