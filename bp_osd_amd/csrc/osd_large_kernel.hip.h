@@ -129,6 +129,97 @@ typedef const unsigned long long* osdl_lds_ptr;
 #endif
 #define OSDL_AT(type, base, byteoff) (*(type*)((char*)(base) + (size_t)(unsigned int)(byteoff)))
 
+// ---- E2c: the panel phase on a compacted list (Gaussian mode).  A row whose panel word is zero after E1 stays zero for
+// the whole panel, and with reliability-sorted columns of a sparse code few rows are non-zero (14520 x 29524 code, OSD-E:
+// <= 256 in three panels out of four, never more than 1024).  The non-zero words sit in an LDS list; ONE wave runs the
+// pivot loop on CR list entries per lane: wave minimum on the DPP path, pivot word and mask broadcast by v_readlane -- no
+// barrier and no LDS round trip per pivot (~400 / ~900 cycles per pivot for CR = 4 / 16 against ~10000 for the all-rows
+// form, which remains for Gauss-Jordan and for denser panels).  A separate, non-inlined function: its registers are
+// allocated on their own, the caller holds no 16-row window when it runs.
+// LDS (offsets from lpw): words [CAP] u64, masks [CAP] u64, ids [CAP] u32 (row | used << 31), pivots [128] u32
+// (list position of pivot q, then its column), new-pivot bits [1024] u16 (bit k of entry t: row t + 1024 k).
+typedef volatile __attribute__((address_space(3))) unsigned long long* osdl_lds_w64;
+typedef volatile __attribute__((address_space(3))) unsigned int* osdl_lds_w32;
+constexpr int OSDL_E2C_CAP = 1024;
+
+template <int CR>
+__device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_addr, unsigned int misc_addr, int nnz,
+                                                              unsigned long long vmask, int rank, int nrank, int done_in) {
+    constexpr int CAP = OSDL_E2C_CAP;
+    const int lane = threadIdx.x & 63;
+    osdl_lds_w64 Lpw = (osdl_lds_w64)(size_t)lpw_addr;
+    osdl_lds_w64 Lt = Lpw + CAP;
+    osdl_lds_w32 Lid = (osdl_lds_w32)(Lt + CAP);
+    osdl_lds_w32 Lpiv = Lid + CAP;
+    osdl_lds_w32 misc = (osdl_lds_w32)(size_t)misc_addr;
+    unsigned long long cp[CR], ct[CR];
+    unsigned int cu = 0u;  // bit s: my s-th entry is a pivot row
+#pragma unroll
+    for (int s2 = 0; s2 < CR; ++s2) {
+        const int pos = s2 * 64 + lane;
+        cp[s2] = pos < nnz ? Lpw[pos] : 0ull;
+        ct[s2] = 0ull;
+        if (pos < nnz && (Lid[pos] >> 31)) cu |= 1u << s2;
+    }
+    int cnp = 0, cnr = nrank;
+    bool cdone = done_in != 0;
+#pragma clang loop unroll(disable)
+    for (;;) {
+        if (cnr >= rank) { cdone = true; break; }
+        unsigned long long cand = 0ull;
+#pragma unroll
+        for (int s2 = 0; s2 < CR; ++s2) cand |= ((cu >> s2) & 1u) ? 0ull : cp[s2];
+        cand &= vmask;
+        const unsigned int lb = osd_ffs64_or_64(cand);
+        const unsigned int wk = osd_wave_min_u32((lb << 6) | (unsigned int)lane);  // wave-uniform
+        const int col = (int)(wk >> 6);
+        if (col >= 64) break;
+        const int first = (int)(wk & 63u);
+        // every lane picks "its" entry with a one in the column (only the winning lane's pick is read)
+        int kb = 0;
+        unsigned long long a = 0ull, c = 0ull;
+#pragma unroll
+        for (int s2 = CR - 1; s2 >= 0; --s2) {
+            const bool hit = (((cp[s2] >> col) & 1ull) != 0ull) && (((cu >> s2) & 1u) == 0u);
+            kb = hit ? s2 : kb;
+            a = hit ? cp[s2] : a;
+            c = hit ? ct[s2] : c;
+        }
+        const unsigned long long pw_p =
+            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a >> 32), first) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)a, first);
+        const unsigned long long t_p =
+            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(c >> 32), first) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)c, first);
+        const unsigned long long tq = t_p ^ (1ull << cnp);
+#pragma unroll
+        for (int s2 = 0; s2 < CR; ++s2) {
+            const unsigned long long mm = (unsigned long long)((long long)(cp[s2] << (63 - col)) >> 63);
+            cp[s2] ^= pw_p & mm;
+            ct[s2] ^= tq & mm;
+        }
+        if (lane == first) {  // the pivot row itself is put back
+#pragma unroll
+            for (int s2 = 0; s2 < CR; ++s2)
+                if (s2 == kb) { cp[s2] = pw_p; ct[s2] = t_p; }
+            cu |= 1u << kb;
+            Lpiv[cnp] = (unsigned int)(kb * 64 + lane);
+            Lpiv[64 + cnp] = (unsigned int)col;
+        }
+        ++cnp;
+        ++cnr;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < CR; ++s2) {
+        const int pos = s2 * 64 + lane;
+        if (pos < nnz) {
+            Lpw[pos] = cp[s2];
+            Lt[pos] = ct[s2];
+        }
+    }
+    if (lane == 0) { misc[4] = (unsigned int)cnp; misc[5] = (unsigned int)cnr; misc[6] = cdone ? 1u : 0u; }
+}
+
 template <int RPT>
 __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -463,16 +554,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         for (int w = 0; w < W && !done; ++w) {
             wlast = w;
             OSDL_FRESH_TID();
-            unsigned long long pw[RPT], t[RPT];
-            {
-                const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    pw[k] = ((frozenmask >> k) & 1u) ? 0ull : OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8);
-                    t[k] = 0ull;
-                }
-            }
-            // ---------------- E1: bring word w up to date with the open groups
+            int npiv = 0;
+            const int nb = n - w * 64;
+            const unsigned long long vmask = nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
+            if (nb <= 0) done = true;
+            // ---------------- E1 tables: XOR combinations of the open groups' pivot rows in word w (16 entries per nibble)
             if (ng > 0) {
                 for (int e = tid; e < ng * 256; e += NT) {
                     const int idx = e & 15, grp = (e >> 4) & 15, g = e >> 8;
@@ -486,29 +572,134 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     }
                     U[e] = v;
                 }
+            }
+            // ---------------- E1c + E2c (Gaussian mode): rows one at a time, non-zero panel words into the LDS list
+            bool compact = false;
+            if (gauss) {
+                constexpr int CAP = OSDL_E2C_CAP;
+                unsigned long long* Lpw = U + OSDL_K * 256;          // behind the E1 tables
+                unsigned long long* Lt = Lpw + CAP;
+                unsigned int* Lid = (unsigned int*)(Lt + CAP);
+                unsigned int* Lpiv = Lid + CAP;                      // [128]
+                unsigned short* Lnew = (unsigned short*)(Lpiv + 128);  // [1024] bit k: row tid + 1024 k became a pivot row
+                if (tid == 0) misc[7] = 0;
+                Lnew[threadIdx.x] = 0;
+                __syncthreads();  // tables, counter
+                unsigned int zmask = 0u;  // rows whose stored word is non-zero but whose up-to-date word is zero
+                {
+                    const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
+                    constexpr int HB = RPT < 8 ? RPT : 8;  // rows per batch: their loads are in flight together
+#pragma unroll
+                    for (int k0 = 0; k0 < RPT; k0 += HB) {
+                        unsigned long long old[HB], v[HB];
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) {
+                            old[i] = ((frozenmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + (k0 + i) * NT * 8);
+                            v[i] = old[i];
+                        }
+#pragma unroll
+                        for (int g = 0; g < OSDL_K; ++g) {
+                            if (g < ng) {
+                                const int ngrp = (gnp[g] + 3) >> 2;
+                                unsigned long long mk[HB];
+#pragma unroll
+                                for (int i = 0; i < HB; ++i)
+                                    mk[i] = ((frozenmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8);
+#pragma unroll
+                                for (int i = 0; i < HB; ++i)
+                                    for (int grp = 0; grp < ngrp; ++grp) v[i] ^= U[(g * 16 + grp) * 16 + (int)((mk[i] >> (4 * grp)) & 15ull)];
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) {
+                            if (v[i] != 0ull) {
+                                const int pos = atomicAdd(&misc[7], 1);
+                                if (pos < CAP) {
+                                    Lpw[pos] = v[i];
+                                    Lid[pos] = (unsigned int)((int)threadIdx.x + (k0 + i) * NT) | (((usedmask >> (k0 + i)) & 1u) << 31);
+                                }
+                            } else if (old[i] != 0ull) {
+                                zmask |= 1u << (k0 + i);
+                            }
+                        }
+                    }
+                }
                 __syncthreads();
-#pragma unroll
-                for (int g = 0; g < OSDL_K; ++g) {
-                    if (g < ng) {
-                        const int ngrp = (gnp[g] + 3) >> 2;
+                const int nnz = misc[7];
+                if (nnz <= CAP) {  // uniform
+                    compact = true;
+                    if (wave == 0) {
+                        const unsigned int la = (unsigned int)(size_t)(osdl_lds_w64)Lpw, ma = (unsigned int)(size_t)(osdl_lds_w32)misc;
+                        if (nnz <= 256) osdl_e2_compact_wave<4>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                        else osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                    }
+                    __syncthreads();
+                    npiv = misc[4];
+                    nrank = misc[5];
+                    done = misc[6] != 0;
+                    // word w is final: the list rows, and zero for the rows that E1 has just cleared
+                    for (int i = threadIdx.x; i < nnz; i += NT) M[(size_t)w * MRL + (Lid[i] & 0x7fffffffu)] = Lpw[i];
+                    {
                         const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
+#pragma clang loop unroll(disable)
+                        for (int k = 0; k < RPT; ++k)
+                            if ((zmask >> k) & 1u) OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8) = 0ull;
+                    }
+                    if (npiv > 0) {
+                        // the new group's masks: zero for every row that is not frozen, then the list rows' on top
+                        {
+                            const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
+#pragma clang loop unroll(disable)
+                            for (int k = 0; k < RPT; ++k)
+                                if (((frozenmask >> k) & 1u) == 0u) OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = 0ull;
+                        }
+                        if ((int)threadIdx.x < npiv) {
+                            const int q = (int)threadIdx.x;
+                            const int r = (int)(Lid[Lpiv[q]] & 0x7fffffffu);
+                            const int j = w * 64 + (int)Lpiv[64 + q];
+                            pivrow[j] = r;
+                            rowpos[r] = j;
+                            grow[ng * 64 + q] = r;
+                            atomicOr((unsigned int*)(Lnew + ((r & (NT - 1)) & ~1)), (1u << (r / NT)) << (16 * (r & 1)));
+                        }
+                        __syncthreads();  // zero masks before the list rows' masks; new-pivot bits
+                        for (int i = threadIdx.x; i < nnz; i += NT) TmO[(size_t)ng * MRL + (Lid[i] & 0x7fffffffu)] = Lt[i];
+                        usedmask |= (unsigned int)Lnew[threadIdx.x];
+                    }
+                }
+                __syncthreads();  // the lists are free again (U is reused by E3)
+            } else if (ng > 0) {
+                __syncthreads();  // tables
+            }
+            if (!compact) {  // ======== the all-rows form: a 16-row register window per thread
+            unsigned long long pw[RPT], t[RPT];
+            {
+                const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
-                        for (int k = 0; k < RPT; ++k) {
-                            // (a frozen row's mask slots are stale: treat them as empty)
-                            const unsigned long long mk = ((frozenmask >> k) & 1u) ? 0ull : OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + k * NT * 8);
-                            for (int grp = 0; grp < ngrp; ++grp)
-                                pw[k] ^= U[(g * 16 + grp) * 16 + (int)((mk >> (4 * grp)) & 15ull)];
+                for (int k = 0; k < RPT; ++k) {
+                    pw[k] = ((frozenmask >> k) & 1u) ? 0ull : OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8);
+                    t[k] = 0ull;
+                }
+                // ---------------- E1: bring word w up to date with the open groups
+                if (ng > 0) {
+#pragma unroll
+                    for (int g = 0; g < OSDL_K; ++g) {
+                        if (g < ng) {
+                            const int ngrp = (gnp[g] + 3) >> 2;
+#pragma unroll
+                            for (int k = 0; k < RPT; ++k) {
+                                // (a frozen row's mask slots are stale: treat them as empty)
+                                const unsigned long long mk = ((frozenmask >> k) & 1u) ? 0ull : OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + k * NT * 8);
+                                for (int grp = 0; grp < ngrp; ++grp)
+                                    pw[k] ^= U[(g * 16 + grp) * 16 + (int)((mk >> (4 * grp)) & 15ull)];
+                            }
                         }
                     }
                 }
             }
             OSDL_TICK(2);
             OSDL_FRESH_TID();
-            // ---------------- E2: panel phase in registers
-            int npiv = 0;
-            const int nb = n - w * 64;
-            const unsigned long long vmask = nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
-            if (nb <= 0) done = true;
+            // ---------------- E2: panel phase in registers (all rows)
 #pragma clang loop unroll(disable)
             for (;;) {
                 if (nrank >= P.rank) { done = true; break; }
@@ -581,23 +772,23 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 par ^= 1;
             }
             OSDL_FRESH_TID();
-            // word w is final
+            // word w is final; the new group's combination masks
             {
                 const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
 #pragma unroll
                 for (int k = 0; k < RPT; ++k)
                     if (((frozenmask >> k) & 1u) == 0u) OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + k * NT * 8) = pw[k];
-            }
-            OSDL_TICK(3);
-            OSDL_COUNT(7);
-            if (npiv > 0) {
-                OSDL_COUNT(8);
-                {
-                    const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
+                if (npiv > 0) {
 #pragma unroll
                     for (int k = 0; k < RPT; ++k)
                         if (((frozenmask >> k) & 1u) == 0u) OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = t[k];
                 }
+            }
+            }  // ======== end of the all-rows form
+            OSDL_TICK(3);
+            OSDL_COUNT(7);
+            if (npiv > 0) {
+                OSDL_COUNT(8);
                 if (tid == 0) gnp[ng] = npiv;
                 __syncthreads();  // grow / gnp / TmO of the new group are visible
                 // ------------ E3: pivot rows of the new group at its start state, for every later word.
