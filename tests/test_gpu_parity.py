@@ -1279,3 +1279,24 @@ def test_decode_attributes_are_lazy_but_exact(gpu_ready, hgp400):
         assert (out2 == ref2.batch_osdw[b]).all() and out2.dtype == np.uint8
         assert (kept == osdw1[b]).all(), "an attribute array handed out earlier was overwritten"
         d.update_channel_probs(np.full(n, q))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q,max_iter,osd,tie", [(0.04, 3, ("osd_e", 6), 0), (0.10, 2, ("osd_e", 3), 1), (0.06, 1, ("osd_0", 0), 1),
+                                                 (0.03, 20, ("osd_cs", 4), 0)])
+def test_large_osd_panel_forms_vs_oracle(gpu_ready, hgp4050, q, max_iter, osd, tie):
+    """The HBM-resident OSD kernel has two panel phases: the compact one-wave form on the LDS list of non-zero panel words
+    (Gaussian mode: OSD-0 / OSD-E, the usual case on sparse codes) and the all-rows form (Gauss-Jordan, and panels with
+    more than 1024 non-zero rows).  Light and heavy noise, shallow BP (nearly every shot is eliminated), both tie
+    policies: every integer output equals the oracle's."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    H = hgp4050.hz
+    _, syn = _syndromes(H, q, 96, int(q * 1000) + max_iter)
+    kw = dict(error_rate=q, max_iter=max_iter, bp_method="ms", ms_scaling_factor=0.7, osd_method=osd[0], osd_order=osd[1],
+              sort_tie_policy=tie)
+    g = BpOsdDecoder(H, **kw)
+    r = _gpu_decode(g, syn, want_llr=False)
+    assert (~r["converged"]).sum() >= 32
+    _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
