@@ -140,7 +140,7 @@ typedef const unsigned long long* osdl_lds_ptr;
 // (list position of pivot q, then its column), new-pivot bits [1024] u16 (bit k of entry t: row t + 1024 k).
 typedef volatile __attribute__((address_space(3))) unsigned long long* osdl_lds_w64;
 typedef volatile __attribute__((address_space(3))) unsigned int* osdl_lds_w32;
-constexpr int OSDL_E2C_CAP = 1024;
+constexpr int OSDL_E2C_CAP = 2048;
 
 template <int CR>
 __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_addr, unsigned int misc_addr, int nnz,
@@ -216,6 +216,87 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
             Lpw[pos] = cp[s2];
             Lt[pos] = ct[s2];
         }
+    }
+    if (lane == 0) { misc[4] = (unsigned int)cnp; misc[5] = (unsigned int)cnr; misc[6] = cdone ? 1u : 0u; }
+}
+
+// E2c for longer lists (1024 < rows <= OSDL_E2C_CAP): the same one-wave pivot loop with the list left in LDS.  A lane owns
+// the entries lane, lane + 64, ...; the pass that applies a pivot also finds, per lane, the entry with the lowest
+// candidate column for the next one (its key goes into the DPP minimum, so the winning lane knows its entry without a
+// second scan).  ~14 instructions per entry and pivot: ~1.8 k cycles per pivot at 2048 rows against ~10 k for the all-rows form.
+__device__ __attribute__((noinline)) void osdl_e2_compact_lds(unsigned int lpw_addr, unsigned int misc_addr, int nnz,
+                                                             unsigned long long vmask, int rank, int nrank, int done_in) {
+    constexpr int CAP = OSDL_E2C_CAP;
+    static_assert(CAP <= 64 * 32, "one bit of the per-lane used mask per owned entry");
+    const int lane = threadIdx.x & 63;
+    osdl_lds_w64 Lpw = (osdl_lds_w64)(size_t)lpw_addr;
+    osdl_lds_w64 Lt = Lpw + CAP;
+    osdl_lds_w32 Lid = (osdl_lds_w32)(Lt + CAP);
+    osdl_lds_w32 Lpiv = Lid + CAP;
+    osdl_lds_w32 misc = (osdl_lds_w32)(size_t)misc_addr;
+    const int epl = (nnz + 63) >> 6;
+    unsigned int cu = 0u;      // bit s: my s-th entry is a pivot row
+    unsigned int bestl = 64u;  // lowest candidate column among my unused entries ...
+    int bests = 0;             // ... and the entry that has it
+#pragma clang loop unroll(disable)
+    for (int s2 = 0; s2 < epl; ++s2) {
+        const int e = s2 * 64 + lane;
+        if (e < nnz) {
+            Lt[e] = 0ull;
+            if (Lid[e] >> 31) {
+                cu |= 1u << s2;
+            } else {
+                const unsigned int l = osd_ffs64_or_64(Lpw[e] & vmask);
+                if (l < bestl) { bestl = l; bests = s2; }
+            }
+        }
+    }
+    int cnp = 0, cnr = nrank;
+    bool cdone = done_in != 0;
+#pragma clang loop unroll(disable)
+    for (;;) {
+        if (cnr >= rank) { cdone = true; break; }
+        const unsigned int wk = osd_wave_min_u32((bestl << 6) | (unsigned int)lane);  // wave-uniform
+        const int col = (int)(wk >> 6);
+        if (col >= 64) break;
+        const int first = (int)(wk & 63u);
+        const int kbw = bests;  // (meaningful in the winning lane)
+        unsigned long long a = 0ull, c = 0ull;
+        if (lane == first) {
+            a = Lpw[kbw * 64 + lane];
+            c = Lt[kbw * 64 + lane];
+            cu |= 1u << kbw;
+            Lpiv[cnp] = (unsigned int)(kbw * 64 + lane);
+            Lpiv[64 + cnp] = (unsigned int)col;
+        }
+        const unsigned long long pw_p =
+            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a >> 32), first) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)a, first);
+        const unsigned long long t_p =
+            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(c >> 32), first) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)c, first);
+        const unsigned long long tq = t_p ^ (1ull << cnp);
+        bestl = 64u;
+        bests = 0;
+#pragma clang loop unroll(disable)
+        for (int s2 = 0; s2 < epl; ++s2) {
+            const int e = s2 * 64 + lane;
+            if (e < nnz) {
+                unsigned long long w = Lpw[e];
+                const bool ispiv = (lane == first) && (s2 == kbw);  // the pivot row itself stays as it is
+                if (((w >> col) & 1ull) && !ispiv) {
+                    w ^= pw_p;
+                    Lpw[e] = w;
+                    Lt[e] = Lt[e] ^ tq;
+                }
+                if (((cu >> s2) & 1u) == 0u) {
+                    const unsigned int l = osd_ffs64_or_64(w & vmask);
+                    if (l < bestl) { bestl = l; bests = s2; }
+                }
+            }
+        }
+        ++cnp;
+        ++cnr;
     }
     if (lane == 0) { misc[4] = (unsigned int)cnp; misc[5] = (unsigned int)cnr; misc[6] = cdone ? 1u : 0u; }
 }
@@ -631,7 +712,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     if (wave == 0) {
                         const unsigned int la = (unsigned int)(size_t)(osdl_lds_w64)Lpw, ma = (unsigned int)(size_t)(osdl_lds_w32)misc;
                         if (nnz <= 256) osdl_e2_compact_wave<4>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
-                        else osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                        else if (nnz <= 1024) osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                        else osdl_e2_compact_lds(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
                     }
                     __syncthreads();
                     npiv = misc[4];
