@@ -113,8 +113,8 @@ def test_output_buffer_pool_never_hands_out_live_memory():
     c = alloc((64, 64))
     assert c.ctypes.data != addr_a and (view == 7).all() and len(fake._out_pool) == 3
     del view
-    d = alloc((32, 64), np.float64)                                              # 16 KB > 4 KB buffers: new one
     e = alloc((64, 64))
-    assert e.ctypes.data == addr_a                                               # the freed buffer is reused
+    assert e.ctypes.data == addr_a and len(fake._out_pool) == 3                  # the freed buffer is reused (from the pool)
+    d = alloc((32, 64), np.float64)                                              # 16 KB > 4 KB buffers: new one
     assert d.dtype == np.float64 and d.shape == (32, 64)
     assert sum(x.nbytes for x in fake._out_pool) <= max(3 << 12, d.nbytes + 2 * 4096) + 4096
