@@ -654,19 +654,27 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     U[e] = v;
                 }
             }
-            // ---------------- E1c + E2c (Gaussian mode): rows one at a time, non-zero panel words into the LDS list
+            // ---------------- E1c + E2c: rows in batches, non-zero panel words into the LDS list.  Gauss-Jordan (OSD-CS) lists
+            // the UNUSED rows only -- the pivot search needs no others -- and brings its pivot rows of earlier panels
+            // up to date afterwards in one step per row ("Jordan fix-up" below).
             bool compact = false;
-            if (gauss) {
+            const bool jordan = !gauss;
+            {
                 constexpr int CAP = OSDL_E2C_CAP;
                 unsigned long long* Lpw = U + OSDL_K * 256;          // behind the E1 tables
                 unsigned long long* Lt = Lpw + CAP;
                 unsigned int* Lid = (unsigned int*)(Lt + CAP);
                 unsigned int* Lpiv = Lid + CAP;                      // [128]
                 unsigned short* Lnew = (unsigned short*)(Lpiv + 128);  // [1024] bit k: row tid + 1024 k became a pivot row
-                if (tid == 0) misc[7] = 0;
+                unsigned long long* PFW = (unsigned long long*)(Lnew + 1024);  // [64] by column: final panel word of the pivot there
+                unsigned long long* TF = PFW + 64;                             // [64] by column: its mask, own bit included
+                unsigned int* pcm = (unsigned int*)(TF + 64);                  // [2] pivot columns of this panel
+                if (tid == 0) { misc[7] = 0; pcm[0] = 0u; pcm[1] = 0u; }
                 Lnew[threadIdx.x] = 0;
                 __syncthreads();  // tables, counter
                 unsigned int zmask = 0u;  // rows whose stored word is non-zero but whose up-to-date word is zero
+                const unsigned int skipmask = frozenmask | (jordan ? usedmask : 0u);  // rows that are not listed
+                const unsigned int usedbefore = usedmask;
                 {
                     const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
                     constexpr int HB = RPT < 8 ? RPT : 8;  // rows per batch: their loads are in flight together
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         unsigned long long old[HB], v[HB];
 #pragma unroll
                         for (int i = 0; i < HB; ++i) {
-                            old[i] = ((frozenmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + (k0 + i) * NT * 8);
+                            old[i] = ((skipmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + (k0 + i) * NT * 8);
                             v[i] = old[i];
                         }
 #pragma unroll
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                 unsigned long long mk[HB];
 #pragma unroll
                                 for (int i = 0; i < HB; ++i)
-                                    mk[i] = ((frozenmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8);
+                                    mk[i] = ((skipmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8);
 #pragma unroll
                                 for (int i = 0; i < HB; ++i)
                                     for (int grp = 0; grp < ngrp; ++grp) v[i] ^= U[(g * 16 + grp) * 16 + (int)((mk[i] >> (4 * grp)) & 15ull)];
@@ -743,15 +751,66 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             rowpos[r] = j;
                             grow[ng * 64 + q] = r;
                             atomicOr((unsigned int*)(Lnew + ((r & (NT - 1)) & ~1)), (1u << (r / NT)) << (16 * (r & 1)));
+                            if (jordan) {
+                                const int col = (int)Lpiv[64 + q];
+                                PFW[col] = Lpw[Lpiv[q]];
+                                TF[col] = Lt[Lpiv[q]] ^ (1ull << q);
+                                atomicOr(&pcm[col >> 5], 1u << (col & 31));
+                            }
                         }
-                        __syncthreads();  // zero masks before the list rows' masks; new-pivot bits
+                        __syncthreads();  // zero masks before the list rows' masks; new-pivot bits; fix-up tables
                         for (int i = threadIdx.x; i < nnz; i += NT) TmO[(size_t)ng * MRL + (Lid[i] & 0x7fffffffu)] = Lt[i];
                         usedmask |= (unsigned int)Lnew[threadIdx.x];
                     }
+                    if (jordan && usedbefore != 0u) {
+                        // ---- Jordan fix-up: a pivot row u of an earlier panel, brought up to date by E1, must lose its ones in
+                        // this panel's pivot columns.  With the pivot rows of the panel in their final (mutually reduced)
+                        // state F_q that is one step: u ^= XOR F_q over the pivot columns in which u has a one, and its
+                        // combination mask is the XOR of the F_q's masks (own bit included) -- the result the sequential
+                        // updates reach, since it is the only element of u + span(pivots) without ones in pivot columns.
+                        const unsigned long long pcmask = ((unsigned long long)pcm[1] << 32) | pcm[0];
+                        const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
+                        constexpr int HB = RPT < 8 ? RPT : 8;
+#pragma unroll
+                        for (int k0 = 0; k0 < RPT; k0 += HB) {
+                            if (((usedbefore >> k0) & ((1u << HB) - 1u)) == 0u) continue;
+                            unsigned long long old[HB], v[HB];
+#pragma unroll
+                            for (int i = 0; i < HB; ++i) {
+                                old[i] = ((usedbefore >> (k0 + i)) & 1u) ? OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + (k0 + i) * NT * 8) : 0ull;
+                                v[i] = old[i];
+                            }
+#pragma unroll
+                            for (int g = 0; g < OSDL_K; ++g) {
+                                if (g < ng) {
+                                    const int ngrp = (gnp[g] + 3) >> 2;
+                                    unsigned long long mk[HB];
+#pragma unroll
+                                    for (int i = 0; i < HB; ++i)
+                                        mk[i] = ((usedbefore >> (k0 + i)) & 1u) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8) : 0ull;
+#pragma unroll
+                                    for (int i = 0; i < HB; ++i)
+                                        for (int grp = 0; grp < ngrp; ++grp) v[i] ^= U[(g * 16 + grp) * 16 + (int)((mk[i] >> (4 * grp)) & 15ull)];
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < HB; ++i) {
+                                if (((usedbefore >> (k0 + i)) & 1u) == 0u) continue;
+                                unsigned long long tm = 0ull;
+                                unsigned long long sbits = npiv > 0 ? (v[i] & pcmask) : 0ull;
+                                while (sbits) {
+                                    const int c = __ffsll((long long)sbits) - 1;
+                                    sbits &= sbits - 1;
+                                    v[i] ^= PFW[c];
+                                    tm ^= TF[c];
+                                }
+                                if (v[i] != old[i]) OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + (k0 + i) * NT * 8) = v[i];
+                                if (tm != 0ull) OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + (k0 + i) * NT * 8) = tm;
+                            }
+                        }
+                    }
                 }
                 __syncthreads();  // the lists are free again (U is reused by E3)
-            } else if (ng > 0) {
-                __syncthreads();  // tables
             }
             if (!compact) {  // ======== the all-rows form: a 16-row register window per thread
             unsigned long long pw[RPT], t[RPT];
