@@ -29,6 +29,10 @@
 // unused rows -- on average half the row updates of Gauss-Jordan -- and the wspan + 1 columns are then solved against
 // the (partly reduced) pivot rows from the last pivot word to the first.
 // OSD-CS weighs all k' single candidates, i.e. needs every non-pivot column reduced: it keeps Gauss-Jordan.
+// E2c (round 2): when few rows have a non-zero panel word -- the usual case on sparse codes -- those words go to an LDS list
+// and ONE wave runs the pivot loop on it without a barrier per pivot (osdl_e2_compact_wave / _lds below); Gauss-Jordan lists
+// the unused rows only and brings the earlier pivot rows up to date afterwards in one step per row (Jordan fix-up).  The
+// all-rows E2 above remains for longer lists.  The apply pass (AP) walks only the rows that some open group touches.
 // Earlier words never change: a row that becomes a pivot later has zeros in every earlier non-pivot
 // column, so the reduced columns the sweep reads are final as soon as their word is stored.
 // Sort: bitonic network over a global key array (n up to 32767).  Sweep: per-wave ballots over the
@@ -129,12 +133,13 @@ typedef const unsigned long long* osdl_lds_ptr;
 #endif
 #define OSDL_AT(type, base, byteoff) (*(type*)((char*)(base) + (size_t)(unsigned int)(byteoff)))
 
-// ---- E2c: the panel phase on a compacted list (Gaussian mode).  A row whose panel word is zero after E1 stays zero for
+// ---- E2c: the panel phase on a compacted list (Gaussian mode: every unfrozen row with a non-zero panel word; Gauss-Jordan:
+// the unused ones, see the Jordan fix-up at the call site).  A row whose panel word is zero after E1 stays zero for
 // the whole panel, and with reliability-sorted columns of a sparse code few rows are non-zero (14520 x 29524 code, OSD-E:
 // <= 256 in three panels out of four, never more than 1024).  The non-zero words sit in an LDS list; ONE wave runs the
 // pivot loop on CR list entries per lane: wave minimum on the DPP path, pivot word and mask broadcast by v_readlane -- no
 // barrier and no LDS round trip per pivot (~400 / ~900 cycles per pivot for CR = 4 / 16 against ~10000 for the all-rows
-// form, which remains for Gauss-Jordan and for denser panels).  A separate, non-inlined function: its registers are
+// form, which remains for denser panels).  A separate, non-inlined function: its registers are
 // allocated on their own, the caller holds no 16-row window when it runs.
 // LDS (offsets from lpw): words [CAP] u64, masks [CAP] u64, ids [CAP] u32 (row | used << 31), pivots [128] u32
 // (list position of pivot q, then its column), new-pivot bits [1024] u16 (bit k of entry t: row t + 1024 k).
