@@ -110,6 +110,23 @@ __device__ __forceinline__ void bit_update_mixed(int dlv, double l0, double R, d
     oY = d0 ? o2 : (d1 ? o0 : o1);
 }
 
+// table entry at a uniform base + per-lane byte offset; the offset is made opaque at the point of use so that the
+// address is formed there (hoisted out of the syndrome loop it would occupy a 64-bit register pair per table row)
+__device__ __forceinline__ int bpl_table_load(const int* base, unsigned int lane_off, unsigned int const_off) {
+    asm volatile("" : "+v"(lane_off));
+    return *(const int*)((const char*)base + (lane_off + const_off));
+}
+
+// Kernel arguments that are read once per syndrome or less often (tables, output pointers, the queue) are fetched from the
+// kernarg segment where they are used -- s_load from the scalar cache -- instead of being held in ~50 SGPRs for the
+// lifetime of the kernel: the 64-VGPR build had run out of SGPRs and of lanes in its SGPR-spill register.
+typedef const __attribute__((address_space(4))) BpLocalParams* bpl_args_ptr;
+__device__ __forceinline__ bpl_args_ptr bpl_args() {
+    bpl_args_ptr a = (bpl_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return a;
+}
+
 // CPT: checks per thread (each with its two owned bits); MPT: positions (power of two) = blockDim.x * CPT;
 // EARLY: the check pass requests the LDS messages of all its checks before it computes the first one (the LDS accesses
 // are volatile, i.e. issued in program order: without this the read latency is exposed once per check)
@@ -122,12 +139,14 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
     constexpr int MP = MPT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NB = 2 * CPT;  // owned bits per thread
 
     double* msg_plain = reinterpret_cast<double*>(smem);
     msg_ptr msg = (msg_ptr)msg_plain;
     unsigned int* diffw = reinterpret_cast<unsigned int*>(msg_plain + (size_t)4 * MP + 2);
     int* sh = reinterpret_cast<int*>(diffw + (MP / 32 + 2));
+    const unsigned int diffw_base = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)diffw;
 
     // ---- per-thread graph tables
     // Padding positions (no check, no bits) need no predicate anywhere in the iteration loop: the host wires the two
@@ -135,34 +154,59 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
     // bits, three edges each, with a zero syndrome bit and a positive prior.  All its messages stay positive for ever
     // (they grow; sums of positive numbers never produce a NaN), its bits never change their decision and its check
     // never mismatches.  Only the stores that leave the workgroup (LLRs, results) test pos_bit >= 0.
-    int alo[NB], ahi[NB], dl[NB];
+    // alo / ahi: LDS BYTE addresses of the two non-local edges of an owned bit (one register each for the hot path AND
+    // the rare decision-flip path, which recovers the position from the address; a slot index kept next to its byte
+    // address cost the default build 84 B/lane of scratch and a scratch reload on the loop's critical path)
+    typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+    const unsigned int msg_base = (unsigned int)(uintptr_t)(lds_bytes)smem;
+    unsigned int alo[NB], ahi[NB];
+    int dl[NB];
     unsigned int dlpack = 0u;  // 2 bits per owned bit: its dl (needed per lane only in mixed groups)
     double l0[UPRIOR ? 1 : NB];
-    if (UPRIOR) l0[0] = P.llr0[0];
+    if (UPRIOR) {  // into a scalar register pair
+        const double v = bpl_args()->llr0[0];
+        l0[0] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
 #define BPL_L0(r) l0[UPRIOR ? 0 : (r)]
+#define BPL_AT(a) ((msg_ptr)(uintptr_t)(a))
+    // r-th owned bit of this thread (-1 = padding): a uniform base plus a 32-bit byte offset per lane, so the loads outside
+    // the iteration loop need no 64-bit per-lane pointers (which the 64-VGPR build kept in scratch)
+#define BPL_BIT(r) bpl_table_load(bpl_args()->pos_bit, (unsigned int)tid * 4u, (unsigned int)((((r) & 1) * MP + ((r) >> 1) * NT) * 4))
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int p = tid + j * NT;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int r = 2 * j + b;
-            const int bit = P.pos_bit[b * MP + p];
-            if (!UPRIOR) l0[r] = bit >= 0 ? P.llr0[bit] : 1.0;  // (UPRIOR: the host has checked that the prior is > 0)
-            alo[r] = P.pos_alo[b * MP + p];
-            ahi[r] = P.pos_ahi[b * MP + p];
-            dl[r] = __builtin_amdgcn_readfirstlane(P.grp_dl[b * (MP >> 6) + (p >> 6)]);  // uniform per wave
-            dlpack |= (unsigned int)P.pos_dl[b * MP + p] << (2 * r);
+            if (!UPRIOR) {
+                const int bit = BPL_BIT(r);
+                l0[r] = bit >= 0 ? bpl_args()->llr0[bit] : 1.0;  // (UPRIOR: the host has checked that the prior is > 0)
+            }
+            alo[r] = msg_base + 8u * (unsigned int)bpl_args()->pos_alo[b * MP + p];
+            ahi[r] = msg_base + 8u * (unsigned int)bpl_args()->pos_ahi[b * MP + p];
+            dl[r] = __builtin_amdgcn_readfirstlane(bpl_args()->grp_dl[b * (MP >> 6) + (p >> 6)]);  // uniform per wave
+            dlpack |= (unsigned int)bpl_args()->pos_dl[b * MP + p] << (2 * r);
         }
     }
 
+    const int want_llr_s = __builtin_amdgcn_readfirstlane(bpl_args()->out_llr != nullptr ? 1 : 0);
+    // tested from ONE scalar register wherever it is needed (as a loop-invariant condition it became a lane mask plus a
+    // vector register that went to scratch)
+    auto want_llr = [&]() -> bool {
+        int w = want_llr_s;
+        asm volatile("" : "+s"(w));
+        return w != 0;
+    };
     for (;;) {
         if (tid == 0) {
-            sh[0] = 0;
-            sh[1] = 0;
-            sh[2] = atomicAdd(&P.counters[0], 1);
+            int zero = 0;
+            asm volatile("" : "+v"(zero));  // (formed here: as a loop-invariant register pair it went to scratch)
+            sh[0] = zero;
+            sh[1] = zero;
+            sh[2] = atomicAdd(&bpl_args()->counters[0], 1);
         }
         __syncthreads();
-        const long long s = sh[2];
+        const long long s = __builtin_amdgcn_readfirstlane(sh[2]);
         if (s >= P.B) break;
 
         // ---- syndrome bits of my checks; the mismatch bitmap (indexed by position) starts as the syndrome
@@ -170,40 +214,44 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int p = tid + j * NT;
-            const int c = P.pos_chk[p];
-            sbit[j] = (c >= 0) ? ((P.synd[(size_t)s * m + c] & 1) != 0) : false;
+            const int c = bpl_table_load(bpl_args()->pos_chk, (unsigned int)tid * 4u, (unsigned int)(j * NT * 4));
+            sbit[j] = (c >= 0) ? ((bpl_args()->synd[(size_t)s * m + c] & 1) != 0) : false;
             const unsigned long long bal = __ballot(sbit[j]);
             if (lane == 0) {
-                const int w0 = (p >> 5);  // p is a multiple of 64 for lane 0
+                const int w0 = ((wave << 6) + j * NT) >> 5;
                 diffw[w0] = (unsigned int)bal;
                 diffw[w0 + 1] = (unsigned int)(bal >> 32);
                 if (bal) sh[0] = 1;
             }
         }
-        if (!UPRIOR && P.sel) {
+        if (!UPRIOR && bpl_args()->sel) {
 #pragma unroll
             for (int j = 0; j < CPT; ++j)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const int i = P.pos_bit[b * MP + tid + j * NT];
-                    if (i >= 0) l0[2 * j + b] = P.sel[(size_t)s * n + i] ? P.llr0_alt[i] : P.llr0[i];
+                    const int i = BPL_BIT(2 * j + b);
+                    if (i >= 0) l0[2 * j + b] = bpl_args()->sel[(size_t)s * n + i] ? bpl_args()->llr0_alt[i] : bpl_args()->llr0[i];
                 }
         }
         // ---- a3: every edge's bit->check message starts at the prior (two in LDS, one in a register)
         double loc[NB];
-        double* llrt = P.llr_tmp + (size_t)blockIdx.x * n;
+#define BPL_LLRT (bpl_args()->llr_tmp + (size_t)blockIdx.x * n)
         unsigned int decmask = 0u;  // bit r: hard decision of my r-th bit
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-            loc[r] = BPL_L0(r);
-            msg[alo[r]] = BPL_L0(r);
-            msg[ahi[r]] = BPL_L0(r);
+            double lp = BPL_L0(r);
+            if (UPRIOR) asm volatile("" : "+s"(lp));  // copied from the scalar pair here, not kept in a vector pair
+            loc[r] = lp;
+            *BPL_AT(alo[r]) = lp;
+            *BPL_AT(ahi[r]) = lp;
         }
-        if (P.out_llr) {  // a syndrome that needs no iteration reports the priors
+        if (want_llr()) {  // a syndrome that needs no iteration reports the priors
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const int i = P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT];
-                if (i >= 0) llrt[i] = BPL_L0(r);
+                const int i = BPL_BIT(r);
+                double lp = BPL_L0(r);
+                if (UPRIOR) asm volatile("" : "+s"(lp));
+                if (i >= 0) BPL_LLRT[i] = lp;
             }
         }
         __syncthreads();
@@ -215,14 +263,14 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
             for (int it = 1;; ++it) {
                 const int fi = it & 1;
                 {
-                    bool mis = false;
+                    // the wave's 64 positions of group j are one aligned pair of bitmap words: one broadcast read per group
+                    // from a wave-uniform address (no per-lane address or mask registers live across the loop)
+                    unsigned long long mis = 0ull;
 #pragma unroll
-                    for (int j = 0; j < CPT; ++j) {
-                        const int p = tid + j * NT;
-                        mis |= ((diffw[p >> 5] >> (p & 31)) & 1u) != 0;  // (padding positions never raise their bits)
-                    }
-                    const unsigned long long anym = __ballot(mis);
-                    if (lane == 0 && anym) sh[fi] = 1;
+                    for (int j = 0; j < CPT; ++j)
+                        mis |= *(const volatile __attribute__((address_space(3))) unsigned long long*)(uintptr_t)(
+                            diffw_base + (unsigned int)(((wave << 6) + j * NT) >> 3));  // (padding positions never raise their bits)
+                    if (lane == 0 && mis) sh[fi] = 1;
                 }
                 if (it > P.max_iter) {
                     __syncthreads();
@@ -282,7 +330,7 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                 }
                 if (tid == 0) sh[fi ^ 1] = 0;
                 // ============ bit pass: posterior, decision, bit -> check (a6 / a7) ============
-                const bool keep_llr = (it == P.max_iter) || (P.out_llr != nullptr);  // uniform
+                const bool keep_llr = (it == P.max_iter) || want_llr();  // uniform
                 // the two LDS messages of every owned bit: all of them up front (latency hidden inside the thread), or,
                 // for the register-capped high-occupancy variant, two bits at a time
                 constexpr int BATCH = (MINW >= 8 && NB > 2) ? 2 : NB;
@@ -292,8 +340,8 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                     if (r % BATCH == 0) {
 #pragma unroll
                         for (int q = r; q < r + BATCH; ++q) {
-                            X[q] = msg[alo[q]];
-                            Y[q] = msg[ahi[q]];
+                            X[q] = *BPL_AT(alo[q]);
+                            Y[q] = *BPL_AT(ahi[q]);
                         }
                     }
                     double oR, oX, oY, t;
@@ -302,18 +350,19 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                     else if (dl[r] == 2) bit_update<2>(BPL_L0(r), loc[r], X[r], Y[r], t, oR, oX, oY);
                     else bit_update_mixed((int)((dlpack >> (2 * r)) & 3u), BPL_L0(r), loc[r], X[r], Y[r], t, oR, oX, oY);
                     if (keep_llr) {
-                        const int bi = P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT];
-                        if (bi >= 0) llrt[bi] = t;
+                        const int bi = BPL_BIT(r);
+                        if (bi >= 0) BPL_LLRT[bi] = t;
                     }
                     loc[r] = oR;
-                    msg[alo[r]] = oX;
-                    msg[ahi[r]] = oY;
+                    *BPL_AT(alo[r]) = oX;
+                    *BPL_AT(ahi[r]) = oY;
                     const unsigned int dnew = (t <= 0.0) ? 1u : 0u;
                     if (dnew != ((decmask >> r) & 1u)) {  // (a padding bit never gets here: see the tables above)
                         decmask ^= 1u << r;
-                        int pa = alo[r], pb = ahi[r];
+                        unsigned int pa = alo[r], pb = ahi[r];
                         asm volatile("" : "+v"(pa), "+v"(pb));  // keep the rare path's address arithmetic in the branch
-                        const int ca = pa & (MP - 1), cb = pb & (MP - 1), co = tid + (r >> 1) * NT;  // slot = k * MP + position
+                        const int ca = (int)((pa - msg_base) >> 3) & (MP - 1), cb = (int)((pb - msg_base) >> 3) & (MP - 1);
+                        const int co = tid + (r >> 1) * NT;  // slot = k * MP + position
                         atomicXor(&diffw[ca >> 5], 1u << (ca & 31));
                         atomicXor(&diffw[cb >> 5], 1u << (cb & 31));
                         atomicXor(&diffw[co >> 5], 1u << (co & 31));
@@ -324,33 +373,33 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
         }
 
         // ---- results
-        const bool to_osd = (!conv) && P.osd_enabled;
+        const bool to_osd = (!conv) && bpl_args()->osd_enabled;
         if (tid == 0) {
             if (to_osd) {
-                const int slot = atomicAdd(&P.counters[1], 1);
-                P.osd_list[slot] = (int)s;
+                const int slot = atomicAdd(&bpl_args()->counters[1], 1);
+                bpl_args()->osd_list[slot] = (int)s;
                 sh[3] = slot;
             }
-            if (P.out_conv) P.out_conv[s] = conv ? 1 : 0;
-            if (P.out_iters) P.out_iters[s] = it_done;
-            if (it_done) atomicAdd(P.iter_total, (unsigned long long)it_done);
+            if (bpl_args()->out_conv) bpl_args()->out_conv[s] = conv ? 1 : 0;
+            if (bpl_args()->out_iters) bpl_args()->out_iters[s] = it_done;
+            if (it_done) atomicAdd(bpl_args()->iter_total, (unsigned long long)it_done);
         }
         __syncthreads();
         const int slot = to_osd ? sh[3] : 0;
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-            const int i = P.pos_bit[(r & 1) * MP + tid + (r >> 1) * NT];
+            const int i = BPL_BIT(r);
             if (i >= 0) {
                 const size_t o = (size_t)s * n + i;
                 const uint8_t b = (uint8_t)((decmask >> r) & 1u);
-                if (P.out_bp) P.out_bp[o] = b;
+                if (bpl_args()->out_bp) bpl_args()->out_bp[o] = b;
                 if (!to_osd) {
-                    P.out_osdw[o] = b;
-                    if (P.out_osd0) P.out_osd0[o] = b;
+                    bpl_args()->out_osdw[o] = b;
+                    if (bpl_args()->out_osd0) bpl_args()->out_osd0[o] = b;
                 } else {
-                    P.llr_ws[(size_t)slot * n + i] = llrt[i];
+                    bpl_args()->llr_ws[(size_t)slot * n + i] = BPL_LLRT[i];
                 }
-                if (P.out_llr) P.out_llr[o] = llrt[i];
+                if (want_llr()) bpl_args()->out_llr[o] = BPL_LLRT[i];
             }
         }
         __syncthreads();
@@ -358,5 +407,8 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
 }
 
 #undef BPL_L0
+#undef BPL_AT
+#undef BPL_BIT
+#undef BPL_LLRT
 
 }  // namespace bposd
