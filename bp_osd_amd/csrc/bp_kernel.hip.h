@@ -88,6 +88,17 @@ __device__ __forceinline__ double alpha_for_iteration(double ms_scaling, int it)
     return 1.0 - __builtin_ldexp(1.0, -it);
 }
 
+// The same value as an integer bit pattern, formed with shifts only (wave-uniform inputs: scalar instructions, where the
+// floating-point form costs ~10 vector instructions per iteration).  1 - 2^-it for 1 <= it <= 53 is exactly representable:
+// biased exponent 0x3FE, the top it - 1 mantissa bits set; from it = 54 on the difference rounds to 1.0 (ties to even),
+// which is also what the subtraction above returns.
+__device__ __forceinline__ unsigned long long alpha_bits_for_iteration(double ms_scaling, int it) {
+    if (ms_scaling != 0.0) return (unsigned long long)__double_as_longlong(ms_scaling);
+    if (it >= 54) return 0x3FF0000000000000ull;
+    const int sh = 53 - it;  // 0 .. 52
+    return 0x3FE0000000000000ull | ((0x000FFFFFFFFFFFFFull >> sh) << sh);
+}
+
 // r = min(t, |v|) exactly as `a = fabs(v); if (a < t) t = a;` for every non-NaN t:
 // v_min_f64 returns the non-NaN operand, and t never is NaN (it starts at DBL_MAX).
 __device__ __forceinline__ double min_abs(double t, double v) {

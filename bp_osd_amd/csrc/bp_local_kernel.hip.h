@@ -279,8 +279,8 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                     break;
                 }
                 // =================== check -> bit pass (a4), speculative for it >= 2 ===========
-                const double alpha = alpha_for_iteration(P.ms_scaling, it);
-                const int alpha_lo = __double2loint(alpha), alpha_hi = __double2hiint(alpha), nalpha_hi = alpha_hi ^ (int)0x80000000;
+                const unsigned long long alpha_u = alpha_bits_for_iteration(P.ms_scaling, it);  // scalar instructions
+                const int alpha_lo = (int)(unsigned int)alpha_u, alpha_hi = (int)(unsigned int)(alpha_u >> 32), nalpha_hi = alpha_hi ^ (int)0x80000000;
                 double vl[EARLY ? CPT : 1][4];
                 if (EARLY) {
 #pragma unroll
@@ -333,7 +333,10 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                 const bool keep_llr = (it == P.max_iter) || want_llr();  // uniform
                 // the two LDS messages of every owned bit: all of them up front (latency hidden inside the thread), or,
                 // for the register-capped high-occupancy variant, two bits at a time
-                constexpr int BATCH = (MINW >= 8 && NB > 2) ? 2 : NB;
+#ifndef BPOSD_BPL_BATCH
+#define BPOSD_BPL_BATCH 2
+#endif
+                constexpr int BATCH = (MINW >= 8 && NB > 2) ? BPOSD_BPL_BATCH : NB;
                 double X[NB], Y[NB];
 #pragma unroll
                 for (int r = 0; r < NB; ++r) {

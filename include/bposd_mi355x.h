@@ -189,8 +189,9 @@ int bposd_info(bposd_handle *h, int32_t *rank, int32_t *num_candidates, int32_t 
 int bposd_layout_info(bposd_handle *h, int64_t *natural_cycles, int64_t *chosen_cycles, int64_t *ideal_cycles);
 
 /* Diagnostics, host only (needs no device): the ownership / position layout the local-edge BP kernel would use for a
- * (3,6)-regular pcm with n = 2m.  out[14]: simulated LDS passes of one bit pass, the conflict-free count, positions in
- * select-free (uniform) groups, mixed (group, slot) pairs, positions, nine class sizes. */
+ * (3,6)-regular pcm with n = 2m.  out[16]: modelled ds_read_b64 cycles of one bit pass, their conflict-free
+ * floor, positions in select-free (uniform) groups, mixed (group, slot) pairs, positions, nine class sizes, modelled
+ * ds_write_b64 cycles of one bit pass, their floor. */
 int bposd_debug_local_layout(const int32_t *csr_indptr, const int32_t *csr_indices, int32_t m, int32_t n, int64_t *out);
 
 /* Tuning knob (not part of the reference surface): which BP kernel / workgroup shape runs.
