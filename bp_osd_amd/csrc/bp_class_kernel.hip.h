@@ -1,0 +1,377 @@
+// bp_class_kernel.hip.h -- BP with all messages in LDS for codes whose checks all have ONE degree and whose bits fall
+// into a few degree classes -- every hypergraph product of regular seeds, i.e. all three example codes the reference
+// ships ([[400,16,6]], [[625,25,8]], [[900,36,10]]: check degree 7, bit degrees 3 and 4;
+// /root/reference/examples/qldpc_decode_example.py:5-23).  Rows a3-a7 of SURVEY.md §8; the scheme (persistent workgroups
+// on an atomic queue, in-place check-major messages  msg[k * MP + c], incremental mismatch bitmap, speculative check
+// pass, two barriers per iteration) is bp_kernel.hip.h's, with what the local-edge kernel taught:
+//
+//   * NO per-lane degree predicates.  The check degree DC is a template constant.  The host sorts bits by degree into
+//     64-lane groups; group (slot r, wave w) has ONE degree, the kernel switches on that wave-uniform number into
+//     straight-line code for DVLO .. DVHI edges (0 = no bits here: skipped).  A padding lane of a group points all its
+//     edges at a private dummy slot that starts at a positive prior: its messages stay positive for ever (sums of
+//     positive numbers), its decision never flips, nobody else reads the slot.  Padding check lanes (positions without
+//     a check) compute on their own never-referenced slots.  Checks sit at host-chosen positions (pos_chk).
+//   * sign on the multiplier (one v_cndmask of alpha's high word per edge, `mag * (+-alpha)` is the one multiply),
+//     alpha = 1 - 2^-it formed by scalar shifts, the suffix recurrence without its identity additions (see bit_update_deg),
+//     LDS byte addresses in one register per edge (hot path and decision-flip path), the uniform prior in a scalar pair,
+//     one broadcast read per wave for the mismatch test, cold kernel arguments read where they are used;
+//   * threads per workgroup = 64 * waves actually needed (not a power of two), with the LDS stride MP a compile-time
+//     power of two >= m, so offsets stay instruction immediates.
+//
+// Arithmetic and association order are the reference's, fp64, -ffp-contract=off: the LLR bits
+// equal the CPU restatement's (tests/test_gpu_parity.py compares them).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bp_kernel.hip.h"
+
+namespace bposd {
+
+struct BpClassParams {
+    int m, n;
+    long long B;
+    int max_iter;
+    double ms_scaling;
+    double ps_clip;
+    int osd_enabled;
+    const uint8_t* __restrict__ synd;     // [B, m]
+    const double* __restrict__ llr0;      // [n]
+    const uint8_t* __restrict__ sel;      // [B, n] nullable
+    const double* __restrict__ llr0_alt;  // [n]
+    const int* __restrict__ pos_chk;      // [CPT * NTMAX]         entry j * NTMAX + tid: check at that position, -1 = none (the host
+                                          //                       orders checks for few bank conflicts in the bit pass)
+    const int* __restrict__ pos_bit;      // [VPT * NTMAX]         entry r * NTMAX + tid: bit in slot r of thread tid, -1 = padding
+    const int* __restrict__ bit_slot;     // [DVHI * VPT * NTMAX]  entry (d * VPT + r) * NTMAX + tid: LDS slot of the d-th edge
+                                          //                       (ascending check index); the thread's dummy slot where there is none
+    const int* __restrict__ grp_deg;      // [VPT * NTMAX / 64]    entry r * (NTMAX / 64) + wave: degree of that 64-lane group, 0 = empty
+    uint8_t* __restrict__ out_bp;
+    uint8_t* __restrict__ out_osd0;
+    uint8_t* __restrict__ out_osdw;
+    uint8_t* __restrict__ out_conv;
+    int* __restrict__ out_iters;
+    double* __restrict__ out_llr;
+    double* __restrict__ llr_ws;
+    double* __restrict__ llr_tmp;         // [gridDim.x][n] LLRs of the syndrome a workgroup is on, written only when they will
+                                          // be read: in the last iteration, or every iteration if out_llr is set
+    int* __restrict__ osd_list;
+    int* __restrict__ counters;
+    unsigned long long* __restrict__ iter_total;
+};
+
+__host__ __device__ inline size_t bp_class_lds_bytes(int DC, int mp, int ntmax) {
+    // messages + one dummy slot per thread + mismatch bitmap + control words
+    return ((size_t)DC * mp + ntmax + 2) * 8 + (size_t)(mp / 32 + 2) * 4 + 8 * 4;
+}
+
+typedef const __attribute__((address_space(4))) BpClassParams* bpc_args_ptr;
+__device__ __forceinline__ bpc_args_ptr bpc_args() {  // cold arguments: read from the kernarg segment at the point of use
+    bpc_args_ptr a = (bpc_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return a;
+}
+__device__ __forceinline__ int bpc_table_load(const int* base, unsigned int lane_off, unsigned int const_off) {
+    asm volatile("" : "+v"(lane_off));  // address formed here, not hoisted into a 64-bit register pair per table row
+    return *(const int*)((const char*)base + (lane_off + const_off));
+}
+
+// Bit update for a bit of degree D: posterior, and the D outgoing messages  out[d] = prefix(d) + suffix(d)  with
+//   prefix(d) = ((l0 + c[0]) + ...) + c[d-1]   (from the top of the column, prior included)
+//   suffix(d) = ((0.0 + c[D-1]) + ...) + c[d+1] (from the bottom)
+// as the reference accumulates them.  The additions with the literal 0.0 are not executed:  x + 0.0 == x  unless x is
+// -0.0, and 0.0 + c == c unless c is -0.0, in which case the two suffixes differ only in the sign of a zero that is then
+// added to a prefix -- and a prefix is never -0.0 (a sum is -0.0 only if both operands are; the prior log((1-p)/p) never
+// is), so  prefix + (+0.0) == prefix + (-0.0)  bit for bit.  tests/test_gpu_parity.py compares LLR bits.
+template <int D>
+__device__ __forceinline__ void bit_update_deg(double l0, const double* c, double& llr, double* out) {
+    double pre[D + 1];
+    pre[0] = l0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) pre[d + 1] = pre[d] + c[d];
+    llr = pre[D];
+    out[D - 1] = pre[D - 1];
+    if (D >= 2) {
+        double suf = c[D - 1];
+        out[D - 2] = pre[D - 2] + suf;
+#pragma unroll
+        for (int d = D - 3; d >= 0; --d) {
+            suf = suf + c[d + 1];
+            out[d] = pre[d] + suf;
+        }
+    }
+}
+
+// wave-uniform degree -> straight-line arm
+template <int D, int DVHI>
+__device__ __forceinline__ void bit_update_dispatch(int deg, double l0, const double* c, double& llr, double* out) {
+    if constexpr (D >= DVHI) {
+        bit_update_deg<DVHI>(l0, c, llr, out);
+    } else {
+        if (deg == D) bit_update_deg<D>(l0, c, llr, out);
+        else bit_update_dispatch<D + 1, DVHI>(deg, l0, c, llr, out);
+    }
+}
+
+// DC: degree of every check;  DVLO .. DVHI: bit degrees that occur;  CPT / VPT: check / bit slots per thread;
+// MPT: LDS stride (power of two >= m);  NTMAX: table stride = largest workgroup this instantiation is launched with;
+// METHOD: 0 product-sum, 1 min-sum;  UPRIOR: uniform channel and no per-shot channel (prior in a scalar pair)
+template <int DC, int DVLO, int DVHI, int CPT, int VPT, int MPT, int NTMAX, int MINW, int METHOD, bool UPRIOR>
+__global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m = P.m, n = P.n;
+    constexpr int MP = MPT;
+    constexpr int NW = NTMAX / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NT = (int)blockDim.x;  // multiple of 64
+
+    typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+    const unsigned int msg_base = (unsigned int)(uintptr_t)(lds_bytes)smem;
+    double* msg_plain = reinterpret_cast<double*>(smem);
+    unsigned int* diffw = reinterpret_cast<unsigned int*>(msg_plain + (size_t)DC * MP + NTMAX + 2);
+    int* sh = reinterpret_cast<int*>(diffw + (MP / 32 + 2));
+    const unsigned int diffw_base = (unsigned int)(uintptr_t)(lds_bytes)diffw;
+#define BPC_AT(a) ((msg_ptr)(uintptr_t)(a))
+#define BPC_BIT(r) bpc_table_load(bpc_args()->pos_bit, (unsigned int)tid * 4u, (unsigned int)((r) * NTMAX * 4))
+
+    // ---- per-thread tables: byte address of every edge of my bits, degree of my groups (wave-uniform)
+    unsigned int eaddr[VPT][DVHI];
+    int gdeg[VPT];
+    double l0[UPRIOR ? 1 : VPT];
+    if (UPRIOR) {
+        const double v = bpc_args()->llr0[0];
+        l0[0] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
+#define BPC_L0(r) l0[UPRIOR ? 0 : (r)]
+#pragma unroll
+    for (int r = 0; r < VPT; ++r) {
+        gdeg[r] = __builtin_amdgcn_readfirstlane(bpc_args()->grp_deg[r * NW + wave]);
+        if (!UPRIOR) {
+            const int bit = BPC_BIT(r);
+            l0[r] = bit >= 0 ? bpc_args()->llr0[bit] : 1.0;  // (UPRIOR: the host has checked that the prior is > 0)
+        }
+#pragma unroll
+        for (int d = 0; d < DVHI; ++d) eaddr[r][d] = msg_base + 8u * (unsigned int)bpc_args()->bit_slot[(d * VPT + r) * NTMAX + tid];
+    }
+    // wave-uniform: does group j of this wave hold any check?  (checks fill the first ceil(m / 64) waves' positions)
+    bool chk_live[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) chk_live[j] = ((wave << 6) + j * NT) < ((m + 63) & ~63);
+    const int want_llr_s = __builtin_amdgcn_readfirstlane(bpc_args()->out_llr != nullptr ? 1 : 0);
+    auto want_llr = [&]() -> bool {
+        int w = want_llr_s;
+        asm volatile("" : "+s"(w));
+        return w != 0;
+    };
+
+    for (;;) {
+        if (tid == 0) {
+            int zero = 0;
+            asm volatile("" : "+v"(zero));
+            sh[0] = zero;
+            sh[1] = zero;
+            sh[2] = atomicAdd(&bpc_args()->counters[0], 1);
+        }
+        __syncthreads();
+        const long long s = __builtin_amdgcn_readfirstlane(sh[2]);
+        if (s >= P.B) break;
+
+        // ---- syndrome bits of my checks; the mismatch bitmap (indexed by check) starts as the syndrome
+        bool sbit[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = bpc_table_load(bpc_args()->pos_chk, (unsigned int)tid * 4u, (unsigned int)(j * NTMAX * 4));
+            sbit[j] = (c >= 0) ? ((bpc_args()->synd[(size_t)s * m + c] & 1) != 0) : false;
+            const unsigned long long bal = __ballot(sbit[j]);
+            if (lane == 0 && ((wave << 6) + j * NT) < MP) {
+                const int w0 = ((wave << 6) + j * NT) >> 5;
+                diffw[w0] = (unsigned int)bal;
+                diffw[w0 + 1] = (unsigned int)(bal >> 32);
+                if (bal) sh[0] = 1;
+            }
+        }
+        if (!UPRIOR && bpc_args()->sel) {
+#pragma unroll
+            for (int r = 0; r < VPT; ++r) {
+                const int i = BPC_BIT(r);
+                if (i >= 0) l0[r] = bpc_args()->sel[(size_t)s * n + i] ? bpc_args()->llr0_alt[i] : bpc_args()->llr0[i];
+            }
+        }
+        // ---- a3: every edge's bit->check message starts at the prior
+#define BPC_LLRT (bpc_args()->llr_tmp + (size_t)blockIdx.x * n)
+        unsigned int decmask = 0u;
+#pragma unroll
+        for (int r = 0; r < VPT; ++r) {
+            double lp = BPC_L0(r);
+            if (UPRIOR) asm volatile("" : "+s"(lp));
+            if (want_llr()) {  // a syndrome that needs no iteration reports the priors
+                const int i = BPC_BIT(r);
+                if (i >= 0) BPC_LLRT[i] = lp;
+            }
+#pragma unroll
+            for (int d = 0; d < DVHI; ++d)
+                if (d < DVLO || d < gdeg[r]) *BPC_AT(eaddr[r][d]) = lp;
+        }
+        __syncthreads();
+
+        int it_done = 0;
+        bool conv = (sh[0] == 0);
+        if (!conv) {
+#pragma clang loop unroll(disable)
+            for (int it = 1;; ++it) {
+                const int fi = it & 1;
+                {
+                    unsigned long long mis = 0ull;
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j)
+                        if (chk_live[j])
+                            mis |= *(const volatile __attribute__((address_space(3))) unsigned long long*)(uintptr_t)(
+                                diffw_base + (unsigned int)(((wave << 6) + j * NT) >> 3));
+                    if (lane == 0 && mis) sh[fi] = 1;
+                }
+                if (it > P.max_iter) {
+                    __syncthreads();
+                    conv = (sh[fi] == 0);
+                    it_done = P.max_iter;
+                    break;
+                }
+                // =================== check -> bit pass (a4 / a5), speculative for it >= 2 ===========
+                const unsigned long long alpha_u = alpha_bits_for_iteration(P.ms_scaling, it);
+                const int alpha_lo = (int)(unsigned int)alpha_u, alpha_hi = (int)(unsigned int)(alpha_u >> 32), nalpha_hi = alpha_hi ^ (int)0x80000000;
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    if (!chk_live[j]) continue;  // wave-uniform
+                    msg_ptr mc = BPC_AT(msg_base + 8u * (unsigned int)(tid + j * NT));
+                    double v[DC];
+#pragma unroll
+                    for (int k = 0; k < DC; ++k) v[k] = mc[k * MP];
+                    if (METHOD == 1) {
+                        double pre[DC], suf[DC];
+                        pre[0] = __DBL_MAX__;
+#pragma unroll
+                        for (int k = 1; k < DC; ++k) pre[k] = min_abs(pre[k - 1], v[k - 1]);
+                        suf[DC - 1] = __DBL_MAX__;
+#pragma unroll
+                        for (int k = DC - 2; k >= 0; --k) suf[k] = min_abs(suf[k + 1], v[k + 1]);
+                        bool neg[DC];
+                        bool par = sbit[j];
+#pragma unroll
+                        for (int k = 0; k < DC; ++k) {
+                            neg[k] = (v[k] <= 0.0);  // a zero counts as negative, as in the reference
+                            par ^= neg[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < DC; ++k) {
+                            const double mag = (k == 0) ? suf[0] : (k == DC - 1 ? pre[DC - 1] : min_pos(pre[k], suf[k]));
+                            const double sa = __hiloint2double((par ^ neg[k]) ? nalpha_hi : alpha_hi, alpha_lo);
+                            mc[k * MP] = mag * sa;
+                        }
+                    } else {
+                        double pre[DC], th[DC];
+                        double t = 1.0;
+#pragma unroll
+                        for (int k = 0; k < DC; ++k) {
+                            pre[k] = t;
+                            th[k] = pm_tanh(v[k] / 2);
+                            t *= th[k];
+                        }
+                        t = 1.0;
+                        const double sg = sbit[j] ? -1.0 : 1.0;
+#pragma unroll
+                        for (int k = DC - 1; k >= 0; --k) {
+                            const double x = pre[k] * t;
+                            double o = sg * pm_log((1 + x) / (1 - x));
+                            if (P.ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
+                                if (o > P.ps_clip) o = P.ps_clip;
+                                if (o < -P.ps_clip) o = -P.ps_clip;
+                            }
+                            mc[k * MP] = o;
+                            t *= th[k];
+                        }
+                    }
+                }
+                __syncthreads();
+                if (sh[fi] == 0) {
+                    conv = true;
+                    it_done = it - 1;
+                    break;
+                }
+                if (tid == 0) sh[fi ^ 1] = 0;
+                const bool keep_llr = (it == P.max_iter) || want_llr();  // uniform
+                // ============ bit pass: posterior, decision, bit -> check (a6 / a7) ============
+                double cm[VPT][DVHI];
+#pragma unroll
+                for (int r = 0; r < VPT; ++r)
+#pragma unroll
+                    for (int d = 0; d < DVHI; ++d)
+                        if (d < DVLO ? gdeg[r] != 0 : d < gdeg[r]) cm[r][d] = *BPC_AT(eaddr[r][d]);
+#pragma unroll
+                for (int r = 0; r < VPT; ++r) {
+                    if (gdeg[r] == 0) continue;  // wave-uniform
+                    double out[DVHI], t;
+                    bit_update_dispatch<DVLO, DVHI>(gdeg[r], BPC_L0(r), cm[r], t, out);
+#pragma unroll
+                    for (int d = 0; d < DVHI; ++d)
+                        if (d < DVLO || d < gdeg[r]) *BPC_AT(eaddr[r][d]) = out[d];
+                    if (keep_llr) {
+                        const int bi = BPC_BIT(r);
+                        if (bi >= 0) BPC_LLRT[bi] = t;
+                    }
+                    const unsigned int dnew = (t <= 0.0) ? 1u : 0u;
+                    if (dnew != ((decmask >> r) & 1u)) {  // (a padding bit never gets here: its messages stay positive)
+                        decmask ^= 1u << r;
+#pragma unroll
+                        for (int d = 0; d < DVHI; ++d) {
+                            if (d < DVLO || d < gdeg[r]) {
+                                unsigned int pa = eaddr[r][d];
+                                asm volatile("" : "+v"(pa));  // keep the rare path's address arithmetic in the branch
+                                const int c = (int)((pa - msg_base) >> 3) & (MP - 1);
+                                atomicXor(&diffw[c >> 5], 1u << (c & 31));
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- results
+        const bool to_osd = (!conv) && bpc_args()->osd_enabled;
+        if (tid == 0) {
+            if (to_osd) {
+                const int slot = atomicAdd(&bpc_args()->counters[1], 1);
+                bpc_args()->osd_list[slot] = (int)s;
+                sh[3] = slot;
+            }
+            if (bpc_args()->out_conv) bpc_args()->out_conv[s] = conv ? 1 : 0;
+            if (bpc_args()->out_iters) bpc_args()->out_iters[s] = it_done;
+            if (it_done) atomicAdd(bpc_args()->iter_total, (unsigned long long)it_done);
+        }
+        __syncthreads();
+        const int slot = to_osd ? sh[3] : 0;
+#pragma unroll
+        for (int r = 0; r < VPT; ++r) {
+            const int i = BPC_BIT(r);
+            if (i >= 0) {
+                const size_t o = (size_t)s * n + i;
+                const uint8_t b = (uint8_t)((decmask >> r) & 1u);
+                if (bpc_args()->out_bp) bpc_args()->out_bp[o] = b;
+                if (!to_osd) {
+                    bpc_args()->out_osdw[o] = b;
+                    if (bpc_args()->out_osd0) bpc_args()->out_osd0[o] = b;
+                } else {
+                    bpc_args()->llr_ws[(size_t)slot * n + i] = BPC_LLRT[i];
+                }
+                if (want_llr()) bpc_args()->out_llr[o] = BPC_LLRT[i];
+            }
+        }
+        __syncthreads();
+    }
+#undef BPC_AT
+#undef BPC_BIT
+#undef BPC_L0
+#undef BPC_LLRT
+}
+
+}  // namespace bposd

@@ -26,10 +26,22 @@
 #include "bp_kernel.hip.h"
 #include "bp_large_kernel.hip.h"
 #include "bp_local_kernel.hip.h"
+#include "bp_class_kernel.hip.h"
+// occupancy targets of the class kernel instances (minimum waves per SIMD the register allocation must allow)
+#ifndef BPOSD_CLASS7_MINW
+#define BPOSD_CLASS7_MINW 6
+#endif
+#ifndef BPOSD_CLASS7_MINW_PS
+#define BPOSD_CLASS7_MINW_PS 4
+#endif
+#ifndef BPOSD_CLASS6_MINW_PS
+#define BPOSD_CLASS6_MINW_PS 4
+#endif
 #include "bp_serial_kernel.hip.h"
 #include "osd_large_kernel.hip.h"
 #include "osd_kernel.hip.h"
 #include "local_layout.h"
+#include "class_layout.h"
 
 using namespace bposd;
 
@@ -102,6 +114,11 @@ struct bposd_handle {
     int local_mp = 0;
     long long local_passes = 0;  // simulated LDS passes of the bit pass in the chosen layout (ideal: 4 * MP / 32)
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
+    // class BP kernel (bp_class_kernel.hip.h): every check has the same degree, bit degrees inside one compiled range
+    bool class_ok = false;
+    int class_dc = 0, class_dvlo = 0, class_dvhi = 0, class_mp = 0, class_nt = 0;
+    long class_read_cycles = 0, class_write_cycles = 0, class_read_floor = 0, class_write_floor = 0;  // modelled, one bit pass
+    int *d_cpos_chk = nullptr, *d_cpos_bit = nullptr, *d_cbit_slot = nullptr, *d_cgrp_deg = nullptr;
     bool large = false;   // beyond the register-resident OSD kernel: HBM-resident matrix, device rank probe
     bool bp_hbm = false;  // BP messages do not fit one CU's LDS either: HBM-resident BP kernel
     int max_iter = 0;
@@ -649,6 +666,109 @@ int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
     return 0;
 }
 
+// ------------------------------------------------------------------ class BP kernel: tables + launch
+// Instances: (check degree; bit degrees) = (7; 3..4) -- the reference's three example codes -- and (6; 3) -- H1922 with
+// product-sum, other (3,6)-regular codes --, LDS stride 256 / 512 / 1024, two bit slots per thread.
+struct ClassShape { int dc, dvlo, dvhi; };
+const ClassShape kClassShapes[] = {{7, 3, 4}, {6, 3, 3}};
+constexpr int kClassVPT = 2;
+
+int build_tables_class(bposd_handle* h) {
+    h->class_ok = false;
+    if (h->bp_hbm || h->m > 1024) return 0;
+    int dc = -1;
+    for (int c = 0; c < h->m; ++c) {
+        const int d = h->rp[c + 1] - h->rp[c];
+        if (dc < 0) dc = d;
+        else if (d != dc) return 0;
+    }
+    std::vector<int> vdeg(h->n, 0);
+    for (int e : h->ci) vdeg[e]++;
+    int lo = 1 << 30, hi = 0;
+    for (int d : vdeg) { lo = std::min(lo, d); hi = std::max(hi, d); }
+    const ClassShape* shp = nullptr;
+    for (const auto& k : kClassShapes)
+        if (k.dc == dc && k.dvlo <= lo && hi <= k.dvhi) { shp = &k; break; }
+    if (!shp) return 0;
+    class_layout::Tables T;
+    bool ok = false;
+    int MP = 0;
+    const int iters = getenv("BPOSD_LAYOUT_ITERS") ? atoi(getenv("BPOSD_LAYOUT_ITERS")) : 200000;
+    for (int mp : {256, 512, 1024}) {
+        if (h->m > mp) continue;
+        if (class_layout::build(h->rp, h->ci, h->m, h->n, shp->dc, shp->dvlo, shp->dvhi, kClassVPT, mp, mp, iters, T)) { ok = true; MP = mp; break; }
+    }
+    if (!ok) return 0;
+    if (getenv("BPOSD_DEBUG_OCC"))
+        fprintf(stderr, "[bposd] class BP layout: %d threads, stride %d, bit pass %ld read cycles (floor %ld) + %ld write cycles (floor %ld)\n", T.NT,
+                MP, T.read_cycles, T.read_floor, T.write_cycles, T.write_floor);
+    auto up = [&](int** dst, const std::vector<int>& v) -> int {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        HIP_TRY(h, hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1)));
+        HIP_TRY(h, hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc;
+    if ((rc = up(&h->d_cpos_chk, T.pos_chk))) return rc;
+    if ((rc = up(&h->d_cpos_bit, T.pos_bit))) return rc;
+    if ((rc = up(&h->d_cbit_slot, T.bit_slot))) return rc;
+    if ((rc = up(&h->d_cgrp_deg, T.grp_deg))) return rc;
+    h->class_dc = shp->dc; h->class_dvlo = shp->dvlo; h->class_dvhi = shp->dvhi; h->class_mp = MP; h->class_nt = T.NT;
+    h->class_read_cycles = T.read_cycles; h->class_write_cycles = T.write_cycles;
+    h->class_read_floor = T.read_floor; h->class_write_floor = T.write_floor;
+    h->class_ok = true;
+    return 0;
+}
+
+template <int DC, int DVLO, int DVHI, int MP, int MINW, int METHOD, bool UPRIOR>
+int launch_bp_class_t(bposd_handle* h, const BpClassParams& C) {
+    auto k = bp_class_kernel<DC, DVLO, DVHI, 1, kClassVPT, MP, MP, MINW, METHOD, UPRIOR>;
+    const int nt = h->class_nt;
+    const size_t lds = bp_class_lds_bytes(DC, MP, MP);
+    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
+    int wg_per_cu = 1;
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void*)k, nt, lds));
+    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] class BP kernel <%d;%d..%d> stride %d: %d threads, %zu B LDS, %d workgroups per CU\n", DC, DVLO, DVHI, MP, nt, lds, wg_per_cu);
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 16));
+    long long grid = std::min<long long>(C.B, (long long)h->num_cu * wg_per_cu);
+    if (grid < 1) grid = 1;
+    int rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n);
+    if (rc) return rc;
+    BpClassParams Cq = C;
+    Cq.llr_tmp = (double*)h->cur->bpl_llr.p;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->cur->stream, Cq);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+template <int DC, int DVLO, int DVHI, int MINW_MS, int MINW_PS>
+int launch_bp_class_shape(bposd_handle* h, const BpClassParams& C, bool uprior) {
+    const bool ms = h->cfg.bp_method == BPOSD_BP_MIN_SUM;
+#define BPOSD_CLASS_MP(MPV)                                                                                              \
+    if (h->class_mp == MPV) {                                                                                            \
+        if (ms) return uprior ? launch_bp_class_t<DC, DVLO, DVHI, MPV, MINW_MS, 1, true>(h, C) : launch_bp_class_t<DC, DVLO, DVHI, MPV, MINW_MS, 1, false>(h, C); \
+        return uprior ? launch_bp_class_t<DC, DVLO, DVHI, MPV, MINW_PS, 0, true>(h, C) : launch_bp_class_t<DC, DVLO, DVHI, MPV, MINW_PS, 0, false>(h, C); \
+    }
+    BPOSD_CLASS_MP(256)
+    BPOSD_CLASS_MP(512)
+    BPOSD_CLASS_MP(1024)
+#undef BPOSD_CLASS_MP
+    return fail(h, BPOSD_ERR_UNSUPPORTED, "no class BP kernel for stride %d", h->class_mp);
+}
+
+int launch_bp_class(bposd_handle* h, const BpParams& P) {
+    BpClassParams C{};
+    C.m = P.m; C.n = P.n; C.B = P.B; C.max_iter = P.max_iter; C.ms_scaling = P.ms_scaling; C.ps_clip = P.ps_clip; C.osd_enabled = P.osd_enabled;
+    C.synd = P.synd; C.llr0 = P.llr0; C.sel = P.sel; C.llr0_alt = P.llr0_alt;
+    C.pos_chk = h->d_cpos_chk; C.pos_bit = h->d_cpos_bit; C.bit_slot = h->d_cbit_slot; C.grp_deg = h->d_cgrp_deg;
+    C.out_bp = P.out_bp; C.out_osd0 = P.out_osd0; C.out_osdw = P.out_osdw; C.out_conv = P.out_conv; C.out_iters = P.out_iters;
+    C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total;
+    const bool uprior = h->probs_uniform && P.sel == nullptr && h->probs[0] > 0.0 && h->probs[0] < 0.5;
+    if (h->class_dc == 7) return launch_bp_class_shape<7, 3, 4, BPOSD_CLASS7_MINW, BPOSD_CLASS7_MINW_PS>(h, C, uprior);
+    if (h->class_dc == 6) return launch_bp_class_shape<6, 3, 3, 8, BPOSD_CLASS6_MINW_PS>(h, C, uprior);
+    return fail(h, BPOSD_ERR_UNSUPPORTED, "no class BP kernel for check degree %d", h->class_dc);
+}
+
 int launch_bp_local(bposd_handle* h, const BpParams& P) {
     BpLocalParams L{};
     L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling; L.osd_enabled = P.osd_enabled;
@@ -1019,6 +1139,7 @@ void bposd_destroy(bposd_handle* h) {
                     (void*)h->d_var_pos, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt,
                     (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
                     (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl,
+                    (void*)h->d_cpos_chk, (void*)h->d_cpos_bit, (void*)h->d_cbit_slot, (void*)h->d_cgrp_deg,
                     (void*)h->d_cp, (void*)h->d_ce, (void*)h->d_erow, (void*)h->d_lvl_ptr, (void*)h->d_lvl_bits})
         if (p) (void)hipFree(p);
     for (CallRecord* rs : {h->rec, h->lane_rec})
@@ -1210,6 +1331,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     if (h->bp_hbm) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
     else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, shp) * shape_cpt(shp), shape_threads(h, shp), 2 * shape_cpt(shp)));
     if (!h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
+    if (!h->bp_hbm && (!(h->local_ok && cfg->bp_method == BPOSD_BP_MIN_SUM) || getenv("BPOSD_CLASS_ALWAYS"))) CREATE_RC(build_tables_class(h));
     if (cfg->schedule == 1) {
         if (h->dv_max > BPS_MAXDV) {
             fail(h, BPOSD_ERR_UNSUPPORTED, "serial schedule: bit degree %d exceeds %d", h->dv_max, BPS_MAXDV);
@@ -1248,9 +1370,11 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26))
-        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes) or 16 .. 26 (local-edge kernel)");
-    if (variant >= 16 && !(h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM))
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32)
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel) or 32 (class kernel)");
+    if (variant == 32 && !h->class_ok)
+        return fail(h, BPOSD_ERR_UNSUPPORTED, "the class BP kernel needs one check degree and bit degrees of a compiled range");
+    if (variant >= 16 && variant <= 26 && !(h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM))
         return fail(h, BPOSD_ERR_UNSUPPORTED, "the local-edge BP kernel needs a (3,6)-regular code with n = 2m and min-sum");
     h->bp_variant = variant;
     return BPOSD_OK;
@@ -1371,8 +1495,10 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         L.out_iters = P.out_iters; L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list;
         L.counters = P.counters; L.iter_total = P.iter_total;
         if ((rc = launch_bp_large(h, L))) return rc;
-    } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || h->bp_variant >= 16)) {
+    } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || (h->bp_variant >= 16 && h->bp_variant <= 26))) {
         if ((rc = launch_bp_local(h, P))) return rc;
+    } else if (h->class_ok && (h->bp_variant == 0 || h->bp_variant == 32)) {
+        if ((rc = launch_bp_class(h, P))) return rc;
     } else if ((rc = launch_bp(h, P))) return rc;
     if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[1], h->cur->stream));
     h->currec->ran_osd = false;
