@@ -101,14 +101,38 @@ __device__ __forceinline__ void bit_update_deg(double l0, const double* c, doubl
     }
 }
 
-// wave-uniform degree -> straight-line arm
-template <int D, int DVHI>
-__device__ __forceinline__ void bit_update_dispatch(int deg, double l0, const double* c, double& llr, double* out) {
-    if constexpr (D >= DVHI) {
-        bit_update_deg<DVHI>(l0, c, llr, out);
+// The bit pass of one owned bit with D edges (D compile-time): messages in, posterior, messages out, decision test.
+template <int D, int MP, class KeepLlr>
+__device__ __forceinline__ void bit_pass_deg(const unsigned int* eaddr, double l0, int r, unsigned int& decmask, unsigned int msg_base,
+                                             unsigned int* diffw, bool keep_llr, KeepLlr&& store_llr) {
+    double c[D], out[D], t;
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[d] = *((msg_ptr)(uintptr_t)eaddr[d]);
+    bit_update_deg<D>(l0, c, t, out);
+#pragma unroll
+    for (int d = 0; d < D; ++d) *((msg_ptr)(uintptr_t)eaddr[d]) = out[d];
+    if (keep_llr) store_llr(t);
+    const unsigned int dnew = (t <= 0.0) ? 1u : 0u;
+    if (dnew != ((decmask >> r) & 1u)) {  // (a padding bit never gets here: its messages stay positive)
+        decmask ^= 1u << r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            unsigned int pa = eaddr[d];
+            asm volatile("" : "+v"(pa));  // keep the rare path's address arithmetic in the branch
+            const int c2 = (int)((pa - msg_base) >> 3) & (MP - 1);
+            atomicXor(&diffw[c2 >> 5], 1u << (c2 & 31));
+        }
+    }
+}
+// run-time (wave-uniform) degree -> compile-time arm
+template <int DVLO, int DVHI, int MP, class KeepLlr>
+__device__ __forceinline__ void bit_pass_arm(int D, const unsigned int* eaddr, double l0, int r, unsigned int& decmask, unsigned int msg_base,
+                                             unsigned int* diffw, bool keep_llr, KeepLlr&& store_llr) {
+    if constexpr (DVLO >= DVHI) {
+        bit_pass_deg<DVHI, MP>(eaddr, l0, r, decmask, msg_base, diffw, keep_llr, store_llr);
     } else {
-        if (deg == D) bit_update_deg<D>(l0, c, llr, out);
-        else bit_update_dispatch<D + 1, DVHI>(deg, l0, c, llr, out);
+        if (D == DVLO) bit_pass_deg<DVLO, MP>(eaddr, l0, r, decmask, msg_base, diffw, keep_llr, store_llr);
+        else bit_pass_arm<DVLO + 1, DVHI, MP>(D, eaddr, l0, r, decmask, msg_base, diffw, keep_llr, store_llr);
     }
 }
 
@@ -300,35 +324,22 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
                 if (tid == 0) sh[fi ^ 1] = 0;
                 const bool keep_llr = (it == P.max_iter) || want_llr();  // uniform
                 // ============ bit pass: posterior, decision, bit -> check (a6 / a7) ============
-                double cm[VPT][DVHI];
-#pragma unroll
-                for (int r = 0; r < VPT; ++r)
-#pragma unroll
-                    for (int d = 0; d < DVHI; ++d)
-                        if (d < DVLO ? gdeg[r] != 0 : d < gdeg[r]) cm[r][d] = *BPC_AT(eaddr[r][d]);
+                // one self-contained arm per (slot, degree): loads, sums, stores and the decision test of a D-edge bit with D a
+                // compile-time constant; the wave-uniform degree of the group picks the arm (no partially defined arrays: those
+                // became loop-carried registers, 24 of them in a first version)
 #pragma unroll
                 for (int r = 0; r < VPT; ++r) {
-                    if (gdeg[r] == 0) continue;  // wave-uniform
-                    double out[DVHI], t;
-                    bit_update_dispatch<DVLO, DVHI>(gdeg[r], BPC_L0(r), cm[r], t, out);
+                    if (gdeg[r] == 0) continue;  // wave-uniform: no bits in this group
+                    bool hit = false;
 #pragma unroll
-                    for (int d = 0; d < DVHI; ++d)
-                        if (d < DVLO || d < gdeg[r]) *BPC_AT(eaddr[r][d]) = out[d];
-                    if (keep_llr) {
-                        const int bi = BPC_BIT(r);
-                        if (bi >= 0) BPC_LLRT[bi] = t;
-                    }
-                    const unsigned int dnew = (t <= 0.0) ? 1u : 0u;
-                    if (dnew != ((decmask >> r) & 1u)) {  // (a padding bit never gets here: its messages stay positive)
-                        decmask ^= 1u << r;
-#pragma unroll
-                        for (int d = 0; d < DVHI; ++d) {
-                            if (d < DVLO || d < gdeg[r]) {
-                                unsigned int pa = eaddr[r][d];
-                                asm volatile("" : "+v"(pa));  // keep the rare path's address arithmetic in the branch
-                                const int c = (int)((pa - msg_base) >> 3) & (MP - 1);
-                                atomicXor(&diffw[c >> 5], 1u << (c & 31));
-                            }
+                    for (int D = DVLO; D <= DVHI; ++D) {
+                        if (!hit && (D == DVHI || gdeg[r] == D)) {
+                            hit = true;
+                            bit_pass_arm<DVLO, DVHI, MP>(D, eaddr[r], BPC_L0(r), r, decmask, msg_base, diffw, keep_llr,
+                                                         [&](double t) {
+                                                             const int bi = BPC_BIT(r);
+                                                             if (bi >= 0) BPC_LLRT[bi] = t;
+                                                         });
                         }
                     }
                 }

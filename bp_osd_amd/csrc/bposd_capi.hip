@@ -29,13 +29,13 @@
 #include "bp_class_kernel.hip.h"
 // occupancy targets of the class kernel instances (minimum waves per SIMD the register allocation must allow)
 #ifndef BPOSD_CLASS7_MINW
-#define BPOSD_CLASS7_MINW 6
+#define BPOSD_CLASS7_MINW 8
 #endif
 #ifndef BPOSD_CLASS7_MINW_PS
-#define BPOSD_CLASS7_MINW_PS 4
+#define BPOSD_CLASS7_MINW_PS 7  // (8 would cap the SGPRs at 80 and spill them)
 #endif
 #ifndef BPOSD_CLASS6_MINW_PS
-#define BPOSD_CLASS6_MINW_PS 4
+#define BPOSD_CLASS6_MINW_PS 7
 #endif
 #include "bp_serial_kernel.hip.h"
 #include "osd_large_kernel.hip.h"
@@ -754,6 +754,13 @@ int launch_bp_class_shape(bposd_handle* h, const BpClassParams& C, bool uprior) 
     BPOSD_CLASS_MP(1024)
 #undef BPOSD_CLASS_MP
     return fail(h, BPOSD_ERR_UNSUPPORTED, "no class BP kernel for stride %d", h->class_mp);
+}
+
+// Measured (tools/bp_iteration_cost.py): the class kernel wins everywhere except product-sum on a (3,6)-regular code of
+// ~1000 checks (H1922: 8.3 against 6.4 ps per edge-iteration) -- VALU-bound, and the two-checks-per-thread shape of the
+// regular LDS kernel interleaves two division chains per thread.
+bool class_preferred(const bposd_handle* h) {
+    return !(h->cfg.bp_method != BPOSD_BP_MIN_SUM && is_reg63(h) && h->class_mp == 1024);
 }
 
 int launch_bp_class(bposd_handle* h, const BpParams& P) {
@@ -1497,7 +1504,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         if ((rc = launch_bp_large(h, L))) return rc;
     } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || (h->bp_variant >= 16 && h->bp_variant <= 26))) {
         if ((rc = launch_bp_local(h, P))) return rc;
-    } else if (h->class_ok && (h->bp_variant == 0 || h->bp_variant == 32)) {
+    } else if (h->class_ok && (h->bp_variant == 32 || (h->bp_variant == 0 && class_preferred(h)))) {
         if ((rc = launch_bp_class(h, P))) return rc;
     } else if ((rc = launch_bp(h, P))) return rc;
     if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[1], h->cur->stream));
