@@ -34,8 +34,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (bp_method, ms_scaling_factor, max_iter, osd_method, osd_order, per-GPU batch, ps_clip)
+    # name: (bp_method, ms_scaling_factor, max_iter, osd_method, osd_order, per-GPU batch, ps_clip)   [code: by name prefix]
     "h1922_ms_cs7": ("ms", 0.0, 0, "osd_cs", 7, 131072, 0.0),    # configs[3]: the metric's configuration
+    # the reference's own stated workload, /root/reference/examples/qldpc_decode_example.py:5-23: [[400,16,6]] =
+    # hgp(mkmn_16_4_6), min-sum with the variable scaling factor, max_iter = n, osd_cs order 42, error rate 0.05
+    "hgp400_ms_cs42": ("ms", 0.0, 0, "osd_cs", 42, 131072, 0.0),
     "h1922_ms_osd0": ("ms", 0.0, 0, "osd0", 0, 65536, 0.0),      # configs[1]
     # configs[2] as the reference computes it: product-sum without clipping saturates (tanh -> 1, log -> inf, NaN)
     "h1922_ps_cs60": ("ps", 0.0, 0, "osd_cs", 60, 65536, 0.0),
@@ -134,14 +137,19 @@ def main():
         max_iter = args.max_iter
     q = args.p
 
-    from bp_osd_amd.codes import h1922, l29k
+    from bp_osd_amd.codes import h1922, l29k, hgp
 
     large = args.config.startswith("l29k")
+    ref400 = args.config.startswith("hgp400")
     cpu_one, cpu_per_proc = CPU_SAMPLE.get(args.config, CPU_SAMPLE_DEFAULT)
     if args.cpu_sample >= 0:
         cpu_one = args.cpu_sample
     # logical operators: the reference's generic route for H1922, the closed-form product basis for the large code
-    code = l29k(compute_logicals="closed_form" if rank == 0 else False) if large else h1922(compute_logicals=(rank == 0))
+    if ref400:
+        seed = np.loadtxt(os.path.join(ROOT, "tests", "golden", "mkmn_16_4_6.txt"), dtype=int).astype(np.uint8)
+        code = hgp(seed, compute_logicals=(rank == 0))
+    else:
+        code = l29k(compute_logicals="closed_form" if rank == 0 else False) if large else h1922(compute_logicals=(rank == 0))
     H = code.hz
     m, n = H.shape
     E = H.nnz
@@ -188,6 +196,9 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if not args.rehearse_on_one_gpu and args.gpus > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s); "
+                         "use --rehearse-on-one-gpu for a functional rehearsal of the N > 1 path on one GPU")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -339,12 +350,17 @@ def main():
         conv_frac = float(d_conv.to(torch.float32).mean().item())
         it_cpu = d_iters.cpu().numpy()
 
-        # which BP kernel ran, and what it moves through LDS per syndrome-iteration
-        local_edge = (not large) and bp_method == "ms" and args.variant in (0, 16, 17, 18)
+        # which BP kernel ran (asked of the library), and what it moves through LDS per syndrome-iteration
+        kinfo = dec.bp_kernel_info()
+        local_edge = kinfo["kernel"] == "bp_local_kernel"
+        code_label = ("[[29524,484]] HGP of a seeded (5,6)-regular 110x132 matrix, hz 14520x29524, " if large else
+                      "[[400,16,6]] HGP of mkmn_16_4_6 (the reference's example code), hz 192x400, " if ref400 else
+                      "[[1922,50]] HGP (31x31 circulant 1+x^2+x^5) hz 961x1922, ")
         num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         out = {
-            "metric": "syndromes decoded/sec (whole node) + logical error rate, HGP [[1922,50]] p=0.05" if not large else
-                      "syndromes decoded/sec (whole node), large HGP 14520x29524 (BASELINE configs[4])",
+            "metric": "syndromes decoded/sec (whole node), large HGP 14520x29524 (BASELINE configs[4])" if large else
+                      "syndromes decoded/sec (whole node) + logical error rate, HGP [[400,16,6]] p=0.05 (reference example)" if ref400 else
+                      "syndromes decoded/sec (whole node) + logical error rate, HGP [[1922,50]] p=0.05",
             "value": value,
             "unit": "syndromes/s",
             "n_gpus": world,
@@ -357,8 +373,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: " + ("[[29524,484]] HGP of a seeded (5,6)-regular 110x132 matrix, hz 14520x29524, "
-                                                  if large else "[[1922,50]] HGP (31x31 circulant 1+x^2+x^5) hz 961x1922, ") +
+                "workload": f"{args.config}: " + code_label +
                             f"{'min-sum' if bp_method == 'ms' else 'product-sum'} BP"
                             f"{' variable scaling' if bp_method == 'ms' and ms == 0 else (f' scaling {ms}' if bp_method == 'ms' else '')}"
                             f"{f' (ps_clip {ps_clip})' if bp_method == 'ps' and ps_clip else (' (no clipping, as the reference)' if bp_method == 'ps' else '')}, "
@@ -370,6 +385,8 @@ def main():
                 "bp_variant": args.variant,
                 "pipelined_steps": nslots,
                 "timed_outputs": ["osdw", "osd0", "bp", "converged", "iters"],
+                "batches": f"{nbatch} distinct seeded batches alternate over the timed steps; the logical error rates, the CPU "
+                           "comparison and the isolated kernel times are on batch 0",
             },
             "logical_error_rate": ler,
             "logical_error_rate_eb": None if ler is None else float(np.sqrt(ler * (1 - ler) / B)),
@@ -390,7 +407,7 @@ def main():
             "kernel_only_syndromes_per_s_per_gpu": B / ((t_last["bp_ms"] + t_last["osd_ms"]) * 1e-3),
             "roofline": {
                 "kernel": "bp_large_kernel (BP message passing, messages in HBM)" if large else
-                          ("bp_local_kernel" if local_edge else "bp_kernel") + " (BP message passing, LDS- and register-resident messages)",
+                          kinfo["kernel"] + " (BP message passing, LDS- and register-resident messages)",
                 "bound": "hbm" if large else "on-chip (HBM algorithmic for reference)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -421,9 +438,11 @@ def main():
             rd = wr = doubles * 8
             cyc = rd / LDS_READ_B64_BYTES_PER_CLK + wr / LDS_WRITE_B64_BYTES_PER_CLK
             bound_ms = lambda iters: iters * cyc / (num_cu * CLOCK_HZ) * 1e3
-            # fp64 VALU issue: per check 14 v_min_f64 + 6 v_mul_f64 + 6 v_cmp (sign test), per bit 6 v_add_f64 + 1 v_cmp;
-            # a wave64 fp64 instruction issues over 4 cycles on one of the CU's 4 SIMDs
-            fp64_cyc = (26 * m + 7 * n) / 64 * 4 / 4
+            # fp64 VALU issue: per check of degree d  3d - 4 v_min_f64 + d v_mul_f64 + d v_cmp (sign test), per bit of degree
+            # d  3d - 3 v_add_f64 + 1 v_cmp (H1922: 26 per check, 7 per bit); a wave64 fp64 instruction issues over 4
+            # cycles on one of the CU's 4 SIMDs
+            vdeg = np.diff(H.tocsc().indptr)
+            fp64_cyc = (float(np.sum(5 * np.diff(H.indptr) - 4)) + float(np.sum(3 * vdeg - 2))) / 64 * 4 / 4
             out["roofline_lds"] = {
                 "kernel": out["roofline"]["kernel"],
                 "bound": "lds",
@@ -437,6 +456,8 @@ def main():
                 "fp64_valu_issue_frac_isolated": (t_last["bp_iterations"] * fp64_cyc / (num_cu * CLOCK_HZ) * 1e3 / t_last["bp_ms"])
                 if t_last["bp_ms"] > 0 else None,
                 "ns_per_syndrome_iteration_isolated": t_last["bp_ms"] * 1e6 / max(t_last["bp_iterations"], 1),
+                "ps_per_edge_iteration_isolated": t_last["bp_ms"] * 1e9 / max(t_last["bp_iterations"], 1) / E,
+                "bit_pass_bank_model": {k: kinfo[k] for k in ("read_cycles", "read_floor", "write_cycles", "write_floor")},
                 "note": "LDS-pipe cycles the selected kernel needs per syndrome-iteration (conflict-free) x executed iterations / "
                         "(CUs x peak clock) over the measured launch time; fp64_valu_issue_frac is the same ratio for the fp64 "
                         "instruction issue slots",

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "bposd_last_timing",
     "bposd_info",
     "bposd_layout_info",
+    "bposd_bp_kernel_info",
     "bposd_set_bp_variant",
     "bposd_debug_local_layout",
     "bposd_last_error",
@@ -116,6 +117,8 @@ def load():
     lib.bposd_info.restype = C.c_int
     lib.bposd_layout_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.bposd_layout_info.restype = C.c_int
+    lib.bposd_bp_kernel_info.argtypes = [vp, C.POINTER(C.c_int32), vp]
+    lib.bposd_bp_kernel_info.restype = C.c_int
     lib.bposd_debug_local_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.bposd_debug_local_layout.restype = C.c_int
     lib.bposd_set_bp_variant.argtypes = [vp, C.c_int32]

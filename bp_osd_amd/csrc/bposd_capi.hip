@@ -112,7 +112,8 @@ struct bposd_handle {
     // local-edge BP kernel (bp_local_kernel.hip.h): available for (3,6)-regular codes with n = 2m, min-sum
     bool local_ok = false;
     int local_mp = 0;
-    long long local_passes = 0;  // simulated LDS passes of the bit pass in the chosen layout (ideal: 4 * MP / 32)
+    long long local_passes = 0;  // modelled ds_read_b64 cycles of the bit pass in the chosen layout (floor: 4 * MP / 32)
+    long long local_wcycles = 0; // modelled ds_write_b64 cycles of the bit pass (floor: 6 * 4 * MP / 64)
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
     // class BP kernel (bp_class_kernel.hip.h): every check has the same degree, bit degrees inside one compiled range
     bool class_ok = false;
@@ -127,6 +128,7 @@ struct bposd_handle {
     bool priors_finite = true;  // no channel probability is exactly 0 or 1
     bool alt_finite = true;     // the same for the alternative channel of the last select call
     int bp_variant = 0;
+    int last_bp_kernel = -1;  // BPOSD_BP_KERNEL_* of the last BP launch
     // host copies
     std::vector<int> rp, ci;
     std::vector<double> probs;
@@ -578,6 +580,7 @@ int build_tables_local(bposd_handle* h) {
         fprintf(stderr, "[bposd] local-edge layout: bit pass %lld read cycles (floor %d) + %lld write cycles (floor %d), %d mixed pairs, %d uniform positions\n",
                 best.passes, 4 * (MP / 32), best.wcycles, 6 * 4 * (MP / 64), best.mixed, best.nfull);
     h->local_passes = best.passes;
+    h->local_wcycles = best.wcycles;
 
     // ---- tables
     const int G = MP / 64;
@@ -1422,6 +1425,22 @@ int bposd_layout_info(bposd_handle* h, int64_t* natural, int64_t* chosen, int64_
     return BPOSD_OK;
 }
 
+int bposd_bp_kernel_info(bposd_handle* h, int32_t* kernel, int64_t* lds_model) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (kernel) *kernel = h->last_bp_kernel;
+    if (lds_model) {
+        for (int k = 0; k < 4; ++k) lds_model[k] = 0;
+        if (h->last_bp_kernel == BPOSD_BP_KERNEL_LOCAL) {
+            lds_model[0] = h->local_passes; lds_model[1] = 4 * (h->local_mp / 32);
+            lds_model[2] = h->local_wcycles; lds_model[3] = 6 * 4 * (h->local_mp / 64);
+        } else if (h->last_bp_kernel == BPOSD_BP_KERNEL_CLASS) {
+            lds_model[0] = h->class_read_cycles; lds_model[1] = h->class_read_floor;
+            lds_model[2] = h->class_write_cycles; lds_model[3] = h->class_write_floor;
+        }
+    }
+    return BPOSD_OK;
+}
+
 int bposd_synchronize(bposd_handle* h) {
     if (!h) return BPOSD_ERR_INVALID;
     DeviceGuard dev_guard(h->device);
@@ -1491,8 +1510,10 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
 
     if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[0], h->cur->stream));
     if (h->cfg.schedule == 1) {
+        h->last_bp_kernel = BPOSD_BP_KERNEL_SERIAL;
         if ((rc = launch_bp_serial(h, P))) return rc;
     } else if (h->bp_hbm) {
+        h->last_bp_kernel = BPOSD_BP_KERNEL_LARGE;
         BpLargeParams L{};
         L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling; L.ps_clip = P.ps_clip;
         L.osd_enabled = P.osd_enabled; L.mp = h->tab_mp;
@@ -1503,10 +1524,15 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         L.counters = P.counters; L.iter_total = P.iter_total;
         if ((rc = launch_bp_large(h, L))) return rc;
     } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || (h->bp_variant >= 16 && h->bp_variant <= 26))) {
+        h->last_bp_kernel = BPOSD_BP_KERNEL_LOCAL;
         if ((rc = launch_bp_local(h, P))) return rc;
     } else if (h->class_ok && (h->bp_variant == 32 || (h->bp_variant == 0 && class_preferred(h)))) {
+        h->last_bp_kernel = BPOSD_BP_KERNEL_CLASS;
         if ((rc = launch_bp_class(h, P))) return rc;
-    } else if ((rc = launch_bp(h, P))) return rc;
+    } else {
+        h->last_bp_kernel = BPOSD_BP_KERNEL_LDS;
+        if ((rc = launch_bp(h, P))) return rc;
+    }
     if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[1], h->cur->stream));
     h->currec->ran_osd = false;
     if (osd_on) {

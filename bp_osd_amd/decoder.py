@@ -454,8 +454,19 @@ class BpOsdDecoder:
         _lib.check(self._lib, self._h, self._lib.bposd_layout_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"natural": a.value, "chosen": b.value, "ideal": c.value}
 
+    BP_KERNEL_NAMES = {0: "bp_kernel", 1: "bp_local_kernel", 2: "bp_class_kernel", 3: "bp_large_kernel", 4: "bp_serial_kernel"}
+
+    def bp_kernel_info(self):
+        """Which BP kernel the last decode call launched, with the bank-conflict model of its bit pass (modelled LDS
+        cycles per workgroup and their conflict-free floors; zeros where the kernel has no such model)."""
+        k = C.c_int32()
+        mdl = np.zeros(4, dtype=np.int64)
+        _lib.check(self._lib, self._h, self._lib.bposd_bp_kernel_info(self._h, C.byref(k), mdl.ctypes.data))
+        return {"kernel": self.BP_KERNEL_NAMES.get(k.value, "none"), "read_cycles": int(mdl[0]), "read_floor": int(mdl[1]),
+                "write_cycles": int(mdl[2]), "write_floor": int(mdl[3])}
+
     def set_bp_variant(self, variant: int):
-        """Tuning / test knob: 0 auto; 1, 2, 4 LDS kernel shapes; 16, 17, 18 local-edge kernel (see the C header)."""
+        """Tuning / test knob: 0 auto; 1, 2, 4 LDS kernel shapes; 16 .. 26 local-edge kernel; 32 class kernel (see the C header)."""
         _lib.check(self._lib, self._h, self._lib.bposd_set_bp_variant(self._h, int(variant)))
 
     # ------------------------------------------------------------------ mutators / attributes

@@ -188,6 +188,16 @@ int bposd_info(bposd_handle *h, int32_t *rank, int32_t *num_candidates, int32_t 
  * order the library chose, and the conflict-free ideal.  Any pointer may be NULL. */
 int bposd_layout_info(bposd_handle *h, int64_t *natural_cycles, int64_t *chosen_cycles, int64_t *ideal_cycles);
 
+/* Diagnostics: which BP kernel the last decode call launched, and the bank-conflict model of its bit pass.
+ * kernel: BPOSD_BP_KERNEL_*.  lds_model[4] (local-edge and class kernels, else zeros): modelled ds_read_b64 cycles of one
+ * bit pass per workgroup, their conflict-free floor, modelled ds_write_b64 cycles, their floor.  Any pointer may be NULL. */
+#define BPOSD_BP_KERNEL_LDS 0    /* bp_kernel: every message in LDS, per-lane degree predicates */
+#define BPOSD_BP_KERNEL_LOCAL 1  /* bp_local_kernel: (3,6)-regular codes, a third of the messages in registers */
+#define BPOSD_BP_KERNEL_CLASS 2  /* bp_class_kernel: one check degree, bits sorted into degree classes */
+#define BPOSD_BP_KERNEL_LARGE 3  /* bp_large_kernel: messages in HBM */
+#define BPOSD_BP_KERNEL_SERIAL 4 /* bp_serial_kernel: schedule = serial */
+int bposd_bp_kernel_info(bposd_handle *h, int32_t *kernel, int64_t *lds_model);
+
 /* Diagnostics, host only (needs no device): the ownership / position layout the local-edge BP kernel would use for a
  * (3,6)-regular pcm with n = 2m.  out[16]: modelled ds_read_b64 cycles of one bit pass, their conflict-free
  * floor, positions in select-free (uniform) groups, mixed (group, slot) pairs, positions, nine class sizes, modelled
@@ -198,7 +208,8 @@ int bposd_debug_local_layout(const int32_t *csr_indptr, const int32_t *csr_indic
  * 0 = auto; 1, 2, 4 = LDS kernel with 1 / 2 / 4 checks per thread; 16, 17, 18 = local-edge kernel (a third of the
  * messages in registers; (3,6)-regular codes with n = 2m and min-sum only, BPOSD_ERR_UNSUPPORTED otherwise):
  * 2 checks per thread at <= 80 / <= 64 VGPRs, 1 check per thread.  Auto picks 16 where it applies.  All variants
- * return identical results. */
+ * return identical results.  32 = class kernel (one check degree, bit degrees of a compiled range; auto picks it where it
+ * applies and the local-edge kernel does not). */
 int bposd_set_bp_variant(bposd_handle *h, int32_t variant);
 
 /* Message for the last error on this handle (h == NULL: last create() failure). */
