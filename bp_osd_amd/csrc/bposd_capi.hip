@@ -18,6 +18,7 @@
 #include <climits>
 #include <cstring>
 #include <string>
+#include <tuple>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -209,6 +210,23 @@ int set_max_lds(bposd_handle* h, const void* kernel, size_t lds) {
     if (lds <= cur) return 0;
     HIP_TRY(h, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     cur = lds;
+    return 0;
+}
+
+// Resident workgroups per CU of a kernel at a workgroup size and dynamic-LDS size: asked of the runtime once per process,
+// device and configuration (the query costs microseconds on the one-syndrome path).
+int cached_occupancy(bposd_handle* h, const void* kernel, int nt, size_t lds, int* out) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, const void*, int, size_t>, int> memo;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_tuple(h->device, kernel, nt, lds);
+    auto it = memo.find(key);
+    if (it == memo.end()) {
+        int v = 1;
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, nt, lds));
+        it = memo.emplace(key, std::max(v, 1)).first;
+    }
+    *out = it->second;
     return 0;
 }
 
@@ -655,7 +673,7 @@ int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
     const size_t lds = bp_local_lds_bytes(L.mp);
     { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
     int wg_per_cu = 1;
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void*)k, nt, lds));
+    { int rc_occ = cached_occupancy(h, (const void*)k, nt, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
     if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] local-edge BP kernel: %d threads, %zu B LDS, %d workgroups per CU\n", nt, lds, wg_per_cu);
     wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
     long long grid = std::min<long long>(L.B, (long long)h->num_cu * wg_per_cu);
@@ -730,7 +748,7 @@ int launch_bp_class_t(bposd_handle* h, const BpClassParams& C) {
     const size_t lds = bp_class_lds_bytes(DC, MP, MP);
     { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
     int wg_per_cu = 1;
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void*)k, nt, lds));
+    { int rc_occ = cached_occupancy(h, (const void*)k, nt, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
     if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] class BP kernel <%d;%d..%d> stride %d: %d threads, %zu B LDS, %d workgroups per CU\n", DC, DVLO, DVHI, MP, nt, lds, wg_per_cu);
     wg_per_cu = std::max(1, std::min(wg_per_cu, 16));
     long long grid = std::min<long long>(C.B, (long long)h->num_cu * wg_per_cu);
@@ -940,14 +958,19 @@ int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
     const int rows_per_thread = OSD_RPT;
     const int NT = std::min(64 * OSD_MAXW, std::max(64, ((h->m + rows_per_thread - 1) / rows_per_thread + 63) / 64 * 64));
     const size_t lds = osd_lds_bytes(W, NT * OSD_RPT);
-    long long grid = std::min<long long>(B, h->num_cu);
+    auto k = osd_kernel<W>;
+    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
+    // persistent workgroups: as many per CU as registers and LDS admit (H1922: one 8-wave workgroup; the reference's
+    // [[400,16,6]] code: four 2-wave workgroups -- with one per CU its 32 k eliminations per batch took longer than BP)
+    int wg_per_cu = 1;
+    { int rc_occ = cached_occupancy(h, (const void*)k, NT, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
+    long long grid = std::min<long long>(B, (long long)h->num_cu * wg_per_cu);
     if (grid < 1) grid = 1;
     int rc = ensure_lanes(h, &Lane::osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
     if (rc) return rc;
     OsdParams Q = P;
     Q.rows_ws = (unsigned long long*)h->cur->osd_rows_ws.p;
-    auto k = osd_kernel<W>;
-    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->osd_now ? h->osd_now : h->cur->osd_stream, Q);
     HIP_TRY(h, hipGetLastError());
     return 0;
