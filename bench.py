@@ -266,7 +266,17 @@ def main():
     elapsed = time.perf_counter() - t0
     bp_ms, osd_ms, iters_tot, osd_tot = stats["bp_ms"], stats["osd_ms"], stats["iters"], stats["osd"]
 
+    per_rank = None
     if world > 1:
+        # per-rank step time, BP / OSD kernel time and gather time, so that a sub-linear scaling curve can be attributed
+        gms = pipe.gather_ms()
+        mine = torch.tensor([1e3 * elapsed / max(args.steps, 1), float(np.mean(bp_ms)) if bp_ms else 0.0,
+                             float(np.mean(osd_ms)) if osd_ms else 0.0, float(np.mean(gms)) if gms else 0.0],
+                            dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(rank=r, ms_per_step=float(t[0]), bp_ms=float(t[1]), osd_ms=float(t[2]), gather_ms=float(t[3]))
+                    for r, t in enumerate(allr)]
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -478,6 +488,12 @@ def main():
                 "note": "the single-pass figure of SURVEY.md §8(d); a blocked elimination revisits the trailing matrix once "
                         "per group of pivot panels and its inner loop is bound by LDS table look-ups (DESIGN.md §4.5)",
             }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if args.rehearse_on_one_gpu:
+            out["rehearsal"] = True
+            out["rehearsal_note"] = ("every rank decoded on device 0 and the gather ran over gloo on host copies of the packed rows: "
+                                     "a functional rehearsal of the N > 1 code path, not a measurement")
         if host is not None:
             out["value_host_to_host"] = B / host["osdw"]
             out["host_to_host"] = {

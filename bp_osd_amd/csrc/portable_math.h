@@ -11,8 +11,15 @@
  *   log:   x = 2^k (1 + f), sqrt(2)/2 <= 1 + f < sqrt(2);  s = f / (2 + f);  log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
  *   expm1: x = k ln2 + r, |r| <= ln2 / 2;  expm1(r) from a rational approximation in r^2;  rescale by 2^k
  *   tanh:  1 - 2 / (expm1(2|x|) + 2) for |x| >= 1,  -t / (t + 2) with t = expm1(-2|x|) below
- * with the published minimax coefficients of those reductions; errors stay below 1 ulp (tests/test_portable_math.py
- * measures them against libm).  Plain C99; usable from host C, host C++ and HIP device code.
+ * These are the reductions and the minimax coefficients (Lg1..Lg7, Q1..Q5, ln2_hi / ln2_lo) of FreeBSD's msun / Sun's
+ * fdlibm -- e_log.c, s_expm1.c, s_tanh.c -- restated here without their table look-ups, special-case branches and
+ * extended-precision tricks that do not matter for the argument ranges of the check update.  fdlibm's licence line:
+ *   "Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.  Developed at SunPro, a Sun Microsystems, Inc.
+ *    business.  Permission to use, copy, modify, and distribute this software is freely granted, provided that this
+ *    notice is preserved."
+ * Errors stay below 1 ulp (tests/test_portable_math.py measures them against libm).  Plain C99; usable from host C,
+ * host C++ and HIP device code.  fdlibm is third-party, permissively licensed code; it is NOT part of the reference
+ * repository (/root/reference contains no arithmetic for this path).
  */
 #ifndef BPOSD_PORTABLE_MATH_H
 #define BPOSD_PORTABLE_MATH_H
@@ -20,7 +27,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PM_FN __host__ __device__ static inline
 #else
 #define PM_FN static inline

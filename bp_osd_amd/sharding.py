@@ -109,7 +109,12 @@ class StepPipeline:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.do_gather = bool(gather) and self.world > 1
+        if self.do_gather and self.nslots > 2:
+            # packed[k & 1] is gathered when step k is finalised; with three steps in flight step k + 2 would pack into
+            # the buffer of step k before that gather has read it
+            raise ValueError("with the gather on, at most 2 steps may be in flight (the packed rows are double-buffered)")
         self.packed = packed
+        self._gather_marks = []    # per gathered step: (start, end) CUDA events, or a host duration in seconds
         self.pending = []          # (k, timed) enqueued, not yet finalised
         self.gather_done = [None, None]
         self.gather_bufs = None
@@ -136,11 +141,21 @@ class StepPipeline:
         if self.do_gather:
             buf = k & 1
             src = self.packed[buf]
+            if src.is_cuda:
+                ev0 = self._torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            else:
+                import time as _time
+                t0 = _time.perf_counter()
             self._dist.gather(src, self.gather_bufs[buf] if self.rank == self.dst else None, dst=self.dst, group=self.group)
             if src.is_cuda:  # the gather runs on torch's stream: guard the buffer's reuse with an event
-                ev = self._torch.cuda.Event()
+                ev = self._torch.cuda.Event(enable_timing=True)
                 ev.record()
                 self.gather_done[buf] = ev
+                if timed:
+                    self._gather_marks.append((ev0, ev))
+            elif timed:
+                self._gather_marks.append(_time.perf_counter() - t0)
             if self.on_gathered is not None and self.rank == self.dst:
                 self.on_gathered(k, [b[:c] for b, c in zip(self.gather_bufs[buf], self.counts)])
 
@@ -156,6 +171,13 @@ class StepPipeline:
                 self.gather_done[buf] = None
             self.pack(slot, buf)
         self.pending.append((k, timed))
+
+    def gather_ms(self):
+        """Durations (ms) of the gathers of the timed steps on this rank; call after fence()."""
+        out = []
+        for g in self._gather_marks:
+            out.append(g[0].elapsed_time(g[1]) if isinstance(g, tuple) else 1e3 * g)
+        return out
 
     def drain(self):
         while self.pending:

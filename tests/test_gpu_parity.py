@@ -3,9 +3,12 @@ the CPU oracle on the same seeded inputs, against the committed golden vectors, 
 benchmark's full batch size -- through size-independent properties.
 
 Bars: bit-exact on every integer output (osdw, osd0, bp, converge, iter) for min-sum AND bit-exact on
-the fp64 LLRs (the OSD column order depends on every bit of them).  Product-sum uses device tanh/log,
-which differ from glibc at the ulp level: LLRs to 1e-9 relative, integer outputs equal wherever BP
-converged on both sides, mismatches elsewhere counted and bounded.
+the fp64 LLRs (the OSD column order depends on every bit of them).  Product-sum: the kernels evaluate
+tanh / log with csrc/portable_math.h (fdlibm's reductions, +-*/ only); against the oracle in the SAME
+mode (`ps_math = 1`) every output and every LLR bit is equal -- which checks the message schedule, not
+the transcendental code, since both sides compile that one header -- and against the oracle on the
+platform libm (`ps_math = 0`, what the reference calls) the bar is a tolerance: LLRs to 1e-9 relative,
+integer outputs equal wherever BP converged on both sides, mismatches elsewhere counted and bounded.
 """
 import itertools
 
@@ -156,6 +159,23 @@ def test_hgp400_vs_oracle(gpu_ready, hgp400, cfg):
         r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
         ref = OracleDecoder(H, **kw).decode_batch(syn)
         _compare_exact(r, ref)
+
+
+def test_h1922_configs1_osd0_at_the_operating_point(gpu_ready, h1922):
+    """BASELINE configs[1]'s exact tuple: min-sum, variable scaling, max_iter = n, osd_method "osd0", q = 0.05 (the auto-
+    selected local-edge kernel); every output and the LLR doubles against the oracle."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    q = 0.05
+    _, syn = _syndromes(h1922.hz, q, 2048, 23)
+    kw = dict(error_rate=q, max_iter=0, bp_method="ms", ms_scaling_factor=0, osd_method="osd0", osd_order=0)
+    dec = BpOsdDecoder(h1922.hz, **kw)
+    r = _gpu_decode(dec, syn)
+    ref = OracleDecoder(h1922.hz, **kw).decode_batch(syn)
+    _compare_exact(r, ref)
+    assert (r["osdw"] == r["osd0"]).all()
+    assert dec.bp_kernel_info()["kernel"] == "bp_local_kernel"
 
 
 @pytest.mark.parametrize("variant", [1, 2, 4])
@@ -705,6 +725,56 @@ def test_reference_example_codes_625_900(gpu_ready, seed_file, N, K):
         r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
         assert 0.02 < (~r["converged"]).mean() < 0.98  # both branches are exercised
         _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
+
+
+@pytest.mark.parametrize("seed_file", ["mkmn_16_4_6.txt", "mkmn_20_5_8.txt", "mkmn_24_6_10.txt"])
+def test_class_kernel_equals_lds_kernel_and_oracle(gpu_ready, seed_file):
+    """bp_class_kernel (auto-selected for the reference's example codes: check degree 7, bit degrees 3 / 4) against the
+    generic LDS kernel (variant 1) and the oracle: min-sum with variable scaling over 3000 iterations (the dummy slots of
+    padding lanes overflow to +inf on the way and must stay inert), a non-uniform channel (per-lane priors), a per-shot
+    two-valued channel, and product-sum with a clip -- every output and the LLR bits."""
+    import os
+
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp
+    from oracle import OracleDecoder
+
+    seed = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", seed_file)).astype(np.uint8)
+    code = hgp(seed, compute_logicals=False)
+    H = code.hz
+    n = H.shape[1]
+    rng = np.random.default_rng(n)
+    q = 0.07
+    _, syn = _syndromes(H, q, 256, n + 1)
+    probs = rng.uniform(0.02, 0.12, size=n)
+    cases = [
+        dict(error_rate=q, max_iter=3000, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=9),
+        dict(channel_probs=probs, max_iter=30, bp_method="ms", ms_scaling_factor=0.75, osd_method="osd_e", osd_order=6),
+        dict(error_rate=q, max_iter=25, bp_method="ps", ps_clip=20.0, ps_math=1, osd_method="osd_cs", osd_order=5),
+    ]
+    for kw in cases:
+        gkw = {k: v for k, v in kw.items() if k != "ps_math"}
+        a = BpOsdDecoder(H, **gkw)
+        ra = _gpu_decode(a, syn)
+        assert a.bp_kernel_info()["kernel"] == "bp_class_kernel"
+        b = BpOsdDecoder(H, **gkw)
+        b.set_bp_variant(1)
+        rb = _gpu_decode(b, syn)
+        assert b.bp_kernel_info()["kernel"] == "bp_kernel"
+        _compare_exact(ra, dict(rb, converged=rb["converged"].astype(np.uint8)))
+        assert 0 < (~ra["converged"]).sum() < len(syn)
+        _compare_exact(ra, OracleDecoder(H, **kw).decode_batch(syn))
+    # per-shot two-valued channel (css_decode_sim.py:207-248): prior selected per syndrome and bit
+    alt = rng.uniform(0.02, 0.3, size=n)
+    sel = (rng.random((len(syn), n)) < 0.3).astype(np.uint8)
+    kw = dict(channel_probs=probs, max_iter=20, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=4)
+    a = BpOsdDecoder(H, **kw)
+    got = a.decode_batch(syn, prior_select=sel, alt_channel_probs=alt)
+    assert a.bp_kernel_info()["kernel"] == "bp_class_kernel"
+    b = BpOsdDecoder(H, **kw)
+    b.set_bp_variant(1)
+    assert (got == b.decode_batch(syn, prior_select=sel, alt_channel_probs=alt)).all()
+    assert (a.batch_iter == b.batch_iter).all() and (a.batch_osd0 == b.batch_osd0).all()
 
 
 def test_reference_example_script_configuration(gpu_ready, hgp400):

@@ -145,6 +145,13 @@ def _pipeline_worker(rank, world, port, total, steps, q_out):
             assert len(pipe.pending) <= nslots
         pipe.fence()
         assert log == [(0, False)] + [(k, True) for k in range(1, steps + 1)]
+        assert len(pipe.gather_ms()) == steps  # one gather duration per timed step
+        # three steps in flight would repack a buffer before its gather has read it: refused
+        try:
+            StepPipeline(3, launch, wait, pack=pack, packed=packed, rows=rows)
+            raise AssertionError("nslots = 3 with the gather on must be refused")
+        except ValueError:
+            pass
         if rank == 0:
             assert checked == list(range(steps + 1))
             q_out.put("ok")
