@@ -59,7 +59,8 @@ class BposdConfig(C.Structure):
         ("weight_fn", C.c_int32),
         ("schedule", C.c_int32),
         ("ps_clip", C.c_double),
-        ("reserved", C.c_int32 * 2),
+        ("osd_e_bit_order", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 

@@ -74,6 +74,7 @@ struct BpParams {
     int* __restrict__ osd_list;         // [cap]: syndrome index of each slot
     int* __restrict__ counters;         // [0] work queue, [1] osd count
     unsigned long long* __restrict__ iter_total;  // sum of iterations executed
+    int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
 };
 
 __host__ __device__ inline size_t bp_lds_bytes(int DC, int mp) {
@@ -171,7 +172,11 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
         }
         __syncthreads();
         const long long s = sh[2];
-        if (s >= P.B) break;  // uniform: every wave reaches this with the same value
+        if (s >= P.B) {
+            // the chunk loop of the host-pointer API launches the next chunk's kernels when this one's tail begins
+            if (s == P.B && tid == 0 && P.tail_flag) *(volatile int*)P.tail_flag = 1;
+            break;
+        }  // uniform: every wave reaches this with the same value
 
         // ---- syndrome bits of my checks; the mismatch bitmap starts as the syndrome itself
         bool sbit[CPT];

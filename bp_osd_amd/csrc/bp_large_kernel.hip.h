@@ -54,6 +54,7 @@ struct BpLargeParams {
     int* __restrict__ osd_list;
     int* __restrict__ counters;
     unsigned long long* __restrict__ iter_total;
+    int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
 };
 
 __host__ __device__ inline size_t bp_large_lds_bytes(int m, int n) {
@@ -82,7 +83,11 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
         }
         __syncthreads();
         const long long s = sh[2];
-        if (s >= P.B) break;
+        if (s >= P.B) {
+            // the chunk loop of the host-pointer API launches the next chunk's kernels when this one's tail begins
+            if (s == P.B && tid == 0 && P.tail_flag) *(volatile int*)P.tail_flag = 1;
+            break;
+        }
         const uint8_t* syn = P.synd + (size_t)s * m;
 
         // mismatch bitmap = syndrome; messages = priors; decisions = 0

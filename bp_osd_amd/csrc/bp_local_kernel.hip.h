@@ -57,6 +57,7 @@ struct BpLocalParams {
     int* __restrict__ osd_list;
     int* __restrict__ counters;
     unsigned long long* __restrict__ iter_total;
+    int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
 };
 
 __host__ __device__ inline size_t bp_local_lds_bytes(int mp) {
@@ -207,7 +208,11 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
         }
         __syncthreads();
         const long long s = __builtin_amdgcn_readfirstlane(sh[2]);
-        if (s >= P.B) break;
+        if (s >= P.B) {
+            // the chunk loop of the host-pointer API launches the next chunk's kernels when this one's tail begins
+            if (s == P.B && tid == 0 && bpl_args()->tail_flag) *(volatile int*)bpl_args()->tail_flag = 1;
+            break;
+        }
 
         // ---- syndrome bits of my checks; the mismatch bitmap (indexed by position) starts as the syndrome
         bool sbit[CPT];

@@ -78,8 +78,24 @@ struct Lane {
     DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
     DevBuf osd_rows_ws;       // OSD kernel's per-workgroup spill area for finished row words
     DevBuf llr_ws, osd_list, io_synd, io_osdw, io_osd0, io_bp, io_conv, io_iters, io_llr, io_sel;
+    // host-pointer calls: the outputs are downloaded on a copy stream of the lane's own right after the BP kernel (event-
+    // ordered), the rows the OSD kernel rewrites come from compact copies [list slot][n] once it has run
+    DevBuf io_cmp0, io_cmpw;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy = nullptr;    // the chunk's downloads have left the lane's io buffers
+    int* h_list = nullptr;           // page-locked copy of the chunk's OSD list (syndrome index per slot)
+    size_t h_list_cap = 0;
+    bool copy_pending = false;
     long long* d_osd_dbg = nullptr;  // diagnostics (BPOSD_OSD_DEBUG=1): phase timestamps
     int* d_counters = nullptr;       // 4 ints
+    // per-shot channel of a device-pointer call (bposd_decode_batch_select_device): priors and weights of the alternative
+    // channel, 2n doubles, copied from a page-locked staging block on the lane's own stream -- consecutive select calls
+    // overlap like plain ones (the first version drained every lane and made two blocking copies per call)
+    double* d_alt = nullptr;
+    double* h_alt = nullptr;
+    hipEvent_t ev_alt = nullptr;     // the staging block has been read
+    bool alt_busy = false;
+    int* h_tail = nullptr;           // page-locked, device-visible: the BP kernel of this lane's current call has entered its tail
 };
 
 // What bposd_last_timing reports: one record per kernel pair launched by the last call (one per chunk for a
@@ -126,8 +142,6 @@ struct bposd_handle {
     int max_iter = 0;
     int rank = 0, kprime = 0, ncand = 0;
     bool probs_uniform = true;
-    bool priors_finite = true;  // no channel probability is exactly 0 or 1
-    bool alt_finite = true;     // the same for the alternative channel of the last select call
     int bp_variant = 0;
     int last_bp_kernel = -1;  // BPOSD_BP_KERNEL_* of the last BP launch
     // host copies
@@ -150,6 +164,9 @@ struct bposd_handle {
     long long batch_hint = 0;          // > 0 while a chunked host call is being enqueued: its whole batch size
     bool async_pending = false;        // a device-pointer call may still be running on some lane
     hipStream_t osd_now = nullptr;     // stream the OSD kernel of the call being enqueued goes to
+    uint8_t *cmp_osd0 = nullptr, *cmp_osdw = nullptr;  // compact OSD rows of the chunk being enqueued (host-pointer calls)
+    bool lane_alt = false;             // the call being enqueued takes the alternative channel from its lane's buffers
+    bool tail_gate = false;            // the call being enqueued is a chunk of a host-pointer call: its BP kernel reports its tail
     std::string err;
 };
 
@@ -194,6 +211,7 @@ int sync_all_lanes(bposd_handle* h) {
     for (auto& l : h->lanes) {
         if (l.stream) HIP_TRY(h, hipStreamSynchronize(l.stream));
         if (l.osd_stream) HIP_TRY(h, hipStreamSynchronize(l.osd_stream));
+        if (l.copy_stream) HIP_TRY(h, hipStreamSynchronize(l.copy_stream));
     }
     h->async_pending = false;
     return 0;
@@ -303,9 +321,6 @@ int upload_priors(bposd_handle* h) {
     h->probs_uniform = true;
     for (int i = 1; i < h->n; ++i)
         if (h->probs[i] != h->probs[0]) { h->probs_uniform = false; break; }
-    h->priors_finite = true;
-    for (int i = 0; i < h->n; ++i)
-        if (!std::isfinite(l0[i])) h->priors_finite = false;
     // a11: weight(x) = sum over set bits of log(1/p_i) (ldpc v2).  For a uniform 0 < p < 1 every term is
     // the same positive number, so the sums order candidates exactly like Hamming weights (identical
     // partial sums, strictly increasing in the count) and the integer path is used.
@@ -790,7 +805,7 @@ int launch_bp_class(bposd_handle* h, const BpParams& P) {
     C.synd = P.synd; C.llr0 = P.llr0; C.sel = P.sel; C.llr0_alt = P.llr0_alt;
     C.pos_chk = h->d_cpos_chk; C.pos_bit = h->d_cpos_bit; C.bit_slot = h->d_cbit_slot; C.grp_deg = h->d_cgrp_deg;
     C.out_bp = P.out_bp; C.out_osd0 = P.out_osd0; C.out_osdw = P.out_osdw; C.out_conv = P.out_conv; C.out_iters = P.out_iters;
-    C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total;
+    C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total; C.tail_flag = P.tail_flag;
     const bool uprior = h->probs_uniform && P.sel == nullptr && h->probs[0] > 0.0 && h->probs[0] < 0.5;
     if (h->class_dc == 7) return launch_bp_class_shape<7, 3, 4, BPOSD_CLASS7_MINW, BPOSD_CLASS7_MINW_PS>(h, C, uprior);
     if (h->class_dc == 6) return launch_bp_class_shape<6, 3, 3, 8, BPOSD_CLASS6_MINW_PS>(h, C, uprior);
@@ -805,7 +820,7 @@ int launch_bp_local(bposd_handle* h, const BpParams& P) {
     L.pos_chk = h->d_lpos_chk; L.pos_bit = h->d_lpos_bit; L.pos_alo = h->d_lpos_alo; L.pos_ahi = h->d_lpos_ahi;
     L.grp_dl = h->d_lgrp_dl; L.pos_dl = h->d_lpos_dl;
     L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv; L.out_iters = P.out_iters;
-    L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list; L.counters = P.counters; L.iter_total = P.iter_total;
+    L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list; L.counters = P.counters; L.iter_total = P.iter_total; L.tail_flag = P.tail_flag;
     if (h->local_mp == 2048) return launch_bp_local_t<2, 2048, 4, false>(h, L);  // 1024 threads, one workgroup per CU
     if (h->bp_variant == 17) return launch_bp_local_t<2, 1024, 8, false>(h, L);   // 512 threads, <= 64 VGPRs: 4 workgroups per CU
     if (h->bp_variant == 18) return launch_bp_local_t<1, 1024, 8, false>(h, L);   // 1024 threads, <= 64 VGPRs: 2 workgroups per CU
@@ -1008,12 +1023,12 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     if (!RPT) return fail(h, BPOSD_ERR_UNSUPPORTED, "m=%d beyond the HBM-resident OSD kernel (16384)", h->m);
     OsdLargeParams Q{};
     Q.m = h->m; Q.n = h->n; Q.W = (h->n + 1 + 63) / 64;
-    Q.rank = P.rank; Q.osd_method = P.osd_method; Q.osd_order = P.osd_order; Q.tie_policy = P.tie_policy;
+    Q.rank = P.rank; Q.osd_method = P.osd_method; Q.osd_order = P.osd_order; Q.tie_policy = P.tie_policy; Q.e_msb_first = P.e_msb_first;
     Q.nsort = 1;
     while (Q.nsort < h->n) Q.nsort <<= 1;
     Q.mrl = OSDL_NT * RPT;
     Q.synd = P.synd; Q.rp = P.rp; Q.ci = P.ci; Q.llr_ws = P.llr_ws; Q.osd_list = P.osd_list; Q.counters = P.counters;
-    Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.rank_out = d_rank_out; Q.dbg = P.dbg;
+    Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.cmp_osd0 = P.cmp_osd0; Q.cmp_osdw = P.cmp_osdw; Q.rank_out = d_rank_out; Q.dbg = P.dbg;
     // fp64 index-order candidate weights (non-uniform channel) -- only OSD-E / OSD-CS rank candidates
     const bool fpw = P.cost != nullptr && Q.osd_method >= BPOSD_OSD_E && Q.osd_order > 0;
     Q.cost = fpw ? P.cost : nullptr; Q.sel = fpw ? P.sel : nullptr; Q.cost_alt = P.cost_alt;
@@ -1155,6 +1170,10 @@ void bposd_destroy(bposd_handle* h) {
     DeviceGuard dev_guard(h->device);
     for (auto& l : h->lanes) {
         if (l.stream) (void)hipStreamSynchronize(l.stream);
+        if (l.h_list) (void)hipHostFree(l.h_list);
+        if (l.ev_copy) (void)hipEventDestroy(l.ev_copy);
+        if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
+        for (DevBuf* b : {&l.io_cmp0, &l.io_cmpw}) release(*b);
         for (DevBuf* b : {&l.bpl_msg, &l.bpl_llr, &l.osdl_ws, &l.io_sel, &l.osd_rows_ws, &l.llr_ws, &l.osd_list, &l.io_synd, &l.io_osdw,
                           &l.io_osd0, &l.io_bp, &l.io_conv, &l.io_iters, &l.io_llr})
             release(*b);
@@ -1162,6 +1181,10 @@ void bposd_destroy(bposd_handle* h) {
             if (p) (void)hipFree(p);
         if (l.osd_stream) (void)hipStreamSynchronize(l.osd_stream);
         if (l.h_stage) (void)hipHostFree(l.h_stage);
+        if (l.h_tail) (void)hipHostFree(l.h_tail);
+        if (l.d_alt) (void)hipFree(l.d_alt);
+        if (l.h_alt) (void)hipHostFree(l.h_alt);
+        if (l.ev_alt) (void)hipEventDestroy(l.ev_alt);
         if (l.ev_bp) (void)hipEventDestroy(l.ev_bp);
         if (l.ev_osd) (void)hipEventDestroy(l.ev_osd);
         if (l.ev_up) (void)hipEventDestroy(l.ev_up);
@@ -1197,7 +1220,9 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     if (cfg->max_iter < 0 || cfg->osd_order < 0) return fail(nullptr, BPOSD_ERR_INVALID, "negative max_iter / osd_order");
     if (cfg->sort_tie_policy < 0 || cfg->sort_tie_policy > 1 || cfg->weight_fn < 0 || cfg->weight_fn > 1)
         return fail(nullptr, BPOSD_ERR_INVALID, "sort_tie_policy / weight_fn out of range");
-    if (cfg->reserved[0] != 0 || cfg->reserved[1] != 0)
+    if (cfg->osd_e_bit_order < 0 || cfg->osd_e_bit_order > 1)
+        return fail(nullptr, BPOSD_ERR_INVALID, "osd_e_bit_order must be 0 (LSB first) or 1 (MSB first)");
+    if (cfg->reserved[0] != 0)
         return fail(nullptr, BPOSD_ERR_INVALID, "reserved config fields must be 0");
     if (cfg->schedule != 0 && cfg->schedule != 1) return fail(nullptr, BPOSD_ERR_INVALID, "schedule must be 0 (parallel) or 1 (serial)");
     if (!(cfg->ps_clip >= 0.0) || std::isinf(cfg->ps_clip)) return fail(nullptr, BPOSD_ERR_INVALID, "ps_clip must be 0 (off) or a finite positive bound");
@@ -1263,7 +1288,11 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_bp, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_osd, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_up, hipEventDisableTiming));
+        CREATE_TRY(hipStreamCreateWithFlags(&l.copy_stream, hipStreamNonBlocking));
+        CREATE_TRY(hipEventCreateWithFlags(&l.ev_copy, hipEventDisableTiming));
         CREATE_TRY(hipMalloc((void**)&l.d_counters, 32));  // 4 counters + the 64-bit iteration total: one memset, one copy
+        CREATE_TRY(hipHostMalloc((void**)&l.h_tail, 64, hipHostMallocMapped));
+        *l.h_tail = 0;
     }
     for (CallRecord* rs : {h->rec, h->lane_rec})
         for (int k = 0; k < (rs == h->rec ? BPOSD_MAX_CHUNKS : BPOSD_LANES); ++k) {
@@ -1515,7 +1544,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.synd = d_synd;
     P.llr0 = h->d_llr0;
     P.sel = d_sel;
-    P.llr0_alt = h->d_llr0_alt;
+    P.llr0_alt = h->lane_alt ? h->cur->d_alt : h->d_llr0_alt;
     P.chk_deg = h->d_chk_deg;
     P.var_deg = h->d_var_deg;
     P.var_pos = h->d_var_pos;
@@ -1530,6 +1559,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.osd_list = (int*)h->cur->osd_list.p;
     P.counters = h->cur->d_counters;
     P.iter_total = (unsigned long long*)(h->cur->d_counters + 4);
+    P.tail_flag = h->tail_gate ? h->cur->h_tail : nullptr;
 
     if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[0], h->cur->stream));
     if (h->cfg.schedule == 1) {
@@ -1544,7 +1574,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         L.chk_deg = h->d_chk_deg; L.var_deg = h->d_var_deg; L.var_pos = h->d_var_pos;
         L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv;
         L.out_iters = P.out_iters; L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list;
-        L.counters = P.counters; L.iter_total = P.iter_total;
+        L.counters = P.counters; L.iter_total = P.iter_total; L.tail_flag = P.tail_flag;
         if ((rc = launch_bp_large(h, L))) return rc;
     } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || (h->bp_variant >= 16 && h->bp_variant <= 26))) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_LOCAL;
@@ -1558,11 +1588,9 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     }
     if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[1], h->cur->stream));
     h->currec->ran_osd = false;
+    if (!lean && (osd_on || h->tail_gate)) HIP_TRY(h, hipEventRecord(h->cur->ev_bp, h->cur->stream));  // the BP kernel has ended
     if (osd_on) {
-        if (!lean) {
-            HIP_TRY(h, hipEventRecord(h->cur->ev_bp, h->cur->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->cur->osd_stream, h->cur->ev_bp, 0));
-        }
+        if (!lean) HIP_TRY(h, hipStreamWaitEvent(h->cur->osd_stream, h->cur->ev_bp, 0));
         OsdParams Q{};
         Q.m = h->m;
         Q.n = h->n;
@@ -1570,6 +1598,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.osd_method = h->cfg.osd_order == 0 ? BPOSD_OSD_0 : h->cfg.osd_method;
         Q.osd_order = h->cfg.osd_order;
         Q.tie_policy = h->cfg.sort_tie_policy;
+        Q.e_msb_first = h->cfg.osd_e_bit_order;
         Q.synd = d_synd;
         Q.rp = h->d_rp;
         Q.ci = h->d_ci;
@@ -1578,10 +1607,12 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.counters = h->cur->d_counters;
         Q.out_osd0 = d_osd0;
         Q.out_osdw = d_osdw;
+        Q.cmp_osd0 = d_osd0 ? h->cmp_osd0 : nullptr;
+        Q.cmp_osdw = h->cmp_osdw;
         Q.dbg = nullptr;
         Q.cost = (h->fp_weights || (d_sel && h->cfg.weight_fn == 0)) ? h->d_cost : nullptr;
         Q.sel = d_sel;
-        Q.cost_alt = h->d_cost_alt;
+        Q.cost_alt = h->lane_alt ? h->cur->d_alt + h->n : h->d_cost_alt;
         const char* dbg_env = getenv("BPOSD_OSD_DEBUG");
         if (dbg_env && dbg_env[0] == '1') {
             if (!h->cur->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->cur->d_osd_dbg, 2048 * sizeof(long long)));
@@ -1631,18 +1662,20 @@ int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     return decode_device_impl(h, d_synd, B, nullptr, d_osdw, d_osd0, d_bp, d_conv, d_iters, d_llr);
 }
 
-static int upload_alt_channel(bposd_handle* h, const double* alt) {
+static int alt_channel_tables(bposd_handle* h, const double* alt, double* l0, double* cost) {
     if (!alt) return fail(h, BPOSD_ERR_INVALID, "channel_probs_alt is required");
-    std::vector<double> l0(h->n), cost(h->n);
     for (int i = 0; i < h->n; ++i) {
         if (!(alt[i] >= 0.0 && alt[i] <= 1.0))
             return fail(h, BPOSD_ERR_INVALID, "channel_probs_alt[%d] = %g is not a probability", i, alt[i]);
         l0[i] = std::log((1 - alt[i]) / alt[i]);
         cost[i] = std::log(1 / alt[i]);
     }
-    h->alt_finite = true;
-    for (int i = 0; i < h->n; ++i)
-        if (!std::isfinite(l0[i])) h->alt_finite = false;
+    return 0;
+}
+
+static int upload_alt_channel(bposd_handle* h, const double* alt) {
+    std::vector<double> l0(h->n), cost(h->n);
+    { int rca = alt_channel_tables(h, alt, l0.data(), cost.data()); if (rca) return rca; }
     DeviceGuard dev_guard(h->device);
     HIP_TRY(h, dev_guard.err);
     { int rcs = sync_all_lanes(h); if (rcs) return rcs; }  // earlier calls may still read the old tables
@@ -1656,9 +1689,26 @@ int bposd_decode_batch_select_device(bposd_handle* h, const uint8_t* d_synd, int
                                      uint8_t* d_conv, int32_t* d_iters, double* d_llr) {
     if (!h) return BPOSD_ERR_INVALID;
     if (!d_sel) return fail(h, BPOSD_ERR_INVALID, "select is required");
-    int rc = upload_alt_channel(h, alt);
-    if (rc) return rc;
-    return decode_device_impl(h, d_synd, B, d_sel, d_osdw, d_osd0, d_bp, d_conv, d_iters, d_llr);
+    // asynchronous like the plain device-pointer call: the alternative channel goes to the buffers of the lane this call
+    // will run on, through that lane's stream
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    Lane& L = h->lanes[h->next_lane];
+    const size_t bytes = sizeof(double) * 2 * (size_t)h->n;
+    if (!L.d_alt) {
+        HIP_TRY(h, hipMalloc((void**)&L.d_alt, bytes));
+        HIP_TRY(h, hipHostMalloc((void**)&L.h_alt, bytes, hipHostMallocDefault));
+        HIP_TRY(h, hipEventCreateWithFlags(&L.ev_alt, hipEventDisableTiming));
+    }
+    if (L.alt_busy) HIP_TRY(h, hipEventSynchronize(L.ev_alt));  // the copy of this lane's previous select call has read the staging block
+    { int rca = alt_channel_tables(h, alt, L.h_alt, L.h_alt + h->n); if (rca) return rca; }
+    HIP_TRY(h, hipMemcpyAsync(L.d_alt, L.h_alt, bytes, hipMemcpyHostToDevice, L.stream));
+    HIP_TRY(h, hipEventRecord(L.ev_alt, L.stream));
+    L.alt_busy = true;
+    h->lane_alt = true;
+    const int rc = decode_device_impl(h, d_synd, B, d_sel, d_osdw, d_osd0, d_bp, d_conv, d_iters, d_llr);
+    h->lane_alt = false;
+    return rc;
 }
 
 static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, const uint8_t* sel, uint8_t* osdw,
@@ -1749,12 +1799,35 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     h->batch_hint = B;  // kernel variants are chosen for the call, not for a chunk
     const size_t n = (size_t)h->n, m = (size_t)h->m;
     int rc;
+    static const bool gate_env = !(getenv("BPOSD_HOST_GATE") && getenv("BPOSD_HOST_GATE")[0] == '0');
+    const bool gate = gate_env && nchunks > 1 && h->cfg.schedule == 0;  // (the serial-schedule kernel does not report its tail)
+    const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF;
+    // rows of chunk c that the OSD kernel rewrote: from the compact copies into the caller's arrays (the lane is idle)
+    auto patch_osd_rows = [&](int c) -> int {
+        Lane& L = h->lanes[c % h->nlanes];
+        HIP_TRY(h, hipStreamSynchronize(L.stream));       // chunk c's kernels and its counter copy
+        HIP_TRY(h, hipStreamSynchronize(L.copy_stream));  // its bulk downloads (the patched rows must land after them)
+        L.copy_pending = false;
+        if (!osd_on || !h->rec[c].ran_osd) return 0;
+        const long long lo = (long long)c * CH;
+        const int count = h->rec[c].h_counters[1];
+        if (count <= 0) return 0;
+        std::vector<uint8_t> rows((size_t)count * n);
+        for (int which = 0; which < 2; ++which) {
+            uint8_t* dst = which ? osd0 : osdw;
+            if (!dst) continue;
+            HIP_TRY(h, hipMemcpy(rows.data(), which ? L.io_cmp0.p : L.io_cmpw.p, rows.size(), hipMemcpyDeviceToHost));
+            for (int k = 0; k < count; ++k) memcpy(dst + ((size_t)lo + (size_t)L.h_list[k]) * n, rows.data() + (size_t)k * n, n);
+        }
+        return 0;
+    };
     for (int c = 0; c < nchunks; ++c) {
         const long long lo = (long long)c * CH, cnt = std::min<long long>(CH, B - lo);
         const int lane = c % h->nlanes;
         Lane& L = h->lanes[lane];
         h->cur = &L;
         const size_t bn = (size_t)cnt * n, bm = (size_t)cnt * m;
+        if (c >= h->nlanes && (rc = patch_osd_rows(c - h->nlanes))) { (void)sync_all_lanes(h); return rc; }  // the lane's previous chunk
         if ((rc = ensure(h, L.io_synd, (size_t)CH * m))) return rc;
         if ((rc = ensure(h, L.io_osdw, (size_t)CH * n))) return rc;
         if (osd0 && (rc = ensure(h, L.io_osd0, (size_t)CH * n))) return rc;
@@ -1762,6 +1835,16 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         if (conv && (rc = ensure(h, L.io_conv, (size_t)CH))) return rc;
         if (iters && (rc = ensure(h, L.io_iters, sizeof(int) * (size_t)CH))) return rc;
         if (llr && (rc = ensure(h, L.io_llr, sizeof(double) * (size_t)CH * n))) return rc;
+        if (osd_on) {
+            if ((rc = ensure(h, L.io_cmpw, (size_t)CH * n))) return rc;
+            if (osd0 && (rc = ensure(h, L.io_cmp0, (size_t)CH * n))) return rc;
+            if (L.h_list_cap < (size_t)CH) {
+                if (L.h_list) (void)hipHostFree(L.h_list);
+                L.h_list = nullptr; L.h_list_cap = 0;
+                HIP_TRY(h, hipHostMalloc((void**)&L.h_list, sizeof(int) * (size_t)CH, hipHostMallocDefault));
+                L.h_list_cap = (size_t)CH;
+            }
+        }
         if (c > 0) HIP_TRY(h, hipStreamWaitEvent(L.stream, h->lanes[(c - 1) % h->nlanes].ev_up, 0));
         HIP_TRY(h, hipMemcpyAsync(L.io_synd.p, synd + (size_t)lo * m, bm, hipMemcpyHostToDevice, L.stream));
         if (sel) {
@@ -1769,18 +1852,41 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
             HIP_TRY(h, hipMemcpyAsync(L.io_sel.p, sel + (size_t)lo * n, bn, hipMemcpyHostToDevice, L.stream));
         }
         HIP_TRY(h, hipEventRecord(L.ev_up, L.stream));
+        // Chunk c's kernels are released when chunk c - 1's BP kernel has handed out its last syndrome (its tail begins; the
+        // flag is written by that kernel into page-locked memory) or has ended: the chunks then run in order, each filling
+        // the previous one's tail, instead of sharing the CUs from the start and all finishing at the end of the call.
+        if (c > 0 && gate) {
+            Lane& Pv = h->lanes[(c - 1) % h->nlanes];
+            while (*(volatile int*)Pv.h_tail == 0 && hipEventQuery(Pv.ev_bp) == hipErrorNotReady) {}
+        }
+        *(volatile int*)L.h_tail = 0;
+        h->tail_gate = true;  // (also makes the call record ev_bp, which the downloads below wait for)
+        h->cmp_osdw = osd_on ? (uint8_t*)L.io_cmpw.p : nullptr;
+        h->cmp_osd0 = (osd_on && osd0) ? (uint8_t*)L.io_cmp0.p : nullptr;
         rc = decode_device_impl(h, (const uint8_t*)L.io_synd.p, cnt, sel ? (const uint8_t*)L.io_sel.p : nullptr,
                                 (uint8_t*)L.io_osdw.p, osd0 ? (uint8_t*)L.io_osd0.p : nullptr,
                                 bp ? (uint8_t*)L.io_bp.p : nullptr, conv ? (uint8_t*)L.io_conv.p : nullptr,
                                 iters ? (int32_t*)L.io_iters.p : nullptr, llr ? (double*)L.io_llr.p : nullptr, lane, c);
+        h->tail_gate = false;
+        h->cmp_osdw = h->cmp_osd0 = nullptr;
         if (rc) { (void)sync_all_lanes(h); return rc; }
-        HIP_TRY(h, hipMemcpyAsync(osdw + (size_t)lo * n, L.io_osdw.p, bn, hipMemcpyDeviceToHost, L.stream));
-        if (osd0) HIP_TRY(h, hipMemcpyAsync(osd0 + (size_t)lo * n, L.io_osd0.p, bn, hipMemcpyDeviceToHost, L.stream));
-        if (bp) HIP_TRY(h, hipMemcpyAsync(bp + (size_t)lo * n, L.io_bp.p, bn, hipMemcpyDeviceToHost, L.stream));
-        if (conv) HIP_TRY(h, hipMemcpyAsync(conv + lo, L.io_conv.p, (size_t)cnt, hipMemcpyDeviceToHost, L.stream));
-        if (iters) HIP_TRY(h, hipMemcpyAsync(iters + lo, L.io_iters.p, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, L.stream));
-        if (llr) HIP_TRY(h, hipMemcpyAsync(llr + (size_t)lo * n, L.io_llr.p, sizeof(double) * bn, hipMemcpyDeviceToHost, L.stream));
+        // Downloads: everything the BP kernel wrote is final when it ends, except the osdw / osd0 rows of its non-converged
+        // syndromes -- those are patched from the compact copies once the OSD kernel has run.  (Queued behind the OSD kernel
+        // on the lane's stream, as in the first version, a chunk's downloads started a whole chunk late: the OSD kernel
+        // needs a drained CU and the next chunk's persistent BP workgroups take every slot that frees up.)
+        hipStream_t cs = L.copy_stream;
+        HIP_TRY(h, hipStreamWaitEvent(cs, L.ev_bp, 0));
+        HIP_TRY(h, hipMemcpyAsync(osdw + (size_t)lo * n, L.io_osdw.p, bn, hipMemcpyDeviceToHost, cs));
+        if (osd0) HIP_TRY(h, hipMemcpyAsync(osd0 + (size_t)lo * n, L.io_osd0.p, bn, hipMemcpyDeviceToHost, cs));
+        if (bp) HIP_TRY(h, hipMemcpyAsync(bp + (size_t)lo * n, L.io_bp.p, bn, hipMemcpyDeviceToHost, cs));
+        if (conv) HIP_TRY(h, hipMemcpyAsync(conv + lo, L.io_conv.p, (size_t)cnt, hipMemcpyDeviceToHost, cs));
+        if (iters) HIP_TRY(h, hipMemcpyAsync(iters + lo, L.io_iters.p, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, cs));
+        if (llr) HIP_TRY(h, hipMemcpyAsync(llr + (size_t)lo * n, L.io_llr.p, sizeof(double) * bn, hipMemcpyDeviceToHost, cs));
+        if (osd_on) HIP_TRY(h, hipMemcpyAsync(L.h_list, L.osd_list.p, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, cs));
+        L.copy_pending = true;
     }
+    for (int c = std::max(0, nchunks - h->nlanes); c < nchunks; ++c)
+        if ((rc = patch_osd_rows(c))) { (void)sync_all_lanes(h); return rc; }
     h->nrec = nchunks;
     return sync_all_lanes(h);
 }

@@ -64,6 +64,7 @@ struct OsdParams {
     int osd_method;  // 1 osd0, 2 osd_e, 3 osd_cs
     int osd_order;
     int tie_policy;
+    int e_msb_first;  // osd_e enumeration: 0 = bit b of pattern i is T position b (LSB first), 1 = T position w - 1 - b
     const uint8_t* __restrict__ synd;  // [B, m]
     const int* __restrict__ rp;        // CSR indptr [m+1]
     const int* __restrict__ ci;        // CSR indices [E]
@@ -71,7 +72,11 @@ struct OsdParams {
     const int* __restrict__ osd_list;  // [cap]
     int* __restrict__ counters;        // [1] = number of list entries, [2] = OSD work queue
     uint8_t* __restrict__ out_osd0;    // [B, n] nullable
-    uint8_t* __restrict__ out_osdw;    // [B, n]
+    uint8_t* __restrict__ out_osdw;
+    // nullable: the same two rows again at [list slot][n] -- the host-pointer API downloads the bulk outputs right after BP
+    // and patches the few OSD rows from these compact copies afterwards
+    uint8_t* __restrict__ cmp_osd0;
+    uint8_t* __restrict__ cmp_osdw;    // [B, n]
     const double* __restrict__ cost;   // nullable: log(1/p_i) per bit -> fp64 weights summed in bit order
                                        // (ldpc v2 weight function with non-uniform channel_probs)
     const uint8_t* __restrict__ sel;   // [B, n] nullable: per-syndrome choice between cost and cost_alt
@@ -225,6 +230,15 @@ __host__ __device__ constexpr size_t osd_lds_bytes(int W, int mr) {
 // One straight-line variant per chunk count: a chunk's loads are issued together and waited for one by one (loading a
 // chunk ahead was measured and is no faster: the pass is bound by LDS / VALU throughput, not latency).  Words past the
 // live window only ever receive table words that are never read.
+// osd_e enumerates patterns i = 1 .. 2^w - 1 and keeps the FIRST lightest one (strict <), so the tie between equally
+// light patterns depends on which T position bit b of i stands for.  `mask` has bit p set when T position p is switched
+// on; the enumeration index of that pattern is mask itself when bit b <-> position b (LSB first: the restatement's
+// reading of upstream) and the w-bit reversal of mask when bit b <-> position w - 1 - b.  The
+// reversal is an involution, so the same function maps a winning index back to its column mask.
+__device__ __forceinline__ unsigned int osd_e_index(unsigned int mask, int w, int msb_first) {
+    return msb_first ? (__brev(mask) >> (32 - w)) : mask;
+}
+
 template <int W, int NCH>
 __device__ __forceinline__ void osd_apply_tables(unsigned long long (&row)[OSD_RPT][W], const unsigned long long (&t)[OSD_RPT],
                                                  const unsigned long long* tab, int ngroups) {
@@ -573,6 +587,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         __syncthreads();
         if (P.out_osd0)
             for (int i = tid; i < n; i += NT) P.out_osd0[(size_t)s * n + i] = L.xout[i];
+        if (P.cmp_osd0)
+            for (int i = tid; i < n; i += NT) P.cmp_osd0[(size_t)slot_id * n + i] = L.xout[i];
 
         int w0 = 0;
         for (int q = 0; q < ncv; ++q) w0 += __popcll(L.yvec[q]);
@@ -779,14 +795,14 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                             }
                             const unsigned long long bits = (unsigned long long)__double_as_longlong(acc);
                             if (pass == 0) atomicMin(&bestw[0], bits);
-                            else if (bits == target) atomicMin(&besti[0], (int)pat);
+                            else if (bits == target) atomicMin(&besti[0], (int)osd_e_index(pat, wspan, P.e_msb_first));
                         }
                         __syncthreads();
                     }
                     const unsigned long long ms = bestw[0];
                     if (ms != ~0ull && __longlong_as_double((long long)ms) < w0d) {
                         sel_a = -2;
-                        sel_b = besti[0];
+                        sel_b = (int)osd_e_index((unsigned int)besti[0], wspan, P.e_msb_first);  // index -> column mask
                     }
                 }
             } else if (P.osd_method == 3) {
@@ -840,14 +856,14 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                         }
                         wgt += __popcll(v);
                     }
-                    const unsigned long long key = ((unsigned long long)wgt << 32) | pat;
+                    const unsigned long long key = ((unsigned long long)wgt << 32) | osd_e_index(pat, wspan, P.e_msb_first);
                     atomicMin(&L.best64[0], key);
                 }
                 __syncthreads();
                 const unsigned long long k1 = L.best64[0];
                 if (k1 != ~0ull && (int)(k1 >> 32) < w0) {
                     sel_a = -2;  // winner is a multi-column pattern
-                    sel_b = (int)(k1 & 0xffffffffu);
+                    sel_b = (int)osd_e_index((unsigned int)(k1 & 0xffffffffu), wspan, P.e_msb_first);
                 }
             }
         }
@@ -856,7 +872,10 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         // ------------------------------------------------- write the OSD-W solution
         if (sel_a == -1) {
             // OSD-0 stays the best
-            for (int i = tid; i < n; i += NT) P.out_osdw[(size_t)s * n + i] = L.xout[i];
+            for (int i = tid; i < n; i += NT) {
+                P.out_osdw[(size_t)s * n + i] = L.xout[i];
+                if (P.cmp_osdw) P.cmp_osdw[(size_t)slot_id * n + i] = L.xout[i];
+            }
         } else {
             __syncthreads();
             for (int i = tid; i < n; i += NT) L.xout[i] = 0;
@@ -892,7 +911,10 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             for (int k = 0; k < RPT; ++k)
                 if (used[k] && xs[k]) L.xout[L.kidx[mypos[k]]] = 1;
             __syncthreads();
-            for (int i = tid; i < n; i += NT) P.out_osdw[(size_t)s * n + i] = L.xout[i];
+            for (int i = tid; i < n; i += NT) {
+                P.out_osdw[(size_t)s * n + i] = L.xout[i];
+                if (P.cmp_osdw) P.cmp_osdw[(size_t)slot_id * n + i] = L.xout[i];
+            }
         }
         OSD_STAMP(6);
         __syncthreads();

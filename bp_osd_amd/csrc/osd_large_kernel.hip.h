@@ -60,6 +60,7 @@ struct OsdLargeParams {
     int m, n, W;  // W = ceil((n + 1) / 64)
     int rank;     // pivots to find (min(m, n) when the true rank is unknown)
     int osd_method, osd_order, tie_policy;
+    int e_msb_first;  // osd_e enumeration order (osd_kernel.hip.h: osd_e_index)
     int nsort;    // power of two >= n
     int mrl;      // padded row count = 1024 * RPT
     const uint8_t* __restrict__ synd;
@@ -70,6 +71,10 @@ struct OsdLargeParams {
     int* __restrict__ counters;
     uint8_t* __restrict__ out_osd0;
     uint8_t* __restrict__ out_osdw;
+    // nullable: the same two rows again at [list slot][n] -- the host-pointer API downloads the bulk outputs right after BP
+    // and patches the few OSD rows from these compact copies afterwards
+    uint8_t* __restrict__ cmp_osd0;
+    uint8_t* __restrict__ cmp_osdw;
     // per-workgroup workspaces (index blockIdx.x)
     unsigned long long* __restrict__ mat;   // [grid][W * mrl]
     unsigned long long* __restrict__ keys;  // [grid][nsort]
@@ -1116,6 +1121,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         __syncthreads();
         if (P.out_osd0)
             for (int i = tid; i < n; i += NT) P.out_osd0[(size_t)s * n + i] = xout[i];
+        if (P.cmp_osd0)
+            for (int i = tid; i < n; i += NT) P.cmp_osd0[(size_t)slot_id * n + i] = xout[i];
         int w0 = 0;
         for (int q = 0; q < NCV; ++q) w0 += __popcll(yvec[q]);
 
@@ -1264,11 +1271,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     __syncthreads();
                     const unsigned long long ms = best64[0];
                     for (unsigned int pat = tid + 1; pat <= npat; pat += NT)
-                        if ((unsigned long long)__double_as_longlong(wd[pat]) == ms) atomicMin(&besti[0], (int)pat);
+                        if ((unsigned long long)__double_as_longlong(wd[pat]) == ms) atomicMin(&besti[0], (int)osd_e_index(pat, ntc, P.e_msb_first));
                     __syncthreads();
                     if (ms != ~0ull && __longlong_as_double((long long)ms) < w0d) {
                         sel_a = -2;
-                        sel_b = besti[0];
+                        sel_b = (int)osd_e_index((unsigned int)besti[0], ntc, P.e_msb_first);
                     }
                 }
             } else if (P.osd_method == 3) {
@@ -1308,18 +1315,21 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         }
                         wgt += __popcll(v);
                     }
-                    atomicMin(&best64[0], ((unsigned long long)wgt << 32) | pat);
+                    atomicMin(&best64[0], ((unsigned long long)wgt << 32) | osd_e_index(pat, wspan, P.e_msb_first));
                 }
                 __syncthreads();
                 const unsigned long long k1 = best64[0];
-                if (k1 != ~0ull && (int)(k1 >> 32) < w0) { sel_a = -2; sel_b = (int)(k1 & 0xffffffffu); }
+                if (k1 != ~0ull && (int)(k1 >> 32) < w0) { sel_a = -2; sel_b = (int)osd_e_index((unsigned int)(k1 & 0xffffffffu), wspan, P.e_msb_first); }
             }
         }
 
         OSDL_FRESH_TID();
         // ------------------------------------------------- write the OSD-W solution
         if (sel_a == -1) {
-            for (int i = tid; i < n; i += NT) P.out_osdw[(size_t)s * n + i] = xout[i];
+            for (int i = tid; i < n; i += NT) {
+                P.out_osdw[(size_t)s * n + i] = xout[i];
+                if (P.cmp_osdw) P.cmp_osdw[(size_t)slot_id * n + i] = xout[i];
+            }
         } else {
             __syncthreads();
             for (int i = tid; i < n; i += NT) xout[i] = 0;
@@ -1358,7 +1368,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 }
             }
             __syncthreads();
-            for (int i = tid; i < n; i += NT) P.out_osdw[(size_t)s * n + i] = xout[i];
+            for (int i = tid; i < n; i += NT) {
+                P.out_osdw[(size_t)s * n + i] = xout[i];
+                if (P.cmp_osdw) P.cmp_osdw[(size_t)slot_id * n + i] = xout[i];
+            }
         }
         __syncthreads();
         OSDL_TICK(6);

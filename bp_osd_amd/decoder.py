@@ -67,7 +67,7 @@ class BpOsdDecoder:
     def __init__(self, pcm, error_rate=None, error_channel=None, max_iter=0, bp_method="minimum_sum",
                  ms_scaling_factor=1.0, schedule="parallel", omp_thread_count=1, osd_method="osd_0",
                  osd_order=0, input_vector_type="syndrome", channel_probs=None, device=0,
-                 sort_tie_policy=0, weight_fn=0, ps_clip=0.0, **kwargs):
+                 sort_tie_policy=0, weight_fn=0, ps_clip=0.0, osd_e_bit_order=0, **kwargs):
         if kwargs:
             raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
         sched = str(schedule).lower()
@@ -138,6 +138,7 @@ class BpOsdDecoder:
         cfg.osd_method = int(self._osd_method)
         cfg.osd_order = osd_order
         cfg.sort_tie_policy = int(sort_tie_policy)
+        cfg.osd_e_bit_order = int(osd_e_bit_order)
         cfg.weight_fn = int(weight_fn)
         cfg.schedule = 1 if sched == "serial" else 0
         cfg.ps_clip = float(ps_clip)

@@ -64,7 +64,12 @@ typedef struct {
                                   C > 0 = every check->bit message is clamped to [-C, C] (build-owned switch,
                                   DESIGN.md "Product-sum").  Occupies two of the four formerly reserved words: a
                                   zero-filled old config means "no clipping"                  */
-    int32_t reserved[2];       /* must be 0                                                  */
+    int32_t osd_e_bit_order;   /* osd_e: which T position bit b of pattern i = 1 .. 2^w - 1 stands for.  0 = position b
+                                  (LSB first; the restatement's reading of upstream), 1 = position
+                                  w - 1 - b.  Only the tie between equally light patterns depends on it (the first one
+                                  enumerated wins).  An UNVERIFIED-upstream-behaviour switch like sort_tie_policy /
+                                  weight_fn; was reserved[0]: a zero-filled old config means LSB first */
+    int32_t reserved[1];       /* must be 0                                                  */
 } bposd_config;
 
 /* Number of visible HIP devices (0 if none / runtime unavailable). */

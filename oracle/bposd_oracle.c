@@ -495,7 +495,7 @@ int oracle_osd(oracle_decoder *d, const uint8_t *syn, const double *llr, uint8_t
                 /* a10 osd_e: pattern i = c+1, least-significant bit -> T position 0 */
                 int pat = c + 1;
                 for (int b = 0; b < w; b++)
-                    if ((pat >> b) & 1) tsel[nt++] = b;
+                    if ((pat >> b) & 1) tsel[nt++] = d->cfg.osd_e_bit_order ? w - 1 - b : b;
             } else if (c < kp) {
                 /* a10 osd_cs: all k' weight-1 patterns first */
                 tsel[nt++] = c;

@@ -47,6 +47,9 @@ typedef struct {
                                  1 = the bit-reproducible routines of bp_osd_amd/csrc/portable_math.h, which is what the
                                  GPU kernels evaluate -- with 1 the oracle and the GPU agree bit for bit, with 0 they
                                  differ by the libm's last-bit behaviour (tests state both bars) */
+    int32_t osd_e_bit_order;  /* osd_e: bit b of pattern i stands for T position b (0, LSB first) or w - 1 - b (1); only
+                                 ties between equally light patterns depend on it.  UNVERIFIED upstream behaviour, a
+                                 switch like sort_tie_policy */
 } oracle_config;
 
 /* pcm as CSR with sorted column indices; channel_probs[n]. Returns 0 or <0. */

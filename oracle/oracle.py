@@ -30,6 +30,7 @@ class _Cfg(C.Structure):
         ("ps_clip", C.c_double),
         ("schedule", C.c_int32),
         ("ps_math", C.c_int32),
+        ("osd_e_bit_order", C.c_int32),
     ]
 
 
@@ -82,7 +83,7 @@ def portable_math(which, x):
 class OracleDecoder:
     def __init__(self, pcm, error_rate=None, channel_probs=None, max_iter=0, bp_method="ms",
                  ms_scaling_factor=1.0, osd_method="osd0", osd_order=0, sort_tie_policy=0, weight_fn=0,
-                 ps_clip=0.0, ps_math=0, schedule="parallel"):
+                 ps_clip=0.0, ps_math=0, schedule="parallel", osd_e_bit_order=0):
         lib = _load()
         h = sp.csr_matrix(pcm).astype(np.uint8)
         h.eliminate_zeros()
@@ -96,7 +97,7 @@ class OracleDecoder:
         self._indices = np.ascontiguousarray(h.indices, dtype=np.int32)
         cfg = _Cfg(_BP[str(bp_method).lower()], float(ms_scaling_factor), int(max_iter),
                    _OSD[str(osd_method).lower()], int(osd_order), int(sort_tie_policy), int(weight_fn), float(ps_clip),
-                   {"parallel": 0, "serial": 1}[str(schedule).lower()], int(ps_math))
+                   {"parallel": 0, "serial": 1}[str(schedule).lower()], int(ps_math), int(osd_e_bit_order))
         self._h = C.c_void_p()
         rc = lib.oracle_create(C.byref(cfg), self._indptr.ctypes.data, self._indices.ctypes.data,
                                self.m, self.n, probs.ctypes.data, C.byref(self._h))

@@ -120,7 +120,7 @@ def _gf2_solve_unique(A, t):
     return x
 
 
-def osd_decode(H, syndrome, llr, probs, osd_method, osd_order, tie_policy=0, weight_fn=0):
+def osd_decode(H, syndrome, llr, probs, osd_method, osd_order, tie_policy=0, weight_fn=0, e_bit_order=0):
     """Returns (osd0, osdw, order, pivot_positions)."""
     H = np.asarray(H, dtype=np.uint8)
     m, n = H.shape
@@ -171,7 +171,7 @@ def osd_decode(H, syndrome, llr, probs, osd_method, osd_order, tie_policy=0, wei
     cands = []
     if osd_method == "osd_e" and osd_order > 0:
         for pat in range(1, 2 ** osd_order):
-            cands.append([b for b in range(osd_order) if (pat >> b) & 1])
+            cands.append([(osd_order - 1 - b if e_bit_order else b) for b in range(osd_order) if (pat >> b) & 1])
     elif osd_method == "osd_cs" and osd_order > 0:
         cands += [[k] for k in range(kp)]
         cands += [[a, b] for a, b in itertools.combinations(range(osd_order), 2)]
@@ -184,7 +184,7 @@ def osd_decode(H, syndrome, llr, probs, osd_method, osd_order, tie_policy=0, wei
 
 
 def bposd_decode(H, syndrome, probs, max_iter, bp_method, ms_scaling_factor, osd_method, osd_order,
-                 tie_policy=0, weight_fn=0):
+                 tie_policy=0, weight_fn=0, e_bit_order=0):
     H = np.asarray(H, dtype=np.uint8)
     n = H.shape[1]
     if not np.any(syndrome):
@@ -194,5 +194,5 @@ def bposd_decode(H, syndrome, probs, max_iter, bp_method, ms_scaling_factor, osd
     dec, conv, its, llr = bp_decode(H, syndrome, probs, max_iter, bp_method, ms_scaling_factor)
     if conv:
         return dict(osdw=dec, osd0=dec.copy(), bp=dec.copy(), converged=True, iters=its, llr=llr)
-    osd0, osdw, _, _ = osd_decode(H, syndrome, llr, probs, osd_method, osd_order, tie_policy, weight_fn)
+    osd0, osdw, _, _ = osd_decode(H, syndrome, llr, probs, osd_method, osd_order, tie_policy, weight_fn, e_bit_order)
     return dict(osdw=osdw, osd0=osd0, bp=dec, converged=False, iters=its, llr=llr)

@@ -227,6 +227,28 @@ def test_sort_tie_policy_switch(gpu_ready, h1922):
         _compare_exact(r, ref)
 
 
+def test_osd_e_bit_order_switch(gpu_ready, hgp400, hgp4050):
+    """osd_e_bit_order = 1 (bit b of pattern i <-> T position w - 1 - b) through the C-ABI on both OSD kernels, integer and
+    fp64 weights: equal to the oracle with the same switch; against the default order only tie winners move."""
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    rng = np.random.default_rng(3)
+    for H, q, nshots, order in ((hgp400.hz, 0.08, 400, 9), (hgp4050.hz, 0.06, 24, 7)):
+        n = H.shape[1]
+        _, syn = _syndromes(H, q, nshots, 31)
+        for chan in (dict(error_rate=q), dict(channel_probs=rng.uniform(0.03, 0.1, size=n))):
+            kw = dict(max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=order, **chan)
+            r1 = _gpu_decode(BpOsdDecoder(H, osd_e_bit_order=1, **kw), syn)
+            _compare_exact(r1, OracleDecoder(H, osd_e_bit_order=1, **kw).decode_batch(syn))
+            r0 = _gpu_decode(BpOsdDecoder(H, **kw), syn)
+            assert (r0["osd0"] == r1["osd0"]).all()
+            if "error_rate" in chan:  # uniform channel: ties exist, and only they may move the winner
+                assert (r0["osdw"].sum(axis=1) == r1["osdw"].sum(axis=1)).all()
+    with pytest.raises(ValueError):
+        BpOsdDecoder(hgp400.hz, error_rate=0.05, osd_method="osd_e", osd_order=4, osd_e_bit_order=2)
+
+
 def test_nonuniform_channel_and_update(gpu_ready, hgp400, h1922):
     """a1/a11/a12: per-bit channel_probs and update_channel_probs.  With non-uniform probabilities the
     OSD-W weights are the ldpc-v2 sums of log(1/p_i) in bit order (fp64) -- the winner must equal the
@@ -961,6 +983,21 @@ def test_device_pointer_api_with_prior_select(gpu_ready, h1922):
     assert (d_out.cpu().numpy() == want).all() and (d_conv.cpu().numpy().astype(bool) == a.batch_converge).all()
     with pytest.raises(ValueError):
         b.decode_batch_device(d_syn.data_ptr(), 700, d_out.data_ptr(), d_prior_select=d_sel.data_ptr())
+    # six select calls queued back to back without a synchronisation in between -- more calls than lanes, so every lane's
+    # channel buffers and staging block are reused -- each with its own alternative channel: equal to the serial results
+    alts = [rng.uniform(0.02, 0.2, n) for _ in range(6)]
+    wants = [a.decode_batch(syn, prior_select=sel, alt_channel_probs=al).copy() for al in alts]
+    outs = [torch.empty((700, n), dtype=torch.uint8, device="cuda") for _ in alts]
+    for al, o in zip(alts, outs):
+        b.decode_batch_device(d_syn.data_ptr(), 700, o.data_ptr(), d_prior_select=d_sel.data_ptr(), alt_channel_probs=al)
+    b.synchronize()
+    for k, (o, w) in enumerate(zip(outs, wants)):
+        assert (o.cpu().numpy() == w).all(), k
+    # and a plain call afterwards still uses the decoder's own channel
+    plain = torch.empty((700, n), dtype=torch.uint8, device="cuda")
+    b.decode_batch_device(d_syn.data_ptr(), 700, plain.data_ptr())
+    b.synchronize()
+    assert (plain.cpu().numpy() == a.decode_batch(syn)).all()
 
 
 @pytest.mark.parametrize("channel_update", [None, "x->z", "z->x"])

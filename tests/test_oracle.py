@@ -182,6 +182,26 @@ def test_sort_tie_policy_switch(surface13):
     assert (H @ o0["osd0"] % 2 == s).all() and (H @ o1["osd0"] % 2 == s).all()
 
 
+def test_osd_e_bit_order_switch(surface13):
+    """Appendix A.4: which T position bit b of OSD-E pattern i stands for is a switch (0 = position b, 1 = w - 1 - b).  It
+    only decides ties between equally light patterns (first enumerated wins): both settings agree with the independent
+    numpy restatement, the weights never differ, and on the uniform channel some winner does."""
+    H = surface13.hz.toarray()
+    probs = np.full(13, 0.05)
+    kw = dict(error_rate=0.05, max_iter=2, bp_method="ms", ms_scaling_factor=0, osd_method="osd_e", osd_order=5)
+    d0, d1 = OracleDecoder(H, **kw), OracleDecoder(H, osd_e_bit_order=1, **kw)
+    differ = 0
+    for bits in itertools.product([0, 1], repeat=6):
+        s = np.array(bits, dtype=np.uint8)
+        r0, r1 = d0.decode(s), d1.decode(s)
+        for r, order in ((r0, 0), (r1, 1)):
+            ref = ref_numpy.bposd_decode(H, s, list(probs), 2, "ms", 0, "osd_e", 5, e_bit_order=order)
+            assert (r["osd0"] == ref["osd0"]).all() and (r["osdw"] == ref["osdw"]).all(), (bits, order)
+        assert (r0["osd0"] == r1["osd0"]).all() and r0["osdw"].sum() == r1["osdw"].sum()
+        differ += int((r0["osdw"] != r1["osdw"]).any())
+    assert differ > 0
+
+
 def test_zero_syndrome_shortcut(surface13):
     dec = OracleDecoder(surface13.hz, error_rate=0.05, osd_method="osd_cs", osd_order=3)
     r = dec.decode(np.zeros(6, dtype=np.uint8))
