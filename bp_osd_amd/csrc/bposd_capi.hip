@@ -1793,8 +1793,22 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     if (const char* e = getenv("BPOSD_HOST_CHUNK")) target = std::max(1LL, atoll(e));
     int nchunks = (int)std::min<long long>(BPOSD_MAX_CHUNKS, std::max<long long>(1, (B + target / 2) / target));
     if (h->large) nchunks = (int)std::min<long long>(nchunks, std::max<long long>(1, B / (4LL * h->num_cu)));
-    const long long CH = (B + nchunks - 1) / nchunks;
+    long long CH = (B + nchunks - 1) / nchunks;  // capacity of a lane's io buffers = the largest chunk
     nchunks = (int)((B + CH - 1) / CH);
+    // chunk boundaries: equal sizes, except that a four-chunk call (one chunk per lane) tapers 7 : 7 : 6 : 4 -- what
+    // stays exposed at the end of the call is the LAST chunk's download and straggler tail
+    std::vector<long long> clo(nchunks + 1);
+    for (int c = 0; c <= nchunks; ++c) clo[c] = std::min<long long>((long long)B, (long long)c * CH);
+    static const bool taper = !(getenv("BPOSD_HOST_TAPER") && getenv("BPOSD_HOST_TAPER")[0] == '0');
+    if (taper && nchunks == 4 && h->nlanes >= 4 && B >= 4096) {
+        const long long w[4] = {7, 7, 6, 4};
+        long long acc = 0;
+        for (int c = 0; c < 4; ++c) { clo[c] = acc; acc += (B * w[c] / 24 + 63) / 64 * 64; }
+        clo[4] = B;
+        for (int c = 0; c < 4; ++c) clo[c] = std::min<long long>(clo[c], (long long)B);
+        CH = 0;
+        for (int c = 0; c < 4; ++c) CH = std::max(CH, clo[c + 1] - clo[c]);
+    }
     struct HintScope { bposd_handle* h; ~HintScope() { h->batch_hint = 0; } } hint_scope{h};
     h->batch_hint = B;  // kernel variants are chosen for the call, not for a chunk
     const size_t n = (size_t)h->n, m = (size_t)h->m;
@@ -1809,7 +1823,7 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         HIP_TRY(h, hipStreamSynchronize(L.copy_stream));  // its bulk downloads (the patched rows must land after them)
         L.copy_pending = false;
         if (!osd_on || !h->rec[c].ran_osd) return 0;
-        const long long lo = (long long)c * CH;
+        const long long lo = clo[c];
         const int count = h->rec[c].h_counters[1];
         if (count <= 0) return 0;
         std::vector<uint8_t> rows((size_t)count * n);
@@ -1822,8 +1836,9 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         return 0;
     };
     for (int c = 0; c < nchunks; ++c) {
-        const long long lo = (long long)c * CH, cnt = std::min<long long>(CH, B - lo);
+        const long long lo = clo[c], cnt = clo[c + 1] - clo[c];
         const int lane = c % h->nlanes;
+        if (cnt <= 0) { h->rec[c].recorded = false; h->rec[c].ran_osd = false; continue; }
         Lane& L = h->lanes[lane];
         h->cur = &L;
         const size_t bn = (size_t)cnt * n, bm = (size_t)cnt * m;
