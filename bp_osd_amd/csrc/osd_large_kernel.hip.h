@@ -40,7 +40,7 @@
 // Non-uniform channel (P.cost != null: channel_probs vector, update_channel_probs, per-shot two-valued channel): candidate
 // weights are fp64 sums of log(1/p_i) over the candidate's set bits accumulated in ASCENDING ORIGINAL BIT INDEX -- the
 // reference's order -- one candidate per lane, exactly as in osd_kernel.hip.h; see the "fp64 weights" block of the sweep.
-// Limits: m <= 16384, n <= 32767, osd_cs / osd_e order <= 16.
+// Limits: m <= 16384, n <= 32767, osd_e order <= 16, osd_cs order <= 64 (<= 16 with a non-uniform channel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -54,7 +54,9 @@ constexpr int OSDL_NW = OSDL_NT / 64;  // waves
 constexpr int OSDL_CW = 8;             // chunk width (words) of the apply pass
 constexpr int OSDL_K = 4;              // open (lazily applied) pivot groups
 constexpr int OSDL_G5 = 13;            // 5-bit fields of a 64-bit pivot mask in the apply pass (12 x 5 + 4)
-constexpr int OSDL_MAXSPAN = 16;       // max osd order
+constexpr int OSDL_MAXSPAN = 16;       // max osd_e order, and max osd_cs order with fp64 (non-uniform channel) weights
+constexpr int OSDL_MAXSPAN_CS = 64;    // max osd_cs order with integer weights (uniform channel): as on the small path; the
+                                       // reduced columns of the first w non-pivots then live in a global workspace
 
 struct OsdLargeParams {
     int m, n, W;  // W = ceil((n + 1) / 64)
@@ -94,6 +96,7 @@ struct OsdLargeParams {
     const uint8_t* __restrict__ sel;        // [B, n] nullable: per-syndrome choice between cost and cost_alt
     const double* __restrict__ cost_alt;    // [n]
     double* __restrict__ costs_ws;          // [grid][n]   this syndrome's per-bit costs
+    unsigned long long* __restrict__ colvec_ws;  // [grid][OSDL_MAXSPAN_CS][RPT * OSDL_NW] reduced columns when osd_cs order > 16
     double* __restrict__ wd_ws;             // [grid][wdn] weights of the single candidates / of the osd_e patterns
     unsigned short* __restrict__ am_ws;     // [grid][mrl] per row: its entries in the first <= 16 non-pivot columns
     int wdn;                                // max(64 * W, 2^16)
@@ -1128,7 +1131,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 
         int sel_a = -1, sel_b = -1;
         if (P.osd_method >= 2 && P.osd_order > 0) {
-            const int wspan = P.osd_order < OSDL_MAXSPAN ? P.osd_order : OSDL_MAXSPAN;
+            // pair span of osd_cs with integer weights: up to 64 columns (/root/reference/examples/qldpc_decode_example.py:16
+            // passes 42); beyond 16 the reduced columns go to a global workspace instead of LDS
+            const int span_cap = (P.osd_method == 3 && !P.cost && P.colvec_ws) ? OSDL_MAXSPAN_CS : OSDL_MAXSPAN;
+            const int wspan = P.osd_order < span_cap ? P.osd_order : span_cap;
+            unsigned long long* colv = wspan > OSDL_MAXSPAN ? P.colvec_ws + (size_t)blockIdx.x * OSDL_MAXSPAN_CS * NCV : colvec;
             int tcount = gauss ? ntc_g : 0;  // gauss mode: colvec / tpos / am come from the back-substitution
 #pragma clang loop unroll(disable)
             for (int w = gauss ? W : 0; w < W; ++w) {
@@ -1155,7 +1162,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         if (P.osd_method == 3) cnt += __popcll(__ballot(usedk && (bitv != y[k])));
                         if (tcount < wspan) {
                             const unsigned long long cb = __ballot(usedk && bitv);
-                            if (lane == 0) colvec[tcount * NCV + k * OSDL_NW + wave] = cb;
+                            if (lane == 0) colv[tcount * NCV + k * OSDL_NW + wave] = cb;
                             if (am && usedk && bitv) am[tid + k * NT] |= (unsigned short)(1u << tcount);  // only the row's owner
                         }
                     }
@@ -1287,7 +1294,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     while (rem >= wspan - 1 - a) { rem -= wspan - 1 - a; ++a; }
                     const int bq = a + 1 + rem;
                     int wgt = 2;
-                    for (int q = 0; q < NCV; ++q) wgt += __popcll(yvec[q] ^ colvec[a * NCV + q] ^ colvec[bq * NCV + q]);
+                    for (int q = 0; q < NCV; ++q) wgt += __popcll(yvec[q] ^ colv[a * NCV + q] ^ colv[bq * NCV + q]);
                     atomicMin(&best64[1], ((unsigned long long)wgt << 32) | (unsigned)pidx);
                 }
                 __syncthreads();

@@ -657,10 +657,21 @@ def test_large_code_limits_and_nonuniform_channel(gpu_ready, hgp4050):
     H = hgp4050.hz
     n = H.shape[1]
     with pytest.raises(ValueError):
-        BpOsdDecoder(H, error_rate=0.05, max_iter=4, bp_method="ms", osd_method="osd_cs", osd_order=17)
+        BpOsdDecoder(H, error_rate=0.05, max_iter=4, bp_method="ms", osd_method="osd_cs", osd_order=65)
+    with pytest.raises(ValueError):
+        BpOsdDecoder(H, error_rate=0.05, max_iter=4, bp_method="ms", osd_method="osd_e", osd_order=17)
     rng = np.random.default_rng(7)
     probs = rng.uniform(0.03, 0.09, n)
     _, syn = _syndromes(H, 0.07, 6, 31)
+    # the reference example's own OSD setting on a large code (examples/qldpc_decode_example.py:15-16: osd_cs, order 42),
+    # and the small path's cap of 64: uniform channel, integer weights, the pair columns in a global workspace
+    for order in (42, 64, 17):
+        kw = dict(error_rate=0.07, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=order)
+        _compare_exact(_gpu_decode(BpOsdDecoder(H, **kw), syn), OracleDecoder(H, **kw).decode_batch(syn))
+    # ... which a non-uniform channel (fp64 weights) does not have beyond order 16: refused when the decode is asked for
+    g = BpOsdDecoder(H, channel_probs=probs, max_iter=6, bp_method="ms", osd_method="osd_cs", osd_order=42)
+    with pytest.raises(ValueError):
+        g.decode_batch(syn)
     for method, order in (("osd_0", 0), ("osd_e", 4), ("osd_e", 9), ("osd_cs", 2), ("osd_cs", 7), ("osd_cs", 16)):
         for weight_fn in (0, 1):
             kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method=method,
