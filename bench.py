@@ -472,6 +472,35 @@ def main():
                         "(CUs x peak clock) over the measured launch time; fp64_valu_issue_frac is the same ratio for the fp64 "
                         "instruction issue slots",
             }
+        if not large and bp_method == "ps":
+            # VALU roofline of the product-sum BP kernel ("report VALU utilisation too").  Per edge-iteration
+            # the check update evaluates one tanh and one log((1+x)/(1-x)) with csrc/portable_math.h -- four fp64 divisions,
+            # ~260 vector instructions per edge-iteration in the compiled loop (tools/isa_loop_count.py on the running
+            # instantiation; profiles/valu_model.json holds the SQ_INSTS_VALU measurement where one was taken).
+            insts = 261.0
+            src = "static count of the compiled iteration loop, tools/isa_loop_count.py bp_kernel<6,3,2,4,512,6,true,0,1024>: 3133 per 12 edges"
+            vm = os.path.join(ROOT, "profiles", "valu_model.json")
+            if os.path.exists(vm):
+                try:
+                    rec = json.load(open(vm)).get(args.config)
+                    if rec:
+                        insts, src = float(rec["valu_wave_insts_per_64_edge_iterations"]), rec["source"]
+                except Exception:
+                    pass
+            simd_cycles = lambda iters: iters * E / 64.0 * insts * 4.0  # a wave64 VALU instruction issues over 4 cycles on one SIMD
+            bound = lambda iters: simd_cycles(iters) / (num_cu * 4 * CLOCK_HZ) * 1e3
+            out["roofline_valu"] = {
+                "kernel": kinfo["kernel"], "bound": "valu",
+                "valu_wave_insts_per_64_edge_iterations": insts, "source": src,
+                "peak": {"simds": num_cu * 4, "clock_hz": CLOCK_HZ, "cycles_per_wave_instruction": 4},
+                "bound_ms_per_launch": bound(avg_iters),
+                "frac": bound(avg_iters) / avg_bp_ms if avg_bp_ms > 0 else None,
+                "frac_isolated": bound(t_last["bp_iterations"]) / t_last["bp_ms"] if t_last["bp_ms"] > 0 else None,
+                "ps_per_edge_iteration_isolated": t_last["bp_ms"] * 1e9 / max(t_last["bp_iterations"], 1) / E,
+                "note": "vector-instruction issue cycles of the executed edge-iterations over the SIMD-cycles of the launch; the "
+                        "kernel is VALU-bound (the messages stay in LDS: roofline.frac above is the on-chip algorithmic figure, not a "
+                        "utilisation)",
+            }
         if large:
             # the OSD kernel dominates this configuration; SURVEY.md §8(d) prices it at one read+write pass over the
             # packed matrix plus the sort plus the candidate sweep per invoked syndrome
