@@ -245,27 +245,33 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                     const int deg = cdeg[r];
                     if (REG || deg > 0) {
                         msg_ptr mc = msg + c;
+                        // An absent edge (k >= deg) enters as +DBL_MAX: neutral for the running minima and for the sign parity
+                        // (min-sum), tanh = 1 exactly (product-sum); its result is never stored.  Every element of the
+                        // arrays below is defined on every path -- partially defined arrays became loop-carried registers
+                        // (one per element) and were the source of this kernel's scratch.
                         double v[DC];
 #pragma unroll
-                        for (int k = 0; k < DC; ++k)
+                        for (int k = 0; k < DC; ++k) {
+                            v[k] = __DBL_MAX__;
                             if (REG || k < deg) v[k] = mc[k * MP];
+                        }
                         if (METHOD == 1) {
                             // parity of (syndrome bit + #non-positive inputs); zero counts as negative
                             bool neg[DC];
                             bool par = sbit[r];
 #pragma unroll
                             for (int k = 0; k < DC; ++k) {
-                                neg[k] = (REG || k < deg) ? (v[k] <= 0.0) : false;
+                                neg[k] = (v[k] <= 0.0);  // (+DBL_MAX: false)
                                 par ^= neg[k];
                             }
                             // forward / backward running minima of |b2c|, both started at DBL_MAX
                             double pre[DC], suf[DC];
                             pre[0] = __DBL_MAX__;
 #pragma unroll
-                            for (int k = 1; k < DC; ++k) pre[k] = (REG || k - 1 < deg) ? min_abs(pre[k - 1], v[k - 1]) : pre[k - 1];
+                            for (int k = 1; k < DC; ++k) pre[k] = min_abs(pre[k - 1], v[k - 1]);  // (min with +DBL_MAX: unchanged)
                             suf[DC - 1] = __DBL_MAX__;
 #pragma unroll
-                            for (int k = DC - 2; k >= 0; --k) suf[k] = (REG || k + 1 < deg) ? min_abs(suf[k + 1], v[k + 1]) : suf[k + 1];
+                            for (int k = DC - 2; k >= 0; --k) suf[k] = min_abs(suf[k + 1], v[k + 1]);
 #pragma unroll
                             for (int k = 0; k < DC; ++k) {
                                 if (REG || k < deg) {
@@ -278,8 +284,9 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                             double t = 1.0;
 #pragma unroll
                             for (int k = 0; k < DC; ++k) {
+                                pre[k] = t;
+                                th[k] = 1.0;
                                 if (REG || k < deg) {
-                                    pre[k] = t;
                                     th[k] = pm_tanh(v[k] / 2);
                                     t *= th[k];
                                 }
@@ -322,10 +329,8 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                     double t = l0[r];
 #pragma unroll
                     for (int d = 0; d < DV; ++d) {
-                        if (REG || d < deg) {
-                            pre[d] = t;  // prefix from the top of the column (prior included)
-                            t += cm[r][d];
-                        }
+                        pre[d] = t;  // prefix from the top of the column (prior included); defined for absent edges too
+                        if (REG || d < deg) t += cm[r][d];
                     }
                     llr[r] = t;
                     const int dnew = (t <= 0.0) ? 1 : 0;
