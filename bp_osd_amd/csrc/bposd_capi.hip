@@ -1629,11 +1629,11 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         if (h->large) {
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
             if (Q.dbg) {
-                long long st[13];
+                long long st[17];
                 HIP_TRY(h, hipStreamSynchronize(h->osd_now));
                 HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[bposd large osd, s_memtime ticks, list slot 0] sort %lld  build %lld  E1 %lld  E2 %lld  E3 %lld  apply %lld  "
-                        "sweep %lld | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld apply table builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12]);
+                        "sweep %lld (back-substitution %lld, column vectors %lld, candidates %lld, write-out %lld) | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld apply table builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[13], st[14], st[15], st[16], st[7], st[8], st[9], st[10], st[11], st[12]);
                 Q.dbg = nullptr;
             }
         } else if ((rc = launch_osd(h, Q, B))) return rc;

@@ -54,6 +54,10 @@ constexpr int OSDL_NW = OSDL_NT / 64;  // waves
 constexpr int OSDL_CW = 8;             // chunk width (words) of the apply pass
 constexpr int OSDL_K = 4;              // open (lazily applied) pivot groups
 constexpr int OSDL_G5 = 13;            // 5-bit fields of a 64-bit pivot mask in the apply pass (12 x 5 + 4)
+#ifndef OSDL_E3D
+#define OSDL_E3D 1   // words in flight per wave in E3 beyond the one being processed (measured: 3 and 4 are SLOWER, 42 -> 57 / 60 M
+                     // cycles per elimination -- E3 is bound by the gather rate of one CU, not by the latency of a round trip)
+#endif
 constexpr int OSDL_MAXSPAN = 16;       // max osd_e order, and max osd_cs order with fp64 (non-uniform channel) weights
 constexpr int OSDL_MAXSPAN_CS = 64;    // max osd_cs order with integer weights (uniform channel): as on the small path; the
                                        // reduced columns of the first w non-pivots then live in a global workspace
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         const double* llr = P.llr_ws + (size_t)slot_id * n;
 
 #ifdef BPOSD_OSD_DIAG
-        long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
+        long long tk[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 13..16: back-substitution, column vectors, candidate sweep, write-out  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
                                                                // apply look-ups per thread, apply row-words per thread
         long long t0 = (long long)__builtin_amdgcn_s_memtime();
 #define OSDL_TICK(i)                                                     \
@@ -961,26 +965,23 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     const bool builder = tg < ng;
                     const int tnp = builder ? gnp[tg] - 4 * tgrp : 0;
                     const int q0 = 4 * tgrp;
-                    unsigned long long prn[4], mvn;
-                    int x = w + 1 + wave;
-                    if (x < W) {
-                        const unsigned long long* src = PRO + ((size_t)(builder ? tg : 0) * W + x) * 64 + q0;
+                    // OSDL_E3D words in flight per wave: the loop is bound by the latency of its own gathers (a row word
+                    // per lane from M, four pivot-row words from PRO), ~10 k cycles each under full load
+                    unsigned long long prq[OSDL_E3D][4], mvq[OSDL_E3D];
+                    auto issue = [&](int d, int xx) {
+                        if (xx < W) {
+                            const unsigned long long* src = PRO + ((size_t)(builder ? tg : 0) * W + xx) * 64 + q0;
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) prn[kk] = src[kk];
-                        mvn = M[(size_t)x * MRL + row];
-                    }
-                    for (; x < W; x += OSDL_NW) {
+                            for (int kk = 0; kk < 4; ++kk) prq[d][kk] = src[kk];
+                            mvq[d] = M[(size_t)xx * MRL + row];
+                        }
+                    };
+                    auto process = [&](int d, int x) {
                         unsigned long long pr[4];
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) pr[kk] = (builder && kk < tnp) ? prn[kk] : 0ull;
-                        unsigned long long v = (lane < npiv) ? mvn : 0ull;
-                        const int xn = x + OSDL_NW;
-                        if (xn < W) {
-                            const unsigned long long* src = PRO + ((size_t)(builder ? tg : 0) * W + xn) * 64 + q0;
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) prn[kk] = src[kk];
-                            mvn = M[(size_t)xn * MRL + row];
-                        }
+                        for (int kk = 0; kk < 4; ++kk) pr[kk] = (builder && kk < tnp) ? prq[d][kk] : 0ull;
+                        unsigned long long v = (lane < npiv) ? mvq[d] : 0ull;
+                        issue(d, x + OSDL_NW * OSDL_E3D);  // this stage's registers are free again
                         if (builder) {
                             unsigned int idx = osdl_opaque(((unsigned int)lane >> 1) & 15u);  // conflict-free start entries
                             unsigned long long tv = 0ull;
@@ -1008,6 +1009,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         }
                         PRO[((size_t)ng * W + x) * 64 + lane] = v;
                         __builtin_amdgcn_wave_barrier();
+                    };
+                    const int xs = w + 1 + wave;
+#pragma unroll
+                    for (int d = 0; d < OSDL_E3D; ++d) issue(d, xs + d * OSDL_NW);
+                    for (int x = xs; x < W; x += OSDL_NW * OSDL_E3D) {
+#pragma unroll
+                        for (int d = 0; d < OSDL_E3D; ++d)
+                            if (x + d * OSDL_NW < W) process(d, x + d * OSDL_NW);
                     }
                 }
                 ++ng;
@@ -1074,6 +1083,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #pragma unroll
                 for (int c = 0; c < NR; ++c) acc[c] = 0ull;
                 if (prow >= 0) {
+                    // (eight row words in flight per lane instead of one: measured slower, 13.3 -> 15.0 M cycles -- the loop is
+                    // not waiting for a single round trip but for the CU's gather rate: 64 distinct lines per wave-level load)
                     for (int x = w + wave; x < W; x += OSDL_NW) {  // the 16 waves split the words to the right
                         const unsigned long long v = M[(size_t)x * MRL + prow];
 #pragma unroll
@@ -1094,6 +1105,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 }
                 __syncthreads();
             }
+            OSDL_TICK(13);
             // reduced columns and reduced syndrome as bit vectors over the pivot ROWS (the layout the sweep below uses)
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
@@ -1126,6 +1138,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             for (int i = tid; i < n; i += NT) P.out_osd0[(size_t)s * n + i] = xout[i];
         if (P.cmp_osd0)
             for (int i = tid; i < n; i += NT) P.cmp_osd0[(size_t)slot_id * n + i] = xout[i];
+        OSDL_TICK(14);
         int w0 = 0;
         for (int q = 0; q < NCV; ++q) w0 += __popcll(yvec[q]);
 
@@ -1310,6 +1323,46 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 }
             } else {
                 const unsigned int npat = (1u << wspan) - 1u;
+                if (wspan >= 4) {
+                    // Gray-code walk: a thread takes aligned runs of 16 consecutive Gray indices g (pattern = g ^ (g >> 1));
+                    // inside a run the pattern changes by ONE column per step -- column ctz(j) at step j, the same for
+                    // every run -- so a candidate costs one LDS word per row word instead of one per set bit (the plain
+                    // loop read ~8.5 words per row word; 14.8 M of an elimination's ~200 M cycles at order 15).  The
+                    // weights are the same integers, the winner is the same (lowest enumeration index among the lightest);
+                    // pattern 0 (OSD-0 itself) takes part with weight w0 and can never win the strict comparison.
+                    const unsigned int nruns = (npat + 1u) >> 4;
+                    unsigned long long mykey = ~0ull;
+                    for (unsigned int run = tid; run < nruns; run += NT) {
+                        const unsigned int g0 = run << 4;
+                        const unsigned int p0 = g0 ^ (g0 >> 1);
+                        int wg[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) wg[j] = 0;
+                        for (int q = 0; q < NCV; ++q) {
+                            unsigned long long v = yvec[q];
+                            unsigned int pp = p0;
+                            while (pp) {
+                                const int bq = __ffs((int)pp) - 1;
+                                pp &= pp - 1;
+                                v ^= colvec[bq * NCV + q];
+                            }
+                            wg[0] += __popcll(v);
+#pragma unroll
+                            for (int j = 1; j < 16; ++j) {
+                                v ^= colvec[(__builtin_ctz(j)) * NCV + q];
+                                wg[j] += __popcll(v);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const unsigned int g = g0 + j, pat = g ^ (g >> 1);
+                            const int wgt = wg[j] + __popc(pat);
+                            const unsigned long long key = ((unsigned long long)wgt << 32) | osd_e_index(pat, wspan, P.e_msb_first);
+                            mykey = key < mykey ? key : mykey;
+                        }
+                    }
+                    if (mykey != ~0ull) atomicMin(&best64[0], mykey);
+                } else
                 for (unsigned int pat = tid + 1; pat <= npat; pat += NT) {
                     int wgt = __popc(pat);
                     for (int q = 0; q < NCV; ++q) {
@@ -1331,6 +1384,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         }
 
         OSDL_FRESH_TID();
+        OSDL_TICK(15);
         // ------------------------------------------------- write the OSD-W solution
         if (sel_a == -1) {
             for (int i = tid; i < n; i += NT) {
@@ -1381,10 +1435,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             }
         }
         __syncthreads();
-        OSDL_TICK(6);
+        OSDL_TICK(16);
 #ifdef BPOSD_OSD_DIAG
+        tk[6] = tk[13] + tk[14] + tk[15] + tk[16];
         if (P.dbg && slot_id == 0 && tid == 0)
-            for (int i = 0; i < 13; ++i) P.dbg[i] = tk[i];
+            for (int i = 0; i < 17; ++i) P.dbg[i] = tk[i];
 #endif
 #undef OSDL_TICK
 #undef OSDL_COUNT
