@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "bposd_decode_batch_select",
     "bposd_decode_batch_select_device",
     "bposd_pack_rows_device",
+    "bposd_pack_rows_device_lane",
     "bposd_synchronize",
     "bposd_num_lanes",
     "bposd_last_lane",
@@ -38,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "bposd_host_free",
     "bposd_last_timing",
     "bposd_info",
+    "bposd_posterior_llr",
     "bposd_layout_info",
     "bposd_bp_kernel_info",
     "bposd_set_bp_variant",
@@ -118,6 +120,10 @@ def load():
     lib.bposd_info.restype = C.c_int
     lib.bposd_layout_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.bposd_layout_info.restype = C.c_int
+    lib.bposd_pack_rows_device_lane.argtypes = [vp, C.c_int32, vp, C.c_int64, C.c_int32, vp]
+    lib.bposd_pack_rows_device_lane.restype = C.c_int
+    lib.bposd_posterior_llr.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp]
+    lib.bposd_posterior_llr.restype = C.c_int
     lib.bposd_bp_kernel_info.argtypes = [vp, C.POINTER(C.c_int32), vp]
     lib.bposd_bp_kernel_info.restype = C.c_int
     lib.bposd_debug_local_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]

@@ -165,6 +165,7 @@ struct bposd_handle {
     bool async_pending = false;        // a device-pointer call may still be running on some lane
     hipStream_t osd_now = nullptr;     // stream the OSD kernel of the call being enqueued goes to
     uint8_t *cmp_osd0 = nullptr, *cmp_osdw = nullptr;  // compact OSD rows of the chunk being enqueued (host-pointer calls)
+    bool bp_only = false;              // the call being enqueued wants BP's outputs only (bposd_posterior_llr): no OSD kernel
     bool lane_alt = false;             // the call being enqueued takes the alternative channel from its lane's buffers
     bool tail_gate = false;            // the call being enqueued is a chunk of a host-pointer call: its BP kernel reports its tail
     std::string err;
@@ -1460,6 +1461,12 @@ int bposd_info(bposd_handle* h, int32_t* rank, int32_t* ncand, int32_t* max_iter
 
 int bposd_pack_rows_device(bposd_handle* h, const uint8_t* d_bytes, int64_t B, int32_t n, uint64_t* d_words) {
     if (!h) return BPOSD_ERR_INVALID;
+    return bposd_pack_rows_device_lane(h, h->last_lane, d_bytes, B, n, d_words);
+}
+
+int bposd_pack_rows_device_lane(bposd_handle* h, int32_t lane, const uint8_t* d_bytes, int64_t B, int32_t n, uint64_t* d_words) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (lane < 0 || lane >= h->nlanes) return fail(h, BPOSD_ERR_INVALID, "lane %d out of range", lane);
     if (B < 0 || n <= 0 || (B > 0 && (!d_bytes || !d_words))) return fail(h, BPOSD_ERR_INVALID, "bad pack arguments");
     if (B == 0) return BPOSD_OK;
     DeviceGuard dev_guard(h->device);
@@ -1469,8 +1476,8 @@ int bposd_pack_rows_device(bposd_handle* h, const uint8_t* d_bytes, int64_t B, i
     const int threads = 256;
     const long long want = (nwords * 64 + threads - 1) / threads;
     const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 16);
-    // queued behind the last device-pointer decode (same lane, stream order)
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(threads), 0, h->lanes[h->last_lane].stream, d_bytes, (long long)B, (int)n, wpr,
+    // queued behind the device-pointer decode that ran on this lane (stream order)
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(threads), 0, h->lanes[lane].stream, d_bytes, (long long)B, (int)n, wpr,
                        (unsigned long long*)d_words);
     HIP_TRY(h, hipGetLastError());
     return BPOSD_OK;
@@ -1532,7 +1539,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     }
     h->cur = &h->lanes[lane];
     h->osd_now = lean ? h->cur->stream : h->cur->osd_stream;
-    const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF;
+    const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF && !h->bp_only;
     int rc;
     if (osd_on) {
         if ((rc = ensure_lanes(h, &Lane::llr_ws, sizeof(double) * (size_t)B * h->n))) return rc;
@@ -1724,6 +1731,17 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
 int bposd_decode_batch(bposd_handle* h, const uint8_t* synd, int64_t B, uint8_t* osdw, uint8_t* osd0,
                        uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr) {
     return decode_host_impl(h, synd, B, nullptr, osdw, osd0, bp, conv, iters, llr);
+}
+
+int bposd_posterior_llr(bposd_handle* h, const uint8_t* synd, int64_t B, double* llr, uint8_t* bp, uint8_t* conv, int32_t* iters) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (!llr) return fail(h, BPOSD_ERR_INVALID, "llr buffer is required");
+    std::vector<uint8_t> scratch;
+    if (!bp) { scratch.resize((size_t)std::max<int64_t>(B, 0) * h->n); bp = scratch.data(); }
+    h->bp_only = true;  // the osdw slot of the call receives BP's hard decisions (what a decoder with osd_method "osd_off" returns)
+    const int rc = decode_host_impl(h, synd, B, nullptr, bp, nullptr, nullptr, conv, iters, llr);
+    h->bp_only = false;
+    return rc;
 }
 
 int bposd_decode_batch_select(bposd_handle* h, const uint8_t* synd, int64_t B, const uint8_t* sel,

@@ -159,6 +159,7 @@ class BpOsdDecoder:
         self._single = None
         self._single_cache = {}
         self._llr_probs = None
+        self._timing_override = None
         # batch results of the last decode_batch call
         self.batch_converge = None
         self.batch_osdw = None
@@ -188,6 +189,7 @@ class BpOsdDecoder:
         two-valued channel: bit i of shot b uses ``alt_channel_probs[i]`` where ``prior_select[b, i]`` is
         set and the decoder's ``channel_probs[i]`` elsewhere -- the batched form of the per-shot
         ``update_channel_probs`` of css_decode_sim.py:207-248."""
+        self._timing_override = None
         s = np.asarray(syndromes)
         received = None
         if s.ndim == 2 and self._is_received(s.shape[1]):
@@ -195,8 +197,16 @@ class BpOsdDecoder:
             # r + correction; the batch_* arrays and the attributes keep the error estimates
             if s.shape[1] != self.n:
                 raise ValueError(f"The received vectors must have shape (B, {self.n}). Not {s.shape}.")
-            received = np.ascontiguousarray(s.astype(np.int64) & 1, dtype=np.uint8)
-            s = np.ascontiguousarray((np.asarray(self._pcm @ received.T.astype(np.int32)) & 1).T, dtype=np.uint8)
+            received = s if s.dtype == np.uint8 else None
+            if received is None or (received > 1).any():
+                received = np.empty(s.shape, np.uint8)
+                for lo in range(0, len(s), 8192):  # (row chunks: no full-size int64 temporaries)
+                    received[lo:lo + 8192] = (s[lo:lo + 8192].astype(np.int64) & 1).astype(np.uint8)
+            received = np.ascontiguousarray(received)
+            syn = np.empty((len(s), self.m), np.uint8)
+            for lo in range(0, len(s), 8192):  # syndromes H r in row chunks of 8192: a sparse product per chunk
+                syn[lo:lo + 8192] = (np.asarray(self._pcm @ received[lo:lo + 8192].T.astype(np.int32)) & 1).T
+            s = syn
         if s.ndim != 2 or s.shape[1] != self.m:
             raise ValueError(f"The syndromes must have shape (B, {self.m}). Not {s.shape}.")
         # uint8 input goes to the device as it is (the kernels look at bit 0 only); other dtypes are reduced mod 2
@@ -281,6 +291,7 @@ class BpOsdDecoder:
 
         The one-syndrome call has its own thin path: page-sized buffers and their pointers are made once per decoder, the
         library runs the call without copy commands or events, and the result attributes are converted when read."""
+        self._timing_override = None
         s = np.asarray(syndrome)
         if s.ndim == 1 and self._is_received(len(s)):
             if len(s) != self.n:
@@ -340,17 +351,26 @@ class BpOsdDecoder:
         """Posterior LLRs of the last ``decode()``: the call is repeated with the LLR output switched on (same syndrome,
         same channel -- also when update_channel_probs has been called since -- hence the same bits)."""
         (s8, _, _, _, _, _, llr), ptrs = self._one
-        scratch = np.empty((1, self.n), np.uint8)
         later = None
+        # a property read must not disturb what last_timing() reports about the decode: keep its record
+        try:
+            self._timing_override = self.last_timing()
+        except (ValueError, RuntimeError):
+            self._timing_override = None
         if self._llr_probs is not None:
             later = self._probs
             _lib.check(self._lib, self._h, self._lib.bposd_update_channel_probs(self._h, self._llr_probs.ctypes.data))
         try:
-            rc = self._lib.bposd_decode_batch(self._h, ptrs[0], 1, scratch.ctypes.data, None, None, None, None, ptrs[6])
+            # BP only (the LLRs do not depend on the OSD stage -- on a large code that is a ~100 ms elimination)
+            rc = self._lib.bposd_posterior_llr(self._h, ptrs[0], 1, ptrs[6], None, None, None)
             _lib.check(self._lib, self._h, rc)
         finally:
             if later is not None:
-                _lib.check(self._lib, self._h, self._lib.bposd_update_channel_probs(self._h, later.ctypes.data))
+                try:
+                    _lib.check(self._lib, self._h, self._lib.bposd_update_channel_probs(self._h, later.ctypes.data))
+                except Exception:
+                    self._probs = self._llr_probs  # the handle still holds the decode's channel: say so
+                    raise
         return llr[0].copy()
 
     def decode_batch_device(self, d_syndromes, B, d_osdw, d_osd0=None, d_bp=None, d_converged=None,
@@ -359,6 +379,7 @@ class BpOsdDecoder:
         decoder's device; call :meth:`synchronize` before reading the outputs.  ``d_prior_select`` (device uint8
         [B, n]) with ``alt_channel_probs`` (host array of n floats) is the per-shot two-valued channel of
         :meth:`decode_batch`."""
+        self._timing_override = None
         if d_prior_select is not None:
             if alt_channel_probs is None:
                 raise ValueError("alt_channel_probs is required with d_prior_select")
@@ -372,9 +393,15 @@ class BpOsdDecoder:
                                                      d_converged, d_iters, d_llr)
         _lib.check(self._lib, self._h, rc)
 
-    def pack_rows_device(self, d_bytes, B, n, d_words):
-        """Bit-pack B device rows of n 0/1 bytes into ceil(n/64) uint64 words each (asynchronous)."""
-        _lib.check(self._lib, self._h, self._lib.bposd_pack_rows_device(self._h, d_bytes, int(B), int(n), d_words))
+    def pack_rows_device(self, d_bytes, B, n, d_words, lane=None):
+        """Bit-pack B device rows of n 0/1 bytes into ceil(n/64) uint64 words each (asynchronous).  Queued on the lane of
+        the most recent device-pointer decode -- call it right after the decode whose rows it packs -- or on ``lane``
+        (``last_lane`` read right after that decode) when other decode calls have been enqueued in between."""
+        if lane is None:
+            rc = self._lib.bposd_pack_rows_device(self._h, d_bytes, int(B), int(n), d_words)
+        else:
+            rc = self._lib.bposd_pack_rows_device_lane(self._h, int(lane), d_bytes, int(B), int(n), d_words)
+        _lib.check(self._lib, self._h, rc)
 
     def synchronize(self, lane=None):
         """Wait for everything queued on this decoder, or (``lane``) for the calls queued on one lane only."""
@@ -420,6 +447,7 @@ class BpOsdDecoder:
         """Host-pointer decode into caller-owned C-contiguous arrays (``uint8 [B, m]`` in; ``uint8 [B, n]``, ``uint8 [B]``,
         ``int32 [B]``, ``float64 [B, n]`` out; any output but ``osdw`` may be None) -- ``bposd_decode_batch`` with no
         allocation or conversion on the way."""
+        self._timing_override = None
         s = syndromes
         if s.dtype != np.uint8 or s.ndim != 2 or s.shape[1] != self.m or not s.flags.c_contiguous:
             raise ValueError(f"syndromes must be a C-contiguous uint8 array of shape (B, {self.m})")
@@ -443,6 +471,8 @@ class BpOsdDecoder:
         """dict(bp_ms, osd_ms, bp_iterations, osd_invocations) of the last decode call (HIP events).  Small host-pointer
         calls (up to 1 MB of staging, e.g. one ``decode()``) run without events: their two times read 0.0, the counters
         are exact."""
+        if getattr(self, "_timing_override", None) is not None:
+            return dict(self._timing_override)
         a, b = C.c_double(), C.c_double()
         it, no = C.c_int64(), C.c_int64()
         rc = self._lib.bposd_last_timing(self._h, C.byref(a), C.byref(b), C.byref(it), C.byref(no))

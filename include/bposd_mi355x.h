@@ -143,6 +143,12 @@ int bposd_decode_batch_select_device(bposd_handle *h, const uint8_t *d_syndromes
  */
 int bposd_pack_rows_device(bposd_handle *h, const uint8_t *d_bytes, int64_t B, int32_t n,
                            uint64_t *d_words);
+/* The same on a given lane.  bposd_pack_rows_device queues the kernel on the lane of the MOST RECENT device-pointer
+ * decode: it must be called before the next decode call is enqueued, or the rows of an earlier call would be packed on a
+ * stream that is not ordered behind the kernel still writing them.  A caller that packs later passes the lane its decode
+ * ran on (bposd_last_lane right after that call). */
+int bposd_pack_rows_device_lane(bposd_handle *h, int32_t lane, const uint8_t *d_bytes, int64_t B, int32_t n,
+                                uint64_t *d_words);
 
 /* Wait for all work queued on the handle (every lane, see below). */
 int bposd_synchronize(bposd_handle *h);
@@ -192,6 +198,14 @@ int bposd_info(bposd_handle *h, int32_t *rank, int32_t *num_candidates, int32_t 
 /* Diagnostics: simulated LDS cycles of one bit pass (bank-conflict model) for the natural bit order, the
  * order the library chose, and the conflict-free ideal.  Any pointer may be NULL. */
 int bposd_layout_info(bposd_handle *h, int64_t *natural_cycles, int64_t *chosen_cycles, int64_t *ideal_cycles);
+
+/* BP only: posterior log-likelihood ratios (and, optionally, BP's hard decisions, converge flags and iteration counts) of
+ * B host syndromes, without the OSD stage whatever osd_method the handle was created with.  This is what the
+ * `log_prob_ratios` attribute of the reference's decoder object holds after a decode (SURVEY.md 8 b); the Python class
+ * calls it when the attribute is read after a `decode()` that did not ask for LLRs.  llr [B, n] required; bp [B, n], conv
+ * [B], iters [B] nullable.  Synchronous. */
+int bposd_posterior_llr(bposd_handle *h, const uint8_t *syndromes, int64_t B, double *llr, uint8_t *bp,
+                        uint8_t *converged, int32_t *iters);
 
 /* Diagnostics: which BP kernel the last decode call launched, and the bank-conflict model of its bit pass.
  * kernel: BPOSD_BP_KERNEL_*.  lds_model[4] (local-edge and class kernels, else zeros): modelled ds_read_b64 cycles of one

@@ -477,6 +477,21 @@ def test_pack_rows_device(gpu_ready, h1922):
         w = d_w.cpu().numpy().view(np.uint64)
         back = np.unpackbits(w.view(np.uint8).reshape(B, -1), axis=1, bitorder="little")[:, :n]
         assert (back == x).all()
+    # packing the rows of an EARLIER decode after a newer one has been enqueued: on the lane that decode ran on
+    _, syn = _syndromes(h1922.hz, 0.05, 300, 11)
+    d_syn = torch.from_numpy(syn).cuda()
+    outs = [torch.empty((300, 1922), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    dec.decode_batch_device(d_syn.data_ptr(), 300, outs[0].data_ptr())
+    lane0 = dec.last_lane
+    dec.decode_batch_device(d_syn.data_ptr(), 300, outs[1].data_ptr())
+    assert dec.last_lane != lane0
+    d_w = torch.zeros((300, 31), dtype=torch.int64, device="cuda")
+    dec.pack_rows_device(outs[0].data_ptr(), 300, 1922, d_w.data_ptr(), lane=lane0)
+    dec.synchronize()
+    back = np.unpackbits(d_w.cpu().numpy().view(np.uint8).reshape(300, -1), axis=1, bitorder="little")[:, :1922]
+    assert (back == outs[0].cpu().numpy()).all() and (outs[0] == outs[1]).all()
+    with pytest.raises(ValueError):
+        dec.pack_rows_device(outs[0].data_ptr(), 300, 1922, d_w.data_ptr(), lane=9)
 
 
 def test_bit_layout_is_conflict_free_for_hgp_codes(gpu_ready, h1922, hgp400):
@@ -1389,8 +1404,10 @@ def test_decode_attributes_are_lazy_but_exact(gpu_ready, hgp400):
         out = d.decode(syn[b].astype(np.int64))
         assert out.dtype == np.int64 and (out == osdw1[b]).all()
         kept = d.osdw_decoding
+        timing = d.last_timing()
         d.update_channel_probs(p2)             # the LLRs of the call above have not been read yet
         assert (d.log_prob_ratios.view(np.uint64) == llr1[b].view(np.uint64)).all()
+        assert d.last_timing() == timing, "reading a property changed what last_timing() says about the decode"
         assert d.iter == int(it1[b]) and (d.osdw_decoding == osdw1[b]).all()
         out2 = d.decode(syn[b])                # now under the new channel
         assert (d.log_prob_ratios.view(np.uint64) == llr2[b].view(np.uint64)).all()
