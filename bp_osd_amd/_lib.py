@@ -43,6 +43,8 @@ EXPORTED_SYMBOLS = (
     "bposd_layout_info",
     "bposd_bp_kernel_info",
     "bposd_set_bp_variant",
+    "bposd_set_osd_variant",
+    "bposd_last_osd_kernel",
     "bposd_debug_local_layout",
     "bposd_last_error",
     "bposd_destroy",
@@ -128,6 +130,10 @@ def load():
     lib.bposd_bp_kernel_info.restype = C.c_int
     lib.bposd_debug_local_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.bposd_debug_local_layout.restype = C.c_int
+    lib.bposd_set_osd_variant.argtypes = [vp, C.c_int32]
+    lib.bposd_set_osd_variant.restype = C.c_int
+    lib.bposd_last_osd_kernel.argtypes = [vp]
+    lib.bposd_last_osd_kernel.restype = C.c_int
     lib.bposd_set_bp_variant.argtypes = [vp, C.c_int32]
     lib.bposd_set_bp_variant.restype = C.c_int
     lib.bposd_last_error.argtypes = [vp]

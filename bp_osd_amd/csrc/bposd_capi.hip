@@ -41,6 +41,7 @@
 #include "bp_serial_kernel.hip.h"
 #include "osd_large_kernel.hip.h"
 #include "osd_kernel.hip.h"
+#include "osd_wave_kernel.hip.h"
 #include "local_layout.h"
 #include "class_layout.h"
 
@@ -144,6 +145,8 @@ struct bposd_handle {
     bool probs_uniform = true;
     int bp_variant = 0;
     int last_bp_kernel = -1;  // BPOSD_BP_KERNEL_* of the last BP launch
+    int osd_variant = 0;      // 0 auto, 1 = one workgroup per elimination (osd_kernel), 2 = one wave per elimination where it applies
+    int last_osd_kernel = -1; // 0 none yet, 1 osd_kernel, 2 osd_wave_kernel, 3 osd_large_kernel
     // host copies
     std::vector<int> rp, ci;
     std::vector<double> probs;
@@ -767,6 +770,7 @@ int launch_bp_class_t(bposd_handle* h, const BpClassParams& C) {
     { int rc_occ = cached_occupancy(h, (const void*)k, nt, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
     if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] class BP kernel <%d;%d..%d> stride %d: %d threads, %zu B LDS, %d workgroups per CU\n", DC, DVLO, DVHI, MP, nt, lds, wg_per_cu);
     wg_per_cu = std::max(1, std::min(wg_per_cu, 16));
+    if (const char* e = getenv("BPOSD_CLASS_WG_CAP")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));
     long long grid = std::min<long long>(C.B, (long long)h->num_cu * wg_per_cu);
     if (grid < 1) grid = 1;
     int rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n);
@@ -999,7 +1003,45 @@ int osd_words(int n) {
     return 0;
 }
 
+// one wave per elimination (osd_wave_kernel.hip.h): small codes, integer weights
+template <int RPL, int W>
+int launch_osd_wave_t(bposd_handle* h, const OsdParams& P, long long B) {
+    auto k = osd_wave_kernel<RPL, W>;
+    const size_t lds = OSDW_WAVES * osdw_lds_per_wave(osdw_nsort(h->n), RPL, W);
+    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
+    int wg_per_cu = 1;
+    { int rc_occ = cached_occupancy(h, (const void*)k, 64 * OSDW_WAVES, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
+    long long grid = std::min<long long>((B + OSDW_WAVES - 1) / OSDW_WAVES, (long long)h->num_cu * wg_per_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * OSDW_WAVES), lds, h->osd_now ? h->osd_now : h->cur->osd_stream, P);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+// 0 = the code / configuration stays on osd_kernel
+int osd_wave_shape(const bposd_handle* h, const OsdParams& P) {
+    static const bool on = !(getenv("BPOSD_OSD_WAVE") && getenv("BPOSD_OSD_WAVE")[0] == '0');
+    if (!on || h->osd_variant == 1 || P.cost != nullptr || P.dbg != nullptr) return 0;  // switched off; fp64 weights; diagnostics
+    if (P.osd_method == BPOSD_OSD_E && P.osd_order > OSDW_MAX_E) return 0;
+    const int m = h->m, n1 = h->n + 1;
+    if (m <= 64 && n1 <= 128) return 1;
+    if (m <= 128 && n1 <= 256) return 2;
+    if (m <= 192 && n1 <= 448) return 3;
+    if (m <= 320 && n1 <= 640) return 4;
+    if (m <= 448 && n1 <= 960) return 5;
+    return 0;
+}
+
 int launch_osd(bposd_handle* h, const OsdParams& P, long long B) {
+    h->last_osd_kernel = osd_wave_shape(h, P) ? 2 : 1;
+    switch (osd_wave_shape(h, P)) {
+        case 1: return launch_osd_wave_t<1, 2>(h, P, B);
+        case 2: return launch_osd_wave_t<2, 4>(h, P, B);
+        case 3: return launch_osd_wave_t<3, 7>(h, P, B);
+        case 4: return launch_osd_wave_t<5, 10>(h, P, B);
+        case 5: return launch_osd_wave_t<7, 15>(h, P, B);
+    }
     switch (osd_words(h->n)) {
         case 1: return launch_osd_t<1>(h, P, B);
         case 2: return launch_osd_t<2>(h, P, B);
@@ -1491,6 +1533,15 @@ int bposd_layout_info(bposd_handle* h, int64_t* natural, int64_t* chosen, int64_
     return BPOSD_OK;
 }
 
+int bposd_set_osd_variant(bposd_handle* h, int32_t variant) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (variant < 0 || variant > 2) return fail(h, BPOSD_ERR_INVALID, "osd variant must be 0 (auto), 1 (workgroup kernel) or 2 (wave kernel where it applies)");
+    h->osd_variant = variant;
+    return BPOSD_OK;
+}
+
+int bposd_last_osd_kernel(bposd_handle* h) { return h ? h->last_osd_kernel : BPOSD_ERR_INVALID; }
+
 int bposd_bp_kernel_info(bposd_handle* h, int32_t* kernel, int64_t* lds_model) {
     if (!h) return BPOSD_ERR_INVALID;
     if (kernel) *kernel = h->last_bp_kernel;
@@ -1634,6 +1685,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             Q.dbg = h->cur->d_osd_dbg;
         }
         if (h->large) {
+            h->last_osd_kernel = 3;
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
             if (Q.dbg) {
                 long long st[17];

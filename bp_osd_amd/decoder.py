@@ -496,6 +496,16 @@ class BpOsdDecoder:
         return {"kernel": self.BP_KERNEL_NAMES.get(k.value, "none"), "read_cycles": int(mdl[0]), "read_floor": int(mdl[1]),
                 "write_cycles": int(mdl[2]), "write_floor": int(mdl[3])}
 
+    OSD_KERNEL_NAMES = {1: "osd_kernel", 2: "osd_wave_kernel", 3: "osd_large_kernel"}
+
+    def set_osd_variant(self, variant: int):
+        """Tuning / test knob: 0 auto; 1 one workgroup per elimination; 2 one wave per elimination where it applies."""
+        _lib.check(self._lib, self._h, self._lib.bposd_set_osd_variant(self._h, int(variant)))
+
+    def last_osd_kernel(self):
+        """Name of the OSD kernel the last decode call launched ("none" before the first one)."""
+        return self.OSD_KERNEL_NAMES.get(self._lib.bposd_last_osd_kernel(self._h), "none")
+
     def set_bp_variant(self, variant: int):
         """Tuning / test knob: 0 auto; 1, 2, 4 LDS kernel shapes; 16 .. 26 local-edge kernel; 32 class kernel (see the C header)."""
         _lib.check(self._lib, self._h, self._lib.bposd_set_bp_variant(self._h, int(variant)))

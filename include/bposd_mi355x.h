@@ -207,6 +207,13 @@ int bposd_layout_info(bposd_handle *h, int64_t *natural_cycles, int64_t *chosen_
 int bposd_posterior_llr(bposd_handle *h, const uint8_t *syndromes, int64_t B, double *llr, uint8_t *bp,
                         uint8_t *converged, int32_t *iters);
 
+/* Tuning / test knob for the small-code OSD stage: 0 = auto, 1 = one workgroup per elimination (osd_kernel.hip.h),
+ * 2 = one wave per elimination (osd_wave_kernel.hip.h) where it applies (uniform channel, m <= 448, n <= 959, osd_e order
+ * <= 12; auto picks it there).  Identical results.  bposd_last_osd_kernel: 1 / 2 as above, 3 = the HBM-resident kernel,
+ * -1 before the first OSD launch. */
+int bposd_set_osd_variant(bposd_handle *h, int32_t variant);
+int bposd_last_osd_kernel(bposd_handle *h);
+
 /* Diagnostics: which BP kernel the last decode call launched, and the bank-conflict model of its bit pass.
  * kernel: BPOSD_BP_KERNEL_*.  lds_model[4] (local-edge and class kernels, else zeros): modelled ds_read_b64 cycles of one
  * bit pass per workgroup, their conflict-free floor, modelled ds_write_b64 cycles, their floor.  Any pointer may be NULL. */

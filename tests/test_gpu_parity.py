@@ -825,6 +825,47 @@ def test_class_kernel_equals_lds_kernel_and_oracle(gpu_ready, seed_file):
     assert (a.batch_iter == b.batch_iter).all() and (a.batch_osd0 == b.batch_osd0).all()
 
 
+@pytest.mark.parametrize("seed_file", ["mkmn_16_4_6.txt", "mkmn_20_5_8.txt", "mkmn_24_6_10.txt", None])
+def test_osd_wave_kernel_equals_workgroup_kernel_and_oracle(gpu_ready, surface13, seed_file):
+    """osd_wave_kernel (one wave per elimination: the reference's three example codes and the [[13,1,3]] surface code) against
+    osd_kernel (one workgroup per elimination) and the oracle: OSD-0, OSD-CS up to the reference example's order 42 and the
+    cap of 64, OSD-E up to 12, both tie policies and both OSD-E bit orders; a non-uniform channel stays on osd_kernel."""
+    import os
+
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp
+    from oracle import OracleDecoder
+
+    if seed_file is None:
+        H = surface13.hz
+    else:
+        seed = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", seed_file)).astype(np.uint8)
+        H = hgp(seed, compute_logicals=False).hx
+    m, n = H.shape
+    q = 0.09
+    _, syn = _syndromes(H, q, 300, n + 7)
+    kmax = n - np.linalg.matrix_rank(np.asarray(H.todense(), dtype=float)) if n < 20 else 64
+    cases = [("osd0", 0, 0, 0), ("osd_cs", min(42, kmax), 0, 0), ("osd_cs", min(64, kmax), 1, 0), ("osd_cs", 3, 0, 0),
+             ("osd_e", min(7, kmax), 0, 0), ("osd_e", min(12, kmax), 1, 1)]
+    for method, order, tie, ebo in cases:
+        kw = dict(error_rate=q, max_iter=3, bp_method="ms", ms_scaling_factor=0.625, osd_method=method, osd_order=order,
+                  sort_tie_policy=tie, osd_e_bit_order=ebo)
+        a = BpOsdDecoder(H, **kw)
+        ra = _gpu_decode(a, syn)
+        assert a.last_osd_kernel() == "osd_wave_kernel", (method, order)
+        b = BpOsdDecoder(H, **kw)
+        b.set_osd_variant(1)
+        rb = _gpu_decode(b, syn)
+        assert b.last_osd_kernel() == "osd_kernel"
+        assert (~ra["converged"]).sum() > 20
+        for k in ("osdw", "osd0", "bp", "converged", "iters"):
+            assert (ra[k] == rb[k]).all(), (method, order, k)
+        _compare_exact(ra, OracleDecoder(H, **kw).decode_batch(syn))
+    g = BpOsdDecoder(H, channel_probs=np.random.default_rng(1).uniform(0.03, 0.1, n), max_iter=3, osd_method="osd_cs", osd_order=min(5, kmax))
+    g.decode_batch(syn)
+    assert g.last_osd_kernel() == "osd_kernel"  # fp64 weights
+
+
 def test_reference_example_script_configuration(gpu_ready, hgp400):
     """examples/qldpc_decode_example.py, option for option ([[400,16,6]], Z-only noise at 5 %, min-sum with the variable
     scaling factor, max_iter = 0 -> N, osd_cs order 42, seed 42, 1000 runs): the batched harness on the MI355X decoder
