@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="BP kernel / workgroup shape (0 auto; see bposd_set_bp_variant)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the final RCCL gather")
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (no overlap of consecutive steps)")
+    ap.add_argument("--slots", type=int, default=0, help="steps in flight (default 2; more needs that many lanes and no gather)")
     ap.add_argument("--max-iter", type=int, default=-1, help="override max_iter (diagnostics; -1 = the config's)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal where only one GPU exists: every rank decodes on device 0 and the gather runs over "
@@ -219,6 +220,8 @@ def main():
     if args.variant:
         dec.set_bp_variant(args.variant)
     nslots = 1 if args.no_pipeline else 2  # steps in flight (the handle has dec.num_lanes >= 2 lanes)
+    if args.slots and not args.no_pipeline:
+        nslots = max(1, min(args.slots, dec.num_lanes))
 
     dev = torch.device("cuda", local_rank)
     d_syn = [torch.from_numpy(b[1]).to(dev) for b in batches]

@@ -1385,6 +1385,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     h->large = (m > 1024) || (osd_words(n) == 0) || h->bp_hbm;
     if (h->large) {
         h->nlanes = 2;
+        if (const char* e = getenv("BPOSD_LARGE_LANES")) h->nlanes = std::max(1, std::min(BPOSD_LANES, atoi(e)));
         if (n > 32767 || m > 16384 || (h->bp_hbm && bp_large_lds_bytes(m, n) > h->lds_per_cu)) {
             fail(nullptr, BPOSD_ERR_UNSUPPORTED, "code too large even for the HBM-resident kernels (m=%d n=%d; limits 16384 / 32767)", m, n);
             bposd_destroy(h);

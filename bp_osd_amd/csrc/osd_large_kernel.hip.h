@@ -318,6 +318,87 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_lds(unsigned int lpw_a
     if (lane == 0) { misc[4] = (unsigned int)cnp; misc[5] = (unsigned int)cnr; misc[6] = cdone ? 1u : 0u; }
 }
 
+// E3 as a function of its own: the pivot rows of the new group (group index ng, npiv rows listed in grow) at their start
+// state for every word to the right of w, written to PRO.  Not inlined, so that its registers are allocated on their own
+// (the kernel sits at its 128-VGPR cap: inside it, more than one word in flight per wave went to scratch and ran slower).
+__device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long* U, const int* grow, const int* gnp, const unsigned long long* TmO,
+                                                              unsigned long long* PRO, const unsigned long long* M, int MRL, int W, int w, int ng,
+                                                              int npiv) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+                        typedef volatile __attribute__((address_space(3))) unsigned long long* lds_rw;
+                        lds_rw tw = (lds_rw)(U + (size_t)wave * (OSDL_K - 1) * 256);
+                        const int row = (lane < npiv) ? grow[ng * 64 + lane] : 0;
+                        unsigned long long mrow[OSDL_K - 1];
+    #pragma unroll
+                        for (int g = 0; g < OSDL_K - 1; ++g) mrow[g] = (g < ng && lane < npiv) ? TmO[(size_t)g * MRL + row] : 0ull;
+                        // lane L < 16 * ng builds the 16-entry table of (group L >> 4, nibble L & 15) by a Gray-code walk
+                        // from its 4 pivot-row words; the inputs of the next word are requested before this word is
+                        // processed (the loop is otherwise bound by the latency of its own loads)
+                        const int tg = lane >> 4, tgrp = lane & 15;
+                        const bool builder = tg < ng;
+                        const int tnp = builder ? gnp[tg] - 4 * tgrp : 0;
+                        const int q0 = 4 * tgrp;
+                        // OSDL_E3D words in flight per wave: the loop is bound by the latency of its own gathers (a row word
+                        // per lane from M, four pivot-row words from PRO), ~10 k cycles each under full load
+                        unsigned long long prq[OSDL_E3D][4], mvq[OSDL_E3D];
+                        auto issue = [&](int d, int xx) {
+                            if (xx < W) {
+                                const unsigned long long* src = PRO + ((size_t)(builder ? tg : 0) * W + xx) * 64 + q0;
+    #pragma unroll
+                                for (int kk = 0; kk < 4; ++kk) prq[d][kk] = src[kk];
+                                mvq[d] = M[(size_t)xx * MRL + row];
+                            }
+                        };
+                        auto process = [&](int d, int x) {
+                            unsigned long long pr[4];
+    #pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) pr[kk] = (builder && kk < tnp) ? prq[d][kk] : 0ull;
+                            unsigned long long v = (lane < npiv) ? mvq[d] : 0ull;
+                            issue(d, x + OSDL_NW * OSDL_E3D);  // this stage's registers are free again
+                            if (builder) {
+                                unsigned int idx = osdl_opaque(((unsigned int)lane >> 1) & 15u);  // conflict-free start entries
+                                unsigned long long tv = 0ull;
+    #pragma unroll
+                                for (int kk = 0; kk < 4; ++kk)
+                                    if ((idx >> kk) & 1u) tv ^= pr[kk];
+                                lds_rw tp = tw + lane * 16;
+                                tp[idx] = tv;
+    #pragma unroll
+                                for (int i = 1; i < 16; ++i) {
+                                    const int bit = (i & 1) ? 0 : ((i & 2) ? 1 : ((i & 4) ? 2 : 3));  // ctz(i)
+                                    idx ^= 1u << bit;
+                                    tv ^= pr[bit];
+                                    tp[idx] = tv;
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                            for (int g = 0; g < OSDL_K - 1; ++g) {
+                                if (g < ng) {
+                                    const int ngrp = (gnp[g] + 3) >> 2;
+                                    for (int grp = 0; grp < ngrp; ++grp)
+                                        v ^= tw[(g * 16 + grp) * 16 + (int)((mrow[g] >> (4 * grp)) & 15ull)];
+                                }
+                            }
+                            PRO[((size_t)ng * W + x) * 64 + lane] = v;
+                            __builtin_amdgcn_wave_barrier();
+                        };
+                        const int xs = w + 1 + wave;
+    #pragma unroll
+                        for (int d = 0; d < OSDL_E3D; ++d) issue(d, xs + d * OSDL_NW);
+                        for (int x = xs; x < W; x += OSDL_NW * OSDL_E3D) {
+    #pragma unroll
+                            for (int d = 0; d < OSDL_E3D; ++d)
+                                if (x + d * OSDL_NW < W) process(d, x + d * OSDL_NW);
+                        }
+}
+
+// (The apply pass as a non-inlined function of its own was measured too: 90 -> 104-113 M cycles per elimination -- its list build and
+// its row loop live on state of the caller (row masks, frozen / used bits) that then crosses the call in memory.  It stays inlined.)
+// (The back-substitution loop as a non-inlined function of its own: 13 -> 29 M cycles per elimination; it stays inlined.  E3 is the one
+// phase that gains from an allocation of its own: 42 -> 25.6 M.)
 template <int RPT>
 __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -951,74 +1032,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 __syncthreads();  // grow / gnp / TmO of the new group are visible
                 // ------------ E3: pivot rows of the new group at its start state, for every later word.
                 // One wave per word, wave-private tables (a wave's LDS operations complete in order).
-                if (w + 1 < W) {
-                    typedef volatile __attribute__((address_space(3))) unsigned long long* lds_rw;
-                    lds_rw tw = (lds_rw)(U + (size_t)wave * (OSDL_K - 1) * 256);
-                    const int row = (lane < npiv) ? grow[ng * 64 + lane] : 0;
-                    unsigned long long mrow[OSDL_K - 1];
-#pragma unroll
-                    for (int g = 0; g < OSDL_K - 1; ++g) mrow[g] = (g < ng && lane < npiv) ? TmO[(size_t)g * MRL + row] : 0ull;
-                    // lane L < 16 * ng builds the 16-entry table of (group L >> 4, nibble L & 15) by a Gray-code walk
-                    // from its 4 pivot-row words; the inputs of the next word are requested before this word is
-                    // processed (the loop is otherwise bound by the latency of its own loads)
-                    const int tg = lane >> 4, tgrp = lane & 15;
-                    const bool builder = tg < ng;
-                    const int tnp = builder ? gnp[tg] - 4 * tgrp : 0;
-                    const int q0 = 4 * tgrp;
-                    // OSDL_E3D words in flight per wave: the loop is bound by the latency of its own gathers (a row word
-                    // per lane from M, four pivot-row words from PRO), ~10 k cycles each under full load
-                    unsigned long long prq[OSDL_E3D][4], mvq[OSDL_E3D];
-                    auto issue = [&](int d, int xx) {
-                        if (xx < W) {
-                            const unsigned long long* src = PRO + ((size_t)(builder ? tg : 0) * W + xx) * 64 + q0;
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) prq[d][kk] = src[kk];
-                            mvq[d] = M[(size_t)xx * MRL + row];
-                        }
-                    };
-                    auto process = [&](int d, int x) {
-                        unsigned long long pr[4];
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) pr[kk] = (builder && kk < tnp) ? prq[d][kk] : 0ull;
-                        unsigned long long v = (lane < npiv) ? mvq[d] : 0ull;
-                        issue(d, x + OSDL_NW * OSDL_E3D);  // this stage's registers are free again
-                        if (builder) {
-                            unsigned int idx = osdl_opaque(((unsigned int)lane >> 1) & 15u);  // conflict-free start entries
-                            unsigned long long tv = 0ull;
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk)
-                                if ((idx >> kk) & 1u) tv ^= pr[kk];
-                            lds_rw tp = tw + lane * 16;
-                            tp[idx] = tv;
-#pragma unroll
-                            for (int i = 1; i < 16; ++i) {
-                                const int bit = (i & 1) ? 0 : ((i & 2) ? 1 : ((i & 4) ? 2 : 3));  // ctz(i)
-                                idx ^= 1u << bit;
-                                tv ^= pr[bit];
-                                tp[idx] = tv;
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int g = 0; g < OSDL_K - 1; ++g) {
-                            if (g < ng) {
-                                const int ngrp = (gnp[g] + 3) >> 2;
-                                for (int grp = 0; grp < ngrp; ++grp)
-                                    v ^= tw[(g * 16 + grp) * 16 + (int)((mrow[g] >> (4 * grp)) & 15ull)];
-                            }
-                        }
-                        PRO[((size_t)ng * W + x) * 64 + lane] = v;
-                        __builtin_amdgcn_wave_barrier();
-                    };
-                    const int xs = w + 1 + wave;
-#pragma unroll
-                    for (int d = 0; d < OSDL_E3D; ++d) issue(d, xs + d * OSDL_NW);
-                    for (int x = xs; x < W; x += OSDL_NW * OSDL_E3D) {
-#pragma unroll
-                        for (int d = 0; d < OSDL_E3D; ++d)
-                            if (x + d * OSDL_NW < W) process(d, x + d * OSDL_NW);
-                    }
-                }
+                if (w + 1 < W) osdl_e3_materialise(U, grow, gnp, TmO, PRO, M, (int)MRL, W, w, ng, npiv);
                 ++ng;
                 __syncthreads();  // PRO of the new group is visible
                 OSDL_TICK(4);
@@ -1076,35 +1090,35 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             if (tid < ntc_g) zv[(size_t)tid * W + (tpos[tid] >> 6)] = 1ull << (tpos[tid] & 63);
             if (tid == 0) zv[(size_t)OSDL_MAXSPAN * W + (W - 1)] = 1ull << 63;
             __syncthreads();
-#pragma clang loop unroll(disable)
-            for (int w = wlast; w >= 0; --w) {
-                const int prow = pivrow[w * 64 + lane];  // lane q: the pivot at sorted position 64 w + q, if any
-                unsigned long long acc[NR];
-#pragma unroll
-                for (int c = 0; c < NR; ++c) acc[c] = 0ull;
-                if (prow >= 0) {
-                    // (eight row words in flight per lane instead of one: measured slower, 13.3 -> 15.0 M cycles -- the loop is
-                    // not waiting for a single round trip but for the CU's gather rate: 64 distinct lines per wave-level load)
-                    for (int x = w + wave; x < W; x += OSDL_NW) {  // the 16 waves split the words to the right
-                        const unsigned long long v = M[(size_t)x * MRL + prow];
-#pragma unroll
-                        for (int c = 0; c < NR; ++c) acc[c] ^= v & zv[(size_t)c * W + x];
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < NR; ++c) {
-                    if (c < ntc_g || c == OSDL_MAXSPAN) {  // uniform
-                        const unsigned long long bits = __ballot(prow >= 0 && (__popcll(acc[c]) & 1));
-                        if (lane == 0 && bits) atomicXor(&resw[c], bits);
-                    }
-                }
-                __syncthreads();
-                if (tid < NR) {
-                    zv[(size_t)tid * W + w] ^= resw[tid];
-                    resw[tid] = 0ull;
-                }
-                __syncthreads();
-            }
+            #pragma clang loop unroll(disable)
+                        for (int w = wlast; w >= 0; --w) {
+                            const int prow = pivrow[w * 64 + lane];  // lane q: the pivot at sorted position 64 w + q, if any
+                            unsigned long long acc[NR];
+            #pragma unroll
+                            for (int c = 0; c < NR; ++c) acc[c] = 0ull;
+                            if (prow >= 0) {
+                                // (eight row words in flight per lane instead of one: measured slower, 13.3 -> 15.0 M cycles -- the loop is
+                                // not waiting for a single round trip but for the CU's gather rate: 64 distinct lines per wave-level load)
+                                for (int x = w + wave; x < W; x += OSDL_NW) {  // the 16 waves split the words to the right
+                                    const unsigned long long v = M[(size_t)x * MRL + prow];
+            #pragma unroll
+                                    for (int c = 0; c < NR; ++c) acc[c] ^= v & zv[(size_t)c * W + x];
+                                }
+                            }
+            #pragma unroll
+                            for (int c = 0; c < NR; ++c) {
+                                if (c < ntc_g || c == OSDL_MAXSPAN) {  // uniform
+                                    const unsigned long long bits = __ballot(prow >= 0 && (__popcll(acc[c]) & 1));
+                                    if (lane == 0 && bits) atomicXor(&resw[c], bits);
+                                }
+                            }
+                            __syncthreads();
+                            if (tid < NR) {
+                                zv[(size_t)tid * W + w] ^= resw[tid];
+                                resw[tid] = 0ull;
+                            }
+                            __syncthreads();
+                        }
             OSDL_TICK(13);
             // reduced columns and reduced syndrome as bit vectors over the pivot ROWS (the layout the sweep below uses)
 #pragma unroll
