@@ -1019,10 +1019,13 @@ int launch_osd_wave_t(bposd_handle* h, const OsdParams& P, long long B) {
     return 0;
 }
 
-// 0 = the code / configuration stays on osd_kernel
-int osd_wave_shape(const bposd_handle* h, const OsdParams& P) {
+// 0 = the code / configuration stays on osd_kernel.  A lone elimination is faster on a workgroup of its own (measured,
+// tools/latency_reference_codes.py: a decode() that needs OSD 1.23 against 1.92 ms on [[900,36,10]], 0.50 / 0.57 ms on
+// [[400,16,6]]); the wave kernel is for throughput, so auto takes it for calls of at least 4096 syndromes.
+int osd_wave_shape(const bposd_handle* h, const OsdParams& P, long long B) {
     static const bool on = !(getenv("BPOSD_OSD_WAVE") && getenv("BPOSD_OSD_WAVE")[0] == '0');
     if (!on || h->osd_variant == 1 || P.cost != nullptr || P.dbg != nullptr) return 0;  // switched off; fp64 weights; diagnostics
+    if (h->osd_variant == 0 && std::max<long long>(B, h->batch_hint) < 4096) return 0;
     if (P.osd_method == BPOSD_OSD_E && P.osd_order > OSDW_MAX_E) return 0;
     const int m = h->m, n1 = h->n + 1;
     if (m <= 64 && n1 <= 128) return 1;
@@ -1034,8 +1037,8 @@ int osd_wave_shape(const bposd_handle* h, const OsdParams& P) {
 }
 
 int launch_osd(bposd_handle* h, const OsdParams& P, long long B) {
-    h->last_osd_kernel = osd_wave_shape(h, P) ? 2 : 1;
-    switch (osd_wave_shape(h, P)) {
+    h->last_osd_kernel = osd_wave_shape(h, P, B) ? 2 : 1;
+    switch (osd_wave_shape(h, P, B)) {
         case 1: return launch_osd_wave_t<1, 2>(h, P, B);
         case 2: return launch_osd_wave_t<2, 4>(h, P, B);
         case 3: return launch_osd_wave_t<3, 7>(h, P, B);

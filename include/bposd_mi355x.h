@@ -209,7 +209,8 @@ int bposd_posterior_llr(bposd_handle *h, const uint8_t *syndromes, int64_t B, do
 
 /* Tuning / test knob for the small-code OSD stage: 0 = auto, 1 = one workgroup per elimination (osd_kernel.hip.h),
  * 2 = one wave per elimination (osd_wave_kernel.hip.h) where it applies (uniform channel, m <= 448, n <= 959, osd_e order
- * <= 12; auto picks it there).  Identical results.  bposd_last_osd_kernel: 1 / 2 as above, 3 = the HBM-resident kernel,
+ * <= 12; auto picks it there for calls of at least 4096 syndromes -- a lone elimination is faster on a workgroup of its own).
+ * Identical results.  bposd_last_osd_kernel: 1 / 2 as above, 3 = the HBM-resident kernel,
  * -1 before the first OSD launch. */
 int bposd_set_osd_variant(bposd_handle *h, int32_t variant);
 int bposd_last_osd_kernel(bposd_handle *h);

@@ -851,6 +851,7 @@ def test_osd_wave_kernel_equals_workgroup_kernel_and_oracle(gpu_ready, surface13
         kw = dict(error_rate=q, max_iter=3, bp_method="ms", ms_scaling_factor=0.625, osd_method=method, osd_order=order,
                   sort_tie_policy=tie, osd_e_bit_order=ebo)
         a = BpOsdDecoder(H, **kw)
+        a.set_osd_variant(2)  # (auto takes the wave kernel for calls of >= 4096 syndromes: a lone elimination is faster on a workgroup)
         ra = _gpu_decode(a, syn)
         assert a.last_osd_kernel() == "osd_wave_kernel", (method, order)
         b = BpOsdDecoder(H, **kw)

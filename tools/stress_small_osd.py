@@ -46,6 +46,7 @@ for case in range(ncases):
         kw["osd_order"] = 2
         g = BpOsdDecoder(H, **kw)
     o = OracleDecoder(H, **kw)
+    g.set_osd_variant(2)  # the wave kernel where it applies (auto keeps small calls on the workgroup kernel)
     out = g.decode_batch(syn)
     ref = o.decode_batch(syn, want_llr=False)
     ok = (out == ref["osdw"]).all() and (g.batch_osd0 == ref["osd0"]).all() and (g.batch_iter == ref["iters"]).all() and (g.batch_bp == ref["bp"]).all()
