@@ -136,25 +136,29 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                     const int deg = P.chk_deg[c];
                     const bool sbit = (syn[c] & 1) != 0;
                     double* mc = msg + c;
+                    // absent edges (k >= deg) enter as +DBL_MAX (neutral for the minima and the sign parity; tanh = 1): every
+                    // array element is defined on every path (partially defined arrays turn into loop-carried registers)
                     double v[DC];
 #pragma unroll
-                    for (int k = 0; k < DC; ++k)
+                    for (int k = 0; k < DC; ++k) {
+                        v[k] = __DBL_MAX__;
                         if (k < deg) v[k] = mc[(size_t)k * MP];
+                    }
                     if (METHOD == 1) {
                         bool neg[DC];
                         bool par = sbit;
 #pragma unroll
                         for (int k = 0; k < DC; ++k) {
-                            neg[k] = (k < deg) ? (v[k] <= 0.0) : false;
+                            neg[k] = (v[k] <= 0.0);
                             par ^= neg[k];
                         }
                         double pre[DC], suf[DC];
                         pre[0] = __DBL_MAX__;
 #pragma unroll
-                        for (int k = 1; k < DC; ++k) pre[k] = (k - 1 < deg) ? min_abs(pre[k - 1], v[k - 1]) : pre[k - 1];
+                        for (int k = 1; k < DC; ++k) pre[k] = min_abs(pre[k - 1], v[k - 1]);
                         suf[DC - 1] = __DBL_MAX__;
 #pragma unroll
-                        for (int k = DC - 2; k >= 0; --k) suf[k] = (k + 1 < deg) ? min_abs(suf[k + 1], v[k + 1]) : suf[k + 1];
+                        for (int k = DC - 2; k >= 0; --k) suf[k] = min_abs(suf[k + 1], v[k + 1]);
 #pragma unroll
                         for (int k = 0; k < DC; ++k) {
                             if (k < deg) {
@@ -167,8 +171,9 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                         double t = 1.0;
 #pragma unroll
                         for (int k = 0; k < DC; ++k) {
+                            pre[k] = t;
+                            th[k] = 1.0;
                             if (k < deg) {
-                                pre[k] = t;
                                 th[k] = pm_tanh(v[k] / 2);
                                 t *= th[k];
                             }
@@ -207,18 +212,20 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                     int pos[DV];
                     double cm[DV], pre[DV];
 #pragma unroll
-                    for (int d = 0; d < DV; ++d)
-                        if (d < deg) {
-                            pos[d] = P.var_pos[(size_t)d * n + i];
-                            cm[d] = msg[pos[d]];
-                        }
-                    double t = l0;
+                    for (int d = 0; d < DV; ++d) {
+                        pos[d] = 0;
+                        cm[d] = 0.0;
+                        if (d < deg) pos[d] = P.var_pos[(size_t)d * n + i];
+                    }
 #pragma unroll
                     for (int d = 0; d < DV; ++d)
-                        if (d < deg) {
-                            pre[d] = t;
-                            t += cm[d];
-                        }
+                        if (d < deg) cm[d] = msg[pos[d]];
+                    double t = l0;
+#pragma unroll
+                    for (int d = 0; d < DV; ++d) {
+                        pre[d] = t;
+                        if (d < deg) t += cm[d];
+                    }
                     if (keep_llr) llrt[i] = t;
                     const int dnew = (t <= 0.0) ? 1 : 0;
                     double suf = 0.0;

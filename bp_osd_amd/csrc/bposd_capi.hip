@@ -879,7 +879,14 @@ int build_tables_large(bposd_handle* h, int DV, int MP) {
 template <int DC, int DV>
 int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
     const size_t lds = bp_large_lds_bytes(h->m, h->n);
-    const int wg_per_cu = std::max<int>(1, std::min<size_t>(4, h->lds_per_cu / lds));
+    // persistent workgroups: what registers and LDS admit per CU (the message workspace is per workgroup)
+    int wg_per_cu = 1;
+    {
+        const void* kq = h->cfg.bp_method == BPOSD_BP_MIN_SUM ? (const void*)bp_large_kernel<DC, DV, 1> : (const void*)bp_large_kernel<DC, DV, 0>;
+        int rc_lds = set_max_lds(h, kq, lds); if (rc_lds) return rc_lds;
+        int rc_occ = cached_occupancy(h, kq, 512, lds, &wg_per_cu); if (rc_occ) return rc_occ;
+    }
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 4));
     const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
     int rc;
     if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * DC * P.mp))) return rc;
