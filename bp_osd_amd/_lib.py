@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "bposd_set_osd_variant",
     "bposd_last_osd_kernel",
     "bposd_debug_local_layout",
+    "bposd_debug_class_layout",
     "bposd_last_error",
     "bposd_destroy",
 )
@@ -130,6 +131,8 @@ def load():
     lib.bposd_bp_kernel_info.restype = C.c_int
     lib.bposd_debug_local_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.bposd_debug_local_layout.restype = C.c_int
+    lib.bposd_debug_class_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
+    lib.bposd_debug_class_layout.restype = C.c_int
     lib.bposd_set_osd_variant.argtypes = [vp, C.c_int32]
     lib.bposd_set_osd_variant.restype = C.c_int
     lib.bposd_last_osd_kernel.argtypes = [vp]

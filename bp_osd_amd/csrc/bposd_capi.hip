@@ -2102,6 +2102,45 @@ int bposd_debug_local_layout(const int32_t* indptr, const int32_t* indices, int3
     return BPOSD_OK;
 }
 
+int bposd_debug_class_layout(const int32_t* indptr, const int32_t* indices, int32_t m, int32_t n, int32_t* pos_chk, int32_t* pos_bit,
+                             int32_t* bit_slot, int32_t* grp_deg, int64_t* info) {
+    // host-only: the tables bp_class_kernel would be launched with for this pcm (tests check their invariants without a GPU).
+    // info[0..9]: DC, DVLO, DVHI, VPT, MP (= NTMAX), threads per workgroup, modelled read cycles, their floor, modelled write cycles, their floor
+    if (!indptr || !indices || !info || m < 1 || n < 1) return BPOSD_ERR_INVALID;
+    std::vector<int> rp(indptr, indptr + m + 1), ci(indices, indices + indptr[m]);
+    int dc = -1;
+    for (int c = 0; c < m; ++c) {
+        const int d = rp[c + 1] - rp[c];
+        if (dc < 0) dc = d;
+        else if (d != dc) return BPOSD_ERR_UNSUPPORTED;
+    }
+    std::vector<int> vdeg(n, 0);
+    for (int e : ci) {
+        if (e < 0 || e >= n) return BPOSD_ERR_INVALID;
+        vdeg[e]++;
+    }
+    int lo = 1 << 30, hi = 0;
+    for (int d : vdeg) { lo = std::min(lo, d); hi = std::max(hi, d); }
+    const ClassShape* shp = nullptr;
+    for (const auto& k : kClassShapes)
+        if (k.dc == dc && k.dvlo <= lo && hi <= k.dvhi) { shp = &k; break; }
+    if (!shp || m > 1024) return BPOSD_ERR_UNSUPPORTED;
+    class_layout::Tables T;
+    bool ok = false;
+    for (int mp : {256, 512, 1024}) {
+        if (m > mp) continue;
+        if (class_layout::build(rp, ci, m, n, shp->dc, shp->dvlo, shp->dvhi, kClassVPT, mp, mp, 50000, T)) { ok = true; break; }
+    }
+    if (!ok) return BPOSD_ERR_UNSUPPORTED;
+    info[0] = shp->dc; info[1] = shp->dvlo; info[2] = shp->dvhi; info[3] = kClassVPT; info[4] = T.MP; info[5] = T.NT;
+    info[6] = T.read_cycles; info[7] = T.read_floor; info[8] = T.write_cycles; info[9] = T.write_floor;
+    if (pos_chk) std::copy(T.pos_chk.begin(), T.pos_chk.end(), pos_chk);    // [MP]
+    if (pos_bit) std::copy(T.pos_bit.begin(), T.pos_bit.end(), pos_bit);    // [VPT * MP]
+    if (bit_slot) std::copy(T.bit_slot.begin(), T.bit_slot.end(), bit_slot);  // [DVHI * VPT * MP]
+    if (grp_deg) std::copy(T.grp_deg.begin(), T.grp_deg.end(), grp_deg);    // [VPT * MP / 64]
+    return BPOSD_OK;
+}
+
 void* bposd_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;

@@ -118,3 +118,75 @@ def test_output_buffer_pool_never_hands_out_live_memory():
     d = alloc((32, 64), np.float64)                                              # 16 KB > 4 KB buffers: new one
     assert d.dtype == np.float64 and d.shape == (32, 64)
     assert sum(x.nbytes for x in fake._out_pool) <= max(3 << 12, d.nbytes + 2 * 4096) + 4096
+
+
+def _csr32(H):
+    import scipy.sparse as sp
+
+    H = sp.csr_matrix(H)
+    H.sort_indices()
+    return np.ascontiguousarray(H.indptr, dtype=np.int32), np.ascontiguousarray(H.indices, dtype=np.int32), H
+
+
+@pytest.mark.parametrize("seed_file", ["mkmn_16_4_6.txt", "mkmn_20_5_8.txt", "mkmn_24_6_10.txt"])
+def test_class_kernel_tables_are_consistent(lib, seed_file):
+    """Host-side tables of bp_class_kernel (no GPU needed): every check sits at exactly one position of the check waves,
+    every bit in exactly one (thread, slot), every edge has its own LDS slot k * MP + position of its check with k its
+    rank inside the check, padding lanes point at their thread's dummy slot, a group's degree is its bits' degree, and
+    the bank model of the chosen layout is not worse than twice its floor."""
+    import os
+
+    from bp_osd_amd.codes import hgp
+
+    seed = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", seed_file)).astype(np.uint8)
+    ip, ix, H = _csr32(hgp(seed, compute_logicals=False).hz)
+    m, n = H.shape
+    MPmax, VPT, DVHI = 1024, 2, 4
+    pos_chk = np.full(MPmax, -7, np.int32)
+    pos_bit = np.full(VPT * MPmax, -7, np.int32)
+    bit_slot = np.full(DVHI * VPT * MPmax, -7, np.int32)
+    grp_deg = np.full(VPT * MPmax // 64, -7, np.int32)
+    info = np.zeros(10, np.int64)
+    rc = lib.bposd_debug_class_layout(ip.ctypes.data, ix.ctypes.data, m, n, pos_chk.ctypes.data, pos_bit.ctypes.data,
+                                      bit_slot.ctypes.data, grp_deg.ctypes.data, info.ctypes.data)
+    assert rc == 0
+    DC, DVLO, DVHI_, VPT_, MP, NT = (int(x) for x in info[:6])
+    assert (DC, DVLO, DVHI_, VPT_) == (7, 3, 4, 2) and MP >= m and NT % 64 == 0 and NT <= MP
+    pc = pos_chk[:MP]
+    assert sorted(pc[pc >= 0].tolist()) == list(range(m)) and (pc[((m + 63) // 64) * 64:] < 0).all()
+    pos_of = np.empty(m, int)
+    pos_of[pc[pc >= 0]] = np.flatnonzero(pc >= 0)
+    pb = pos_bit[:VPT * MP].reshape(VPT, MP)
+    assert sorted(pb[pb >= 0].tolist()) == list(range(n)) and (pb[:, NT:] < 0).all()
+    bs = bit_slot[:DVHI_ * VPT * MP].reshape(DVHI_, VPT, MP)
+    gd = grp_deg[:VPT * MP // 64].reshape(VPT, MP // 64)
+    Hc = H.tocsc()
+    seen = set()
+    for r in range(VPT):
+        for t in range(NT):
+            i, deg_g = pb[r, t], gd[r, t // 64]
+            if i < 0:
+                assert (bs[:, r, t] == DC * MP + t).all()  # the thread's dummy slot
+                continue
+            checks = Hc.indices[Hc.indptr[i]:Hc.indptr[i + 1]]
+            assert len(checks) == deg_g
+            for d, c in enumerate(sorted(checks)):
+                k = int(np.searchsorted(H.indices[H.indptr[c]:H.indptr[c + 1]], i))
+                assert bs[d, r, t] == k * MP + pos_of[c]
+                seen.add(int(bs[d, r, t]))
+    assert len(seen) == H.nnz
+    assert info[6] <= 2.1 * info[7] and info[8] <= 1.3 * info[9]
+
+
+def test_local_edge_layout_model_regression(lib):
+    """Host-side layout search of bp_local_kernel on H1922 (no GPU needed): a perfect ownership exists, at most one mixed
+    group, and the modelled LDS cycles of the bit pass stay near what the search reached when it was tuned (218 read /
+    408 write cycles against floors of 128 / 384)."""
+    from bp_osd_amd.codes import h1922
+
+    ip, ix, H = _csr32(h1922(compute_logicals=False).hz)
+    out = np.zeros(16, np.int64)
+    assert lib.bposd_debug_local_layout(ip.ctypes.data, ix.ctypes.data, H.shape[0], H.shape[1], out.ctypes.data) == 0
+    assert out[1] == 128 and out[15] == 384 and out[4] == 1024
+    assert out[0] <= 240 and out[14] <= 430 and out[3] <= 2
+    assert out[5:14].sum() == H.shape[0]
