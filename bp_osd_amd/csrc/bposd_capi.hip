@@ -707,10 +707,11 @@ int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
 }
 
 // ------------------------------------------------------------------ class BP kernel: tables + launch
-// Instances: (check degree; bit degrees) = (7; 3..4) -- the reference's three example codes -- and (6; 3) -- H1922 with
-// product-sum, other (3,6)-regular codes --, LDS stride 256 / 512 / 1024, two bit slots per thread.
+// Instances: (check degree; bit degrees) = (7; 3..4) -- the reference's three example codes --, (6; 3) -- H1922 with
+// product-sum, other (3,6)-regular codes --, (4; 2) -- toric codes, hgp(ring_code) -- and (8; 4); LDS stride 256 / 512 / 1024,
+// two bit slots per thread.
 struct ClassShape { int dc, dvlo, dvhi; };
-const ClassShape kClassShapes[] = {{7, 3, 4}, {6, 3, 3}};
+const ClassShape kClassShapes[] = {{7, 3, 4}, {6, 3, 3}, {4, 2, 2}, {8, 4, 4}};  // + toric-like codes, products of (4,4)-regular seeds
 constexpr int kClassVPT = 2;
 
 int build_tables_class(bposd_handle* h) {
@@ -814,6 +815,8 @@ int launch_bp_class(bposd_handle* h, const BpParams& P) {
     const bool uprior = h->probs_uniform && P.sel == nullptr && h->probs[0] > 0.0 && h->probs[0] < 0.5;
     if (h->class_dc == 7) return launch_bp_class_shape<7, 3, 4, BPOSD_CLASS7_MINW, BPOSD_CLASS7_MINW_PS>(h, C, uprior);
     if (h->class_dc == 6) return launch_bp_class_shape<6, 3, 3, 8, BPOSD_CLASS6_MINW_PS>(h, C, uprior);
+    if (h->class_dc == 4) return launch_bp_class_shape<4, 2, 2, 8, 7>(h, C, uprior);
+    if (h->class_dc == 8) return launch_bp_class_shape<8, 4, 4, 7, 6>(h, C, uprior);
     return fail(h, BPOSD_ERR_UNSUPPORTED, "no class BP kernel for check degree %d", h->class_dc);
 }
 

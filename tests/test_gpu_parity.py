@@ -825,6 +825,34 @@ def test_class_kernel_equals_lds_kernel_and_oracle(gpu_ready, seed_file):
     assert (a.batch_iter == b.batch_iter).all() and (a.batch_osd0 == b.batch_osd0).all()
 
 
+@pytest.mark.parametrize("family", ["toric", "reg44"])
+def test_class_kernel_other_degree_families(gpu_ready, family):
+    """bp_class_kernel's other instances: (check degree 4; bit degree 2) -- a toric code, hgp(ring_code(12)) -- and (8; 4) --
+    the product of a (4,4)-regular seed: auto-selected, equal to the generic LDS kernel and to the oracle (min-sum and
+    product-sum with clip, LLR bits)."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp, regular_ldpc_seed, ring_code
+    from oracle import OracleDecoder
+
+    seed = ring_code(12) if family == "toric" else regular_ldpc_seed(12, 12, 4, 4, seed=3)
+    H = hgp(seed, compute_logicals=False).hx
+    n = H.shape[1]
+    q = 0.06
+    _, syn = _syndromes(H, q, 300, n)
+    for kw in (dict(error_rate=q, max_iter=40, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=6),
+               dict(error_rate=q, max_iter=15, bp_method="ps", ps_clip=20.0, ps_math=1, osd_method="osd_e", osd_order=5)):
+        gkw = {k: v for k, v in kw.items() if k != "ps_math"}
+        a = BpOsdDecoder(H, **gkw)
+        ra = _gpu_decode(a, syn)
+        assert a.bp_kernel_info()["kernel"] == "bp_class_kernel"
+        b = BpOsdDecoder(H, **gkw)
+        b.set_bp_variant(1)
+        rb = _gpu_decode(b, syn)
+        assert b.bp_kernel_info()["kernel"] == "bp_kernel"
+        _compare_exact(ra, dict(rb, converged=rb["converged"].astype(np.uint8)))
+        _compare_exact(ra, OracleDecoder(H, **kw).decode_batch(syn))
+
+
 @pytest.mark.parametrize("seed_file", ["mkmn_16_4_6.txt", "mkmn_20_5_8.txt", "mkmn_24_6_10.txt", None])
 def test_osd_wave_kernel_equals_workgroup_kernel_and_oracle(gpu_ready, surface13, seed_file):
     """osd_wave_kernel (one wave per elimination: the reference's three example codes and the [[13,1,3]] surface code) against
