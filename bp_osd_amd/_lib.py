@@ -131,7 +131,7 @@ def load():
     lib.bposd_bp_kernel_info.restype = C.c_int
     lib.bposd_debug_local_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     lib.bposd_debug_local_layout.restype = C.c_int
-    lib.bposd_debug_class_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
+    lib.bposd_debug_class_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.bposd_debug_class_layout.restype = C.c_int
     lib.bposd_set_osd_variant.argtypes = [vp, C.c_int32]
     lib.bposd_set_osd_variant.restype = C.c_int

@@ -1,13 +1,15 @@
-// bp_class_kernel.hip.h -- BP with all messages in LDS for codes whose checks all have ONE degree and whose bits fall
-// into a few degree classes -- every hypergraph product of regular seeds, i.e. all three example codes the reference
-// ships ([[400,16,6]], [[625,25,8]], [[900,36,10]]: check degree 7, bit degrees 3 and 4;
-// /root/reference/examples/qldpc_decode_example.py:5-23).  Rows a3-a7 of SURVEY.md §8; the scheme (persistent workgroups
+// bp_class_kernel.hip.h -- BP with all messages in LDS for codes whose checks and bits fall into a few degree classes:
+// every hypergraph product of regular seeds, i.e. all three example codes the reference ships ([[400,16,6]],
+// [[625,25,8]], [[900,36,10]]: check degree 7, bit degrees 3 and 4; /root/reference/examples/qldpc_decode_example.py:5-23),
+// toric codes (4; 2), and products with open boundaries such as the surface codes (check degrees 3..4, bit degrees 1..2;
+// the reference's README example is the distance-3 one).  Rows a3-a7 of SURVEY.md §8; the scheme (persistent workgroups
 // on an atomic queue, in-place check-major messages  msg[k * MP + c], incremental mismatch bitmap, speculative check
 // pass, two barriers per iteration) is bp_kernel.hip.h's, with what the local-edge kernel taught:
 //
-//   * NO per-lane degree predicates.  The check degree DC is a template constant.  The host sorts bits by degree into
-//     64-lane groups; group (slot r, wave w) has ONE degree, the kernel switches on that wave-uniform number into
-//     straight-line code for DVLO .. DVHI edges (0 = no bits here: skipped).  A padding lane of a group points all its
+//   * NO per-lane degree predicates.  The host sorts checks by degree into waves and bits by degree into 64-lane
+//     groups; a wave's checks have ONE degree (DCLO .. DC) and group (slot r, wave w) of bits has ONE degree
+//     (DVLO .. DVHI); the kernel switches on those wave-uniform numbers into straight-line code (0 = nothing here:
+//     skipped).  A padding lane of a group points all its
 //     edges at a private dummy slot that starts at a positive prior: its messages stay positive for ever (sums of
 //     positive numbers), its decision never flips, nobody else reads the slot.  Padding check lanes (positions without
 //     a check) compute on their own never-referenced slots.  Checks sit at host-chosen positions (pos_chk).
@@ -45,6 +47,8 @@ struct BpClassParams {
     const int* __restrict__ bit_slot;     // [DVHI * VPT * NTMAX]  entry (d * VPT + r) * NTMAX + tid: LDS slot of the d-th edge
                                           //                       (ascending check index); the thread's dummy slot where there is none
     const int* __restrict__ grp_deg;      // [VPT * NTMAX / 64]    entry r * (NTMAX / 64) + wave: degree of that 64-lane group, 0 = empty
+    const int* __restrict__ grp_cdeg;     // [CPT * NTMAX / 64]    entry j * (NTMAX / 64) + wave: degree of the checks at that wave's
+                                          //                       positions, 0 = no checks there
     uint8_t* __restrict__ out_bp;
     uint8_t* __restrict__ out_osd0;
     uint8_t* __restrict__ out_osdw;
@@ -137,10 +141,72 @@ __device__ __forceinline__ void bit_pass_arm(int D, const unsigned int* eaddr, d
     }
 }
 
-// DC: degree of every check;  DVLO .. DVHI: bit degrees that occur;  CPT / VPT: check / bit slots per thread;
+// The check pass of one check with D edges (D compile-time) at LDS position mc: a4 (product-sum) / a5 (min-sum).
+template <int D, int MP, int METHOD>
+__device__ __forceinline__ void check_pass_deg(msg_ptr mc, bool sbit, int alpha_lo, int alpha_hi, int nalpha_hi, double ps_clip) {
+    double v[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) v[k] = mc[k * MP];
+    if (METHOD == 1) {
+        double pre[D], suf[D];
+        pre[0] = __DBL_MAX__;
+#pragma unroll
+        for (int k = 1; k < D; ++k) pre[k] = min_abs(pre[k - 1], v[k - 1]);
+        suf[D - 1] = __DBL_MAX__;
+#pragma unroll
+        for (int k = D - 2; k >= 0; --k) suf[k] = min_abs(suf[k + 1], v[k + 1]);
+        bool neg[D];
+        bool par = sbit;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            neg[k] = (v[k] <= 0.0);  // a zero counts as negative, as in the reference
+            par ^= neg[k];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double mag = (k == 0) ? suf[0] : (k == D - 1 ? pre[D - 1] : min_pos(pre[k], suf[k]));
+            const double sa = __hiloint2double((par ^ neg[k]) ? nalpha_hi : alpha_hi, alpha_lo);
+            mc[k * MP] = mag * sa;
+        }
+    } else {
+        double pre[D], th[D];
+        double t = 1.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            pre[k] = t;
+            th[k] = pm_tanh(v[k] / 2);
+            t *= th[k];
+        }
+        t = 1.0;
+        const double sg = sbit ? -1.0 : 1.0;
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) {
+            const double x = pre[k] * t;
+            double o = sg * pm_log((1 + x) / (1 - x));
+            if (ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
+                if (o > ps_clip) o = ps_clip;
+                if (o < -ps_clip) o = -ps_clip;
+            }
+            mc[k * MP] = o;
+            t *= th[k];
+        }
+    }
+}
+// run-time (wave-uniform) check degree -> compile-time arm
+template <int DLO, int DHI, int MP, int METHOD>
+__device__ __forceinline__ void check_pass_arm(int D, msg_ptr mc, bool sbit, int alpha_lo, int alpha_hi, int nalpha_hi, double ps_clip) {
+    if constexpr (DLO >= DHI) {
+        check_pass_deg<DHI, MP, METHOD>(mc, sbit, alpha_lo, alpha_hi, nalpha_hi, ps_clip);
+    } else {
+        if (D == DLO) check_pass_deg<DLO, MP, METHOD>(mc, sbit, alpha_lo, alpha_hi, nalpha_hi, ps_clip);
+        else check_pass_arm<DLO + 1, DHI, MP, METHOD>(D, mc, sbit, alpha_lo, alpha_hi, nalpha_hi, ps_clip);
+    }
+}
+
+// DCLO .. DC: check degrees that occur (DC also sizes the message array);  DVLO .. DVHI: bit degrees that occur;  CPT / VPT: check / bit slots per thread;
 // MPT: LDS stride (power of two >= m);  NTMAX: table stride = largest workgroup this instantiation is launched with;
 // METHOD: 0 product-sum, 1 min-sum;  UPRIOR: uniform channel and no per-shot channel (prior in a scalar pair)
-template <int DC, int DVLO, int DVHI, int CPT, int VPT, int MPT, int NTMAX, int MINW, int METHOD, bool UPRIOR>
+template <int DCLO, int DC, int DVLO, int DVHI, int CPT, int VPT, int MPT, int NTMAX, int MINW, int METHOD, bool UPRIOR>
 __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n;
@@ -179,10 +245,10 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
 #pragma unroll
         for (int d = 0; d < DVHI; ++d) eaddr[r][d] = msg_base + 8u * (unsigned int)bpc_args()->bit_slot[(d * VPT + r) * NTMAX + tid];
     }
-    // wave-uniform: does group j of this wave hold any check?  (checks fill the first ceil(m / 64) waves' positions)
-    bool chk_live[CPT];
+    // wave-uniform: degree of the checks at this wave's positions of group j (0 = none)
+    int cdeg[CPT];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) chk_live[j] = ((wave << 6) + j * NT) < ((m + 63) & ~63);
+    for (int j = 0; j < CPT; ++j) cdeg[j] = __builtin_amdgcn_readfirstlane(bpc_args()->grp_cdeg[j * NW + wave]);
     const int want_llr_s = __builtin_amdgcn_readfirstlane(bpc_args()->out_llr != nullptr ? 1 : 0);
     auto want_llr = [&]() -> bool {
         int w = want_llr_s;
@@ -254,7 +320,7 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
                     unsigned long long mis = 0ull;
 #pragma unroll
                     for (int j = 0; j < CPT; ++j)
-                        if (chk_live[j])
+                        if (cdeg[j] != 0)
                             mis |= *(const volatile __attribute__((address_space(3))) unsigned long long*)(uintptr_t)(
                                 diffw_base + (unsigned int)(((wave << 6) + j * NT) >> 3));
                     if (lane == 0 && mis) sh[fi] = 1;
@@ -270,55 +336,9 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
                 const int alpha_lo = (int)(unsigned int)alpha_u, alpha_hi = (int)(unsigned int)(alpha_u >> 32), nalpha_hi = alpha_hi ^ (int)0x80000000;
 #pragma unroll
                 for (int j = 0; j < CPT; ++j) {
-                    if (!chk_live[j]) continue;  // wave-uniform
-                    msg_ptr mc = BPC_AT(msg_base + 8u * (unsigned int)(tid + j * NT));
-                    double v[DC];
-#pragma unroll
-                    for (int k = 0; k < DC; ++k) v[k] = mc[k * MP];
-                    if (METHOD == 1) {
-                        double pre[DC], suf[DC];
-                        pre[0] = __DBL_MAX__;
-#pragma unroll
-                        for (int k = 1; k < DC; ++k) pre[k] = min_abs(pre[k - 1], v[k - 1]);
-                        suf[DC - 1] = __DBL_MAX__;
-#pragma unroll
-                        for (int k = DC - 2; k >= 0; --k) suf[k] = min_abs(suf[k + 1], v[k + 1]);
-                        bool neg[DC];
-                        bool par = sbit[j];
-#pragma unroll
-                        for (int k = 0; k < DC; ++k) {
-                            neg[k] = (v[k] <= 0.0);  // a zero counts as negative, as in the reference
-                            par ^= neg[k];
-                        }
-#pragma unroll
-                        for (int k = 0; k < DC; ++k) {
-                            const double mag = (k == 0) ? suf[0] : (k == DC - 1 ? pre[DC - 1] : min_pos(pre[k], suf[k]));
-                            const double sa = __hiloint2double((par ^ neg[k]) ? nalpha_hi : alpha_hi, alpha_lo);
-                            mc[k * MP] = mag * sa;
-                        }
-                    } else {
-                        double pre[DC], th[DC];
-                        double t = 1.0;
-#pragma unroll
-                        for (int k = 0; k < DC; ++k) {
-                            pre[k] = t;
-                            th[k] = pm_tanh(v[k] / 2);
-                            t *= th[k];
-                        }
-                        t = 1.0;
-                        const double sg = sbit[j] ? -1.0 : 1.0;
-#pragma unroll
-                        for (int k = DC - 1; k >= 0; --k) {
-                            const double x = pre[k] * t;
-                            double o = sg * pm_log((1 + x) / (1 - x));
-                            if (P.ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
-                                if (o > P.ps_clip) o = P.ps_clip;
-                                if (o < -P.ps_clip) o = -P.ps_clip;
-                            }
-                            mc[k * MP] = o;
-                            t *= th[k];
-                        }
-                    }
+                    if (cdeg[j] == 0) continue;  // wave-uniform
+                    check_pass_arm<DCLO, DC, MP, METHOD>(cdeg[j], BPC_AT(msg_base + 8u * (unsigned int)(tid + j * NT)), sbit[j], alpha_lo, alpha_hi,
+                                                         nalpha_hi, P.ps_clip);
                 }
                 __syncthreads();
                 if (sh[fi] == 0) {

@@ -135,9 +135,9 @@ struct bposd_handle {
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
     // class BP kernel (bp_class_kernel.hip.h): every check has the same degree, bit degrees inside one compiled range
     bool class_ok = false;
-    int class_dc = 0, class_dvlo = 0, class_dvhi = 0, class_mp = 0, class_nt = 0;
+    int class_dclo = 0, class_dc = 0, class_dvlo = 0, class_dvhi = 0, class_mp = 0, class_nt = 0;
     long class_read_cycles = 0, class_write_cycles = 0, class_read_floor = 0, class_write_floor = 0;  // modelled, one bit pass
-    int *d_cpos_chk = nullptr, *d_cpos_bit = nullptr, *d_cbit_slot = nullptr, *d_cgrp_deg = nullptr;
+    int *d_cpos_chk = nullptr, *d_cpos_bit = nullptr, *d_cbit_slot = nullptr, *d_cgrp_deg = nullptr, *d_cgrp_cdeg = nullptr;
     bool large = false;   // beyond the register-resident OSD kernel: HBM-resident matrix, device rank probe
     bool bp_hbm = false;  // BP messages do not fit one CU's LDS either: HBM-resident BP kernel
     int max_iter = 0;
@@ -707,29 +707,32 @@ int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
 }
 
 // ------------------------------------------------------------------ class BP kernel: tables + launch
-// Instances: (check degree; bit degrees) = (7; 3..4) -- the reference's three example codes --, (6; 3) -- H1922 with
-// product-sum, other (3,6)-regular codes --, (4; 2) -- toric codes, hgp(ring_code) -- and (8; 4); LDS stride 256 / 512 / 1024,
-// two bit slots per thread.
-struct ClassShape { int dc, dvlo, dvhi; };
-const ClassShape kClassShapes[] = {{7, 3, 4}, {6, 3, 3}, {4, 2, 2}, {8, 4, 4}};  // + toric-like codes, products of (4,4)-regular seeds
+// Instances: (check degrees; bit degrees) = (7; 3..4) -- the reference's three example codes --, (6; 3) -- H1922 with
+// product-sum, other (3,6)-regular codes --, (4; 2) -- toric codes, hgp(ring_code) --, (8; 4), and (3..4; 1..2) -- surface
+// codes, hgp(rep_code) --; LDS stride 256 / 512 / 1024, two bit slots per thread.
+struct ClassShape { int dclo, dc, dvlo, dvhi; };
+const ClassShape kClassShapes[] = {{7, 7, 3, 4}, {6, 6, 3, 3}, {4, 4, 2, 2}, {8, 8, 4, 4}, {3, 4, 1, 2}};
 constexpr int kClassVPT = 2;
+
+// the first instance whose degree ranges cover the code's, or null
+const ClassShape* class_shape_for(const std::vector<int>& rp, const std::vector<int>& ci, int m, int n) {
+    int clo = 1 << 30, chi = 0, lo = 1 << 30, hi = 0;
+    for (int c = 0; c < m; ++c) {
+        const int d = rp[c + 1] - rp[c];
+        clo = std::min(clo, d); chi = std::max(chi, d);
+    }
+    std::vector<int> vdeg(n, 0);
+    for (int e : ci) vdeg[e]++;
+    for (int d : vdeg) { lo = std::min(lo, d); hi = std::max(hi, d); }
+    for (const auto& k : kClassShapes)
+        if (k.dclo <= clo && chi <= k.dc && k.dvlo <= lo && hi <= k.dvhi) return &k;
+    return nullptr;
+}
 
 int build_tables_class(bposd_handle* h) {
     h->class_ok = false;
     if (h->bp_hbm || h->m > 1024) return 0;
-    int dc = -1;
-    for (int c = 0; c < h->m; ++c) {
-        const int d = h->rp[c + 1] - h->rp[c];
-        if (dc < 0) dc = d;
-        else if (d != dc) return 0;
-    }
-    std::vector<int> vdeg(h->n, 0);
-    for (int e : h->ci) vdeg[e]++;
-    int lo = 1 << 30, hi = 0;
-    for (int d : vdeg) { lo = std::min(lo, d); hi = std::max(hi, d); }
-    const ClassShape* shp = nullptr;
-    for (const auto& k : kClassShapes)
-        if (k.dc == dc && k.dvlo <= lo && hi <= k.dvhi) { shp = &k; break; }
+    const ClassShape* shp = class_shape_for(h->rp, h->ci, h->m, h->n);
     if (!shp) return 0;
     class_layout::Tables T;
     bool ok = false;
@@ -737,7 +740,7 @@ int build_tables_class(bposd_handle* h) {
     const int iters = getenv("BPOSD_LAYOUT_ITERS") ? atoi(getenv("BPOSD_LAYOUT_ITERS")) : 200000;
     for (int mp : {256, 512, 1024}) {
         if (h->m > mp) continue;
-        if (class_layout::build(h->rp, h->ci, h->m, h->n, shp->dc, shp->dvlo, shp->dvhi, kClassVPT, mp, mp, iters, T)) { ok = true; MP = mp; break; }
+        if (class_layout::build(h->rp, h->ci, h->m, h->n, shp->dclo, shp->dc, shp->dvlo, shp->dvhi, kClassVPT, mp, mp, iters, T)) { ok = true; MP = mp; break; }
     }
     if (!ok) return 0;
     if (getenv("BPOSD_DEBUG_OCC"))
@@ -754,22 +757,23 @@ int build_tables_class(bposd_handle* h) {
     if ((rc = up(&h->d_cpos_bit, T.pos_bit))) return rc;
     if ((rc = up(&h->d_cbit_slot, T.bit_slot))) return rc;
     if ((rc = up(&h->d_cgrp_deg, T.grp_deg))) return rc;
-    h->class_dc = shp->dc; h->class_dvlo = shp->dvlo; h->class_dvhi = shp->dvhi; h->class_mp = MP; h->class_nt = T.NT;
+    if ((rc = up(&h->d_cgrp_cdeg, T.grp_cdeg))) return rc;
+    h->class_dclo = shp->dclo; h->class_dc = shp->dc; h->class_dvlo = shp->dvlo; h->class_dvhi = shp->dvhi; h->class_mp = MP; h->class_nt = T.NT;
     h->class_read_cycles = T.read_cycles; h->class_write_cycles = T.write_cycles;
     h->class_read_floor = T.read_floor; h->class_write_floor = T.write_floor;
     h->class_ok = true;
     return 0;
 }
 
-template <int DC, int DVLO, int DVHI, int MP, int MINW, int METHOD, bool UPRIOR>
+template <int DCLO, int DC, int DVLO, int DVHI, int MP, int MINW, int METHOD, bool UPRIOR>
 int launch_bp_class_t(bposd_handle* h, const BpClassParams& C) {
-    auto k = bp_class_kernel<DC, DVLO, DVHI, 1, kClassVPT, MP, MP, MINW, METHOD, UPRIOR>;
+    auto k = bp_class_kernel<DCLO, DC, DVLO, DVHI, 1, kClassVPT, MP, MP, MINW, METHOD, UPRIOR>;
     const int nt = h->class_nt;
     const size_t lds = bp_class_lds_bytes(DC, MP, MP);
     { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
     int wg_per_cu = 1;
     { int rc_occ = cached_occupancy(h, (const void*)k, nt, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
-    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] class BP kernel <%d;%d..%d> stride %d: %d threads, %zu B LDS, %d workgroups per CU\n", DC, DVLO, DVHI, MP, nt, lds, wg_per_cu);
+    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] class BP kernel <%d..%d;%d..%d> stride %d: %d threads, %zu B LDS, %d workgroups per CU\n", DCLO, DC, DVLO, DVHI, MP, nt, lds, wg_per_cu);
     wg_per_cu = std::max(1, std::min(wg_per_cu, 16));
     if (const char* e = getenv("BPOSD_CLASS_WG_CAP")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));
     long long grid = std::min<long long>(C.B, (long long)h->num_cu * wg_per_cu);
@@ -783,13 +787,13 @@ int launch_bp_class_t(bposd_handle* h, const BpClassParams& C) {
     return 0;
 }
 
-template <int DC, int DVLO, int DVHI, int MINW_MS, int MINW_PS>
+template <int DCLO, int DC, int DVLO, int DVHI, int MINW_MS, int MINW_PS>
 int launch_bp_class_shape(bposd_handle* h, const BpClassParams& C, bool uprior) {
     const bool ms = h->cfg.bp_method == BPOSD_BP_MIN_SUM;
 #define BPOSD_CLASS_MP(MPV)                                                                                              \
     if (h->class_mp == MPV) {                                                                                            \
-        if (ms) return uprior ? launch_bp_class_t<DC, DVLO, DVHI, MPV, MINW_MS, 1, true>(h, C) : launch_bp_class_t<DC, DVLO, DVHI, MPV, MINW_MS, 1, false>(h, C); \
-        return uprior ? launch_bp_class_t<DC, DVLO, DVHI, MPV, MINW_PS, 0, true>(h, C) : launch_bp_class_t<DC, DVLO, DVHI, MPV, MINW_PS, 0, false>(h, C); \
+        if (ms) return uprior ? launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_MS, 1, true>(h, C) : launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_MS, 1, false>(h, C); \
+        return uprior ? launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 0, true>(h, C) : launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 0, false>(h, C); \
     }
     BPOSD_CLASS_MP(256)
     BPOSD_CLASS_MP(512)
@@ -809,14 +813,15 @@ int launch_bp_class(bposd_handle* h, const BpParams& P) {
     BpClassParams C{};
     C.m = P.m; C.n = P.n; C.B = P.B; C.max_iter = P.max_iter; C.ms_scaling = P.ms_scaling; C.ps_clip = P.ps_clip; C.osd_enabled = P.osd_enabled;
     C.synd = P.synd; C.llr0 = P.llr0; C.sel = P.sel; C.llr0_alt = P.llr0_alt;
-    C.pos_chk = h->d_cpos_chk; C.pos_bit = h->d_cpos_bit; C.bit_slot = h->d_cbit_slot; C.grp_deg = h->d_cgrp_deg;
+    C.pos_chk = h->d_cpos_chk; C.pos_bit = h->d_cpos_bit; C.bit_slot = h->d_cbit_slot; C.grp_deg = h->d_cgrp_deg; C.grp_cdeg = h->d_cgrp_cdeg;
     C.out_bp = P.out_bp; C.out_osd0 = P.out_osd0; C.out_osdw = P.out_osdw; C.out_conv = P.out_conv; C.out_iters = P.out_iters;
     C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total; C.tail_flag = P.tail_flag;
     const bool uprior = h->probs_uniform && P.sel == nullptr && h->probs[0] > 0.0 && h->probs[0] < 0.5;
-    if (h->class_dc == 7) return launch_bp_class_shape<7, 3, 4, BPOSD_CLASS7_MINW, BPOSD_CLASS7_MINW_PS>(h, C, uprior);
-    if (h->class_dc == 6) return launch_bp_class_shape<6, 3, 3, 8, BPOSD_CLASS6_MINW_PS>(h, C, uprior);
-    if (h->class_dc == 4) return launch_bp_class_shape<4, 2, 2, 8, 7>(h, C, uprior);
-    if (h->class_dc == 8) return launch_bp_class_shape<8, 4, 4, 7, 6>(h, C, uprior);
+    if (h->class_dc == 7) return launch_bp_class_shape<7, 7, 3, 4, BPOSD_CLASS7_MINW, BPOSD_CLASS7_MINW_PS>(h, C, uprior);
+    if (h->class_dc == 6) return launch_bp_class_shape<6, 6, 3, 3, 8, BPOSD_CLASS6_MINW_PS>(h, C, uprior);
+    if (h->class_dc == 4 && h->class_dclo == 4) return launch_bp_class_shape<4, 4, 2, 2, 8, 7>(h, C, uprior);
+    if (h->class_dc == 4 && h->class_dclo == 3) return launch_bp_class_shape<3, 4, 1, 2, 8, 7>(h, C, uprior);
+    if (h->class_dc == 8) return launch_bp_class_shape<8, 8, 4, 4, 7, 6>(h, C, uprior);
     return fail(h, BPOSD_ERR_UNSUPPORTED, "no class BP kernel for check degree %d", h->class_dc);
 }
 
@@ -1257,7 +1262,7 @@ void bposd_destroy(bposd_handle* h) {
                     (void*)h->d_var_pos, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt,
                     (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
                     (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl,
-                    (void*)h->d_cpos_chk, (void*)h->d_cpos_bit, (void*)h->d_cbit_slot, (void*)h->d_cgrp_deg,
+                    (void*)h->d_cpos_chk, (void*)h->d_cpos_bit, (void*)h->d_cbit_slot, (void*)h->d_cgrp_deg, (void*)h->d_cgrp_cdeg,
                     (void*)h->d_cp, (void*)h->d_ce, (void*)h->d_erow, (void*)h->d_lvl_ptr, (void*)h->d_lvl_bits})
         if (p) (void)hipFree(p);
     for (CallRecord* rs : {h->rec, h->lane_rec})
@@ -2106,41 +2111,30 @@ int bposd_debug_local_layout(const int32_t* indptr, const int32_t* indices, int3
 }
 
 int bposd_debug_class_layout(const int32_t* indptr, const int32_t* indices, int32_t m, int32_t n, int32_t* pos_chk, int32_t* pos_bit,
-                             int32_t* bit_slot, int32_t* grp_deg, int64_t* info) {
+                             int32_t* bit_slot, int32_t* grp_deg, int32_t* grp_cdeg, int64_t* info) {
     // host-only: the tables bp_class_kernel would be launched with for this pcm (tests check their invariants without a GPU).
-    // info[0..9]: DC, DVLO, DVHI, VPT, MP (= NTMAX), threads per workgroup, modelled read cycles, their floor, modelled write cycles, their floor
+    // info[0..10]: DC, DVLO, DVHI, VPT, MP (= NTMAX), threads per workgroup, modelled read cycles, their floor, modelled write cycles, their
+    // floor, DCLO
     if (!indptr || !indices || !info || m < 1 || n < 1) return BPOSD_ERR_INVALID;
     std::vector<int> rp(indptr, indptr + m + 1), ci(indices, indices + indptr[m]);
-    int dc = -1;
-    for (int c = 0; c < m; ++c) {
-        const int d = rp[c + 1] - rp[c];
-        if (dc < 0) dc = d;
-        else if (d != dc) return BPOSD_ERR_UNSUPPORTED;
-    }
-    std::vector<int> vdeg(n, 0);
-    for (int e : ci) {
+    for (int e : ci)
         if (e < 0 || e >= n) return BPOSD_ERR_INVALID;
-        vdeg[e]++;
-    }
-    int lo = 1 << 30, hi = 0;
-    for (int d : vdeg) { lo = std::min(lo, d); hi = std::max(hi, d); }
-    const ClassShape* shp = nullptr;
-    for (const auto& k : kClassShapes)
-        if (k.dc == dc && k.dvlo <= lo && hi <= k.dvhi) { shp = &k; break; }
+    const ClassShape* shp = class_shape_for(rp, ci, m, n);
     if (!shp || m > 1024) return BPOSD_ERR_UNSUPPORTED;
     class_layout::Tables T;
     bool ok = false;
     for (int mp : {256, 512, 1024}) {
         if (m > mp) continue;
-        if (class_layout::build(rp, ci, m, n, shp->dc, shp->dvlo, shp->dvhi, kClassVPT, mp, mp, 50000, T)) { ok = true; break; }
+        if (class_layout::build(rp, ci, m, n, shp->dclo, shp->dc, shp->dvlo, shp->dvhi, kClassVPT, mp, mp, 50000, T)) { ok = true; break; }
     }
     if (!ok) return BPOSD_ERR_UNSUPPORTED;
     info[0] = shp->dc; info[1] = shp->dvlo; info[2] = shp->dvhi; info[3] = kClassVPT; info[4] = T.MP; info[5] = T.NT;
-    info[6] = T.read_cycles; info[7] = T.read_floor; info[8] = T.write_cycles; info[9] = T.write_floor;
+    info[6] = T.read_cycles; info[7] = T.read_floor; info[8] = T.write_cycles; info[9] = T.write_floor; info[10] = shp->dclo;
     if (pos_chk) std::copy(T.pos_chk.begin(), T.pos_chk.end(), pos_chk);    // [MP]
     if (pos_bit) std::copy(T.pos_bit.begin(), T.pos_bit.end(), pos_bit);    // [VPT * MP]
     if (bit_slot) std::copy(T.bit_slot.begin(), T.bit_slot.end(), bit_slot);  // [DVHI * VPT * MP]
     if (grp_deg) std::copy(T.grp_deg.begin(), T.grp_deg.end(), grp_deg);    // [VPT * MP / 64]
+    if (grp_cdeg) std::copy(T.grp_cdeg.begin(), T.grp_cdeg.end(), grp_cdeg);  // [MP / 64]
     return BPOSD_OK;
 }
 

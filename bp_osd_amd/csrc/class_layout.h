@@ -19,14 +19,16 @@ struct Tables {
     std::vector<int> pos_bit;    // [VPT * NTMAX]
     std::vector<int> bit_slot;   // [DVHI * VPT * NTMAX]
     std::vector<int> grp_deg;    // [VPT * NTMAX / 64]
+    std::vector<int> grp_cdeg;   // [NTMAX / 64]  check degree of a wave's positions, 0 = the wave holds no checks
     long read_cycles = 0, write_cycles = 0;  // modelled LDS cycles of one bit pass
     long read_floor = 0, write_floor = 0;
 };
 
-// rp / ci: CSR of the pcm (every row has DC entries); DVLO .. DVHI: bit degrees the kernel instance handles.
-// Returns false when the code does not fit (a bit degree outside the range, too many groups for VPT slots of NTMAX threads).
-inline bool build(const std::vector<int>& rp, const std::vector<int>& ci, int m, int n, int DC, int DVLO, int DVHI, int VPT, int MP,
-                  int NTMAX, int iters, Tables& T) {
+// rp / ci: CSR of the pcm; DCLO .. DC: check degrees, DVLO .. DVHI: bit degrees the kernel instance handles.  Checks are
+// sorted by degree into waves (a wave's 64 positions hold checks of ONE degree), bits by degree into 64-lane groups.
+// Returns false when the code does not fit (a degree outside the ranges, too many groups for VPT slots of NTMAX threads).
+inline bool build(const std::vector<int>& rp, const std::vector<int>& ci, int m, int n, int DCLO, int DC, int DVLO, int DVHI, int VPT,
+                  int MP, int NTMAX, int iters, Tables& T) {
     if (m > MP || NTMAX % 64 != 0) return false;
     // CSC view with the LDS slot (k * MP + c) of every edge, ascending check index inside a column
     std::vector<int> cptr(n + 1, 0), fill(n, 0);
@@ -35,7 +37,7 @@ inline bool build(const std::vector<int>& rp, const std::vector<int>& ci, int m,
     for (int i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
     std::vector<int> ek(E), ec(E);  // per CSC entry: edge number k inside its check, and the check
     for (int c = 0; c < m; ++c) {
-        if (rp[c + 1] - rp[c] != DC) return false;
+        if (rp[c + 1] - rp[c] < DCLO || rp[c + 1] - rp[c] > DC) return false;
         for (int e = rp[c]; e < rp[c + 1]; ++e) {
             const int i = ci[e];
             ek[cptr[i] + fill[i]] = e - rp[c];
@@ -44,9 +46,24 @@ inline bool build(const std::vector<int>& rp, const std::vector<int>& ci, int m,
     }
     // checks may sit at any position of the waves that hold checks (the check pass is linear in the position whatever
     // the order; the syndrome bit and the mismatch bitmap go through pos_chk): LDS slot of an edge = k * MP + position
-    const int cw0 = (m + 63) / 64;
-    std::vector<int> pos_of(m), chk_at(cw0 * 64, -1);
-    for (int c = 0; c < m; ++c) { pos_of[c] = c; chk_at[c] = c; }
+    // -- inside the waves of the check's degree class (heaviest class first)
+    std::vector<int> reg_lo(DC + 2, 0), reg_hi(DC + 2, 0), wave_cdeg;
+    std::vector<int> pos_of(m);
+    {
+        int at = 0;
+        for (int d = DC; d >= DCLO; --d) {
+            reg_lo[d] = at;
+            for (int c = 0; c < m; ++c)
+                if (rp[c + 1] - rp[c] == d) pos_of[c] = at++;
+            at = (at + 63) & ~63;
+            reg_hi[d] = at;
+            for (int w = reg_lo[d] / 64; w < reg_hi[d] / 64; ++w) wave_cdeg.push_back(d);
+        }
+    }
+    const int cw0 = (int)wave_cdeg.size();
+    if (cw0 * 64 > MP) return false;
+    std::vector<int> chk_at(cw0 * 64, -1);
+    for (int c = 0; c < m; ++c) chk_at[pos_of[c]] = c;
     auto eslot_of = [&](int e) { return ek[e] * MP + pos_of[ec[e]]; };
     // degree classes -> groups of 64 lanes
     std::vector<std::vector<int>> cls(DVHI + 1);
@@ -63,14 +80,14 @@ inline bool build(const std::vector<int>& rp, const std::vector<int>& ci, int m,
             for (size_t l = 0; l < 64 && q + l < cls[d].size(); ++l) g.bits[l] = cls[d][q + l];
             groups.push_back(g);
         }
-    const int cw = (m + 63) / 64;  // waves that hold checks
+    const int cw = cw0;  // waves that hold checks
     int nw = std::max(cw, ((int)groups.size() + VPT - 1) / VPT);
     if (nw * 64 > NTMAX) return false;
     // deal the groups to waves: heaviest first, to the wave with the least work that still has a free slot
     // (work in LDS cycles: a check wave 8 * DC, a bit group 8 * degree)
     std::vector<long> load(nw, 0);
     std::vector<int> used(nw, 0);
-    for (int w = 0; w < cw; ++w) load[w] = 8L * DC;
+    for (int w = 0; w < cw; ++w) load[w] = 8L * wave_cdeg[w];
     std::vector<int> g_wave(groups.size()), g_slot(groups.size());
     for (size_t q = 0; q < groups.size(); ++q) {
         int best = -1;
@@ -140,7 +157,8 @@ inline bool build(const std::vector<int>& rp, const std::vector<int>& ci, int m,
     double temp = T0;
     for (int it = 0; it < iters && !groups.empty(); ++it, temp *= cool) {
         if (rnd(3) == 0) {  // swap the positions of two checks (or move one to an empty position)
-            const int p1 = pos_of[rnd(m)], p2 = rnd(cw0 * 64);
+            const int p1 = pos_of[rnd(m)];
+            const int dcl = wave_cdeg[p1 >> 6], p2 = reg_lo[dcl] + rnd(reg_hi[dcl] - reg_lo[dcl]);  // stays in its degree class
             if (p1 == p2) continue;
             const int c1 = chk_at[p1], c2 = chk_at[p2];
             touched.clear();
@@ -197,6 +215,8 @@ inline bool build(const std::vector<int>& rp, const std::vector<int>& ci, int m,
     T.pos_bit.assign((size_t)VPT * NTMAX, -1);
     T.bit_slot.assign((size_t)DVHI * VPT * NTMAX, 0);
     T.grp_deg.assign((size_t)VPT * NW, 0);
+    T.grp_cdeg.assign((size_t)NW, 0);
+    for (int w = 0; w < cw; ++w) T.grp_cdeg[w] = wave_cdeg[w];
     for (int r = 0; r < VPT; ++r)
         for (int t = 0; t < NTMAX; ++t)
             for (int d = 0; d < DVHI; ++d) T.bit_slot[((size_t)d * VPT + r) * NTMAX + t] = DC * MP + t;  // the thread's dummy slot

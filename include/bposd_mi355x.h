@@ -231,13 +231,14 @@ int bposd_bp_kernel_info(bposd_handle *h, int32_t *kernel, int64_t *lds_model);
  * ds_write_b64 cycles of one bit pass, their floor. */
 int bposd_debug_local_layout(const int32_t *csr_indptr, const int32_t *csr_indices, int32_t m, int32_t n, int64_t *out);
 
-/* Diagnostics, host only: the tables bp_class_kernel would run with for a pcm whose checks all have one degree (7 with bit
- * degrees 3..4, or 6 with 3; BPOSD_ERR_UNSUPPORTED otherwise).  info[10]: check degree, lowest / highest bit degree, bit
- * slots per thread, LDS stride MP, threads per workgroup, modelled read cycles of one bit pass and their floor, modelled
- * write cycles and their floor.  Nullable outputs: pos_chk [MP], pos_bit [slots * MP], bit_slot [DVHI * slots * MP],
- * grp_deg [slots * MP / 64] -- callers size them for MP = 1024, 2 slots, DVHI = 4. */
+/* Diagnostics, host only: the tables bp_class_kernel would run with for a pcm whose check and bit degrees fall inside one
+ * compiled instance -- (check degrees; bit degrees) = (7; 3..4), (6; 3), (4; 2), (8; 4), (3..4; 1..2) -- and
+ * BPOSD_ERR_UNSUPPORTED otherwise.  info[11]: highest check degree, lowest / highest bit degree, bit slots per thread, LDS
+ * stride MP, threads per workgroup, modelled read cycles of one bit pass and their floor, modelled write cycles and their
+ * floor, lowest check degree.  Nullable outputs: pos_chk [MP], pos_bit [slots * MP], bit_slot [DVHI * slots * MP],
+ * grp_deg [slots * MP / 64], grp_cdeg [MP / 64] -- callers size them for MP = 1024, 2 slots, DVHI = 4. */
 int bposd_debug_class_layout(const int32_t *csr_indptr, const int32_t *csr_indices, int32_t m, int32_t n, int32_t *pos_chk,
-                             int32_t *pos_bit, int32_t *bit_slot, int32_t *grp_deg, int64_t *info);
+                             int32_t *pos_bit, int32_t *bit_slot, int32_t *grp_deg, int32_t *grp_cdeg, int64_t *info);
 
 /* Tuning knob (not part of the reference surface): which BP kernel / workgroup shape runs.
  * 0 = auto; 1, 2, 4 = LDS kernel with 1 / 2 / 4 checks per thread; 16, 17, 18 = local-edge kernel (a third of the

@@ -825,17 +825,19 @@ def test_class_kernel_equals_lds_kernel_and_oracle(gpu_ready, seed_file):
     assert (a.batch_iter == b.batch_iter).all() and (a.batch_osd0 == b.batch_osd0).all()
 
 
-@pytest.mark.parametrize("family", ["toric", "reg44"])
+@pytest.mark.parametrize("family", ["toric", "reg44", "surface", "surface_x"])
 def test_class_kernel_other_degree_families(gpu_ready, family):
-    """bp_class_kernel's other instances: (check degree 4; bit degree 2) -- a toric code, hgp(ring_code(12)) -- and (8; 4) --
-    the product of a (4,4)-regular seed: auto-selected, equal to the generic LDS kernel and to the oracle (min-sum and
-    product-sum with clip, LLR bits)."""
+    """bp_class_kernel's other instances: (check degree 4; bit degree 2) -- a toric code, hgp(ring_code(12)) --, (8; 4) --
+    the product of a (4,4)-regular seed -- and (check degrees 3..4; bit degrees 1..2) -- the distance-13 surface code,
+    hgp(rep_code(13)), both stabiliser types: auto-selected, equal to the generic LDS kernel and to the oracle (min-sum
+    and product-sum with clip, LLR bits)."""
     from bp_osd_amd import BpOsdDecoder
-    from bp_osd_amd.codes import hgp, regular_ldpc_seed, ring_code
+    from bp_osd_amd.codes import hgp, regular_ldpc_seed, rep_code, ring_code
     from oracle import OracleDecoder
 
-    seed = ring_code(12) if family == "toric" else regular_ldpc_seed(12, 12, 4, 4, seed=3)
-    H = hgp(seed, compute_logicals=False).hx
+    seed = {"toric": lambda: ring_code(12), "reg44": lambda: regular_ldpc_seed(12, 12, 4, 4, seed=3)}.get(family, lambda: rep_code(13))()
+    code = hgp(seed, compute_logicals=False)
+    H = code.hz if family == "surface" else code.hx
     n = H.shape[1]
     q = 0.06
     _, syn = _syndromes(H, q, 300, n)

@@ -128,17 +128,21 @@ def _csr32(H):
     return np.ascontiguousarray(H.indptr, dtype=np.int32), np.ascontiguousarray(H.indices, dtype=np.int32), H
 
 
-@pytest.mark.parametrize("seed_file", ["mkmn_16_4_6.txt", "mkmn_20_5_8.txt", "mkmn_24_6_10.txt"])
+@pytest.mark.parametrize("seed_file", ["mkmn_16_4_6.txt", "mkmn_20_5_8.txt", "mkmn_24_6_10.txt", "surface:9", "surface:17"])
 def test_class_kernel_tables_are_consistent(lib, seed_file):
     """Host-side tables of bp_class_kernel (no GPU needed): every check sits at exactly one position of the check waves,
     every bit in exactly one (thread, slot), every edge has its own LDS slot k * MP + position of its check with k its
-    rank inside the check, padding lanes point at their thread's dummy slot, a group's degree is its bits' degree, and
-    the bank model of the chosen layout is not worse than twice its floor."""
+    rank inside the check, padding lanes point at their thread's dummy slot, a group's degree is its bits' degree, a
+    wave's checks all have the wave's degree (surface codes: degrees 3 and 4), and the bank model of the chosen layout
+    is not worse than twice its floor."""
     import os
 
-    from bp_osd_amd.codes import hgp
+    from bp_osd_amd.codes import hgp, rep_code
 
-    seed = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", seed_file)).astype(np.uint8)
+    if seed_file.startswith("surface:"):
+        seed = rep_code(int(seed_file.split(":")[1]))
+    else:
+        seed = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", seed_file)).astype(np.uint8)
     ip, ix, H = _csr32(hgp(seed, compute_logicals=False).hz)
     m, n = H.shape
     MPmax, VPT, DVHI = 1024, 2, 4
@@ -146,14 +150,23 @@ def test_class_kernel_tables_are_consistent(lib, seed_file):
     pos_bit = np.full(VPT * MPmax, -7, np.int32)
     bit_slot = np.full(DVHI * VPT * MPmax, -7, np.int32)
     grp_deg = np.full(VPT * MPmax // 64, -7, np.int32)
-    info = np.zeros(10, np.int64)
+    grp_cdeg = np.full(MPmax // 64, -7, np.int32)
+    info = np.zeros(11, np.int64)
     rc = lib.bposd_debug_class_layout(ip.ctypes.data, ix.ctypes.data, m, n, pos_chk.ctypes.data, pos_bit.ctypes.data,
-                                      bit_slot.ctypes.data, grp_deg.ctypes.data, info.ctypes.data)
+                                      bit_slot.ctypes.data, grp_deg.ctypes.data, grp_cdeg.ctypes.data, info.ctypes.data)
     assert rc == 0
     DC, DVLO, DVHI_, VPT_, MP, NT = (int(x) for x in info[:6])
-    assert (DC, DVLO, DVHI_, VPT_) == (7, 3, 4, 2) and MP >= m and NT % 64 == 0 and NT <= MP
+    DCLO = int(info[10])
+    want = (3, 4, 1, 2, 2) if seed_file.startswith("surface:") else (7, 7, 3, 4, 2)
+    assert (DCLO, DC, DVLO, DVHI_, VPT_) == want and MP >= m and NT % 64 == 0 and NT <= MP
     pc = pos_chk[:MP]
-    assert sorted(pc[pc >= 0].tolist()) == list(range(m)) and (pc[((m + 63) // 64) * 64:] < 0).all()
+    assert sorted(pc[pc >= 0].tolist()) == list(range(m))
+    cd = grp_cdeg[:MP // 64]
+    row_deg = np.diff(H.indptr)
+    for w in range(MP // 64):  # a wave's checks all have the wave's degree; waves without checks say 0
+        here = pc[w * 64:(w + 1) * 64]
+        assert (cd[w] == 0 and (here < 0).all()) or (cd[w] > 0 and (here >= 0).any() and (row_deg[here[here >= 0]] == cd[w]).all())
+    assert (cd[NT // 64:] == 0).all()
     pos_of = np.empty(m, int)
     pos_of[pc[pc >= 0]] = np.flatnonzero(pc >= 0)
     pb = pos_bit[:VPT * MP].reshape(VPT, MP)

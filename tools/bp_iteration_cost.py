@@ -10,6 +10,15 @@ variants = [int(v) for v in sys.argv[1:]] or [0]
 method = os.environ.get("BP_METHOD", "ms")
 codes = [(os.path.basename(f), hgp(np.loadtxt(f, dtype=int).astype(np.uint8), compute_logicals=False).hz) for f in sorted(glob.glob("tests/golden/mkmn_*.txt"))]
 codes.append(("h1922", h1922(compute_logicals=False).hz))
+# EXTRA_CODES=surface:15,toric:12 adds hypergraph products of the distance-d repetition / ring code
+if os.environ.get("EXTRA_CODES"):
+    from bp_osd_amd.codes import rep_code, ring_code
+    extra = []
+    for spec in os.environ["EXTRA_CODES"].split(","):
+        kind, d = spec.split(":")
+        seed = rep_code(int(d)) if kind == "surface" else ring_code(int(d))
+        extra.append((spec, hgp(seed, compute_logicals=False).hz))
+    codes = extra if os.environ.get("ONLY_EXTRA") else codes + extra
 for name, H in codes:
     m, n = H.shape; q = 0.25; B = 65536
     rng = np.random.default_rng(0)

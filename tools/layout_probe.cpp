@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
         const int DC = atoi(argv[3]), DVLO = atoi(argv[4]), DVHI = atoi(argv[5]), MP = atoi(argv[6]);
         const int iters = argc > 7 ? atoi(argv[7]) : 200000;
         class_layout::Tables T;
-        if (!class_layout::build(rp, ci, m, n, DC, DVLO, DVHI, 2, MP, MP, iters, T)) { printf("no class layout\n"); return 1; }
+        if (!class_layout::build(rp, ci, m, n, getenv("DCLO") ? atoi(getenv("DCLO")) : DC, DC, DVLO, DVHI, 2, MP, MP, iters, T)) { printf("no class layout\n"); return 1; }
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("class layout: %.2f s, %d threads, read cycles %ld (floor %ld), write cycles %ld (floor %ld); group degrees:", sec, T.NT,
                T.read_cycles, T.read_floor, T.write_cycles, T.write_floor);
