@@ -62,6 +62,10 @@ struct BpClassParams {
     int* __restrict__ counters;
     unsigned long long* __restrict__ iter_total;
     int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
+    int queue_batch, queue_shift; // a workgroup takes  clamp((syndromes left) >> queue_shift, 1, queue_batch)  syndromes from the queue per
+                                  // atomic -- big batches first, single syndromes at the end (2^queue_shift ~ 2 x the grid).  With codes
+                                  // of a few hundred bits the chip retires a syndrome every ~25 ns, which is what one same-address
+                                  // atomic per syndrome costs.
 };
 
 __host__ __device__ inline size_t bp_class_lds_bytes(int DC, int mp, int ntmax) {
@@ -251,26 +255,32 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
     for (int j = 0; j < CPT; ++j) cdeg[j] = __builtin_amdgcn_readfirstlane(bpc_args()->grp_cdeg[j * NW + wave]);
     const int want_llr_s = __builtin_amdgcn_readfirstlane(bpc_args()->out_llr != nullptr ? 1 : 0);
     auto want_llr = [&]() -> bool {
-        int w = want_llr_s;
+        int w = __builtin_amdgcn_readfirstlane(want_llr_s);
         asm volatile("" : "+s"(w));
         return w != 0;
     };
 
+    unsigned long long it_acc = 0ull;  // iterations this workgroup ran (uniform), added to iter_total once at the end
+    long long s_seen = 0;  // queue position at my previous fetch (uniform): estimates what is left
+    if (tid == 0) {
+        sh[0] = 0;
+        sh[1] = 0;
+    }
     for (;;) {
-        if (tid == 0) {
-            int zero = 0;
-            asm volatile("" : "+v"(zero));
-            sh[0] = zero;
-            sh[1] = zero;
-            sh[2] = atomicAdd(&bpc_args()->counters[0], 1);
-        }
+        int qb = (int)((P.B - s_seen) >> bpc_args()->queue_shift);
+        qb = qb < 1 ? 1 : (qb > bpc_args()->queue_batch ? bpc_args()->queue_batch : qb);
+        qb = __builtin_amdgcn_readfirstlane(qb);
+        if (tid == 0) sh[2] = atomicAdd(&bpc_args()->counters[0], qb);
         __syncthreads();
-        const long long s = __builtin_amdgcn_readfirstlane(sh[2]);
-        if (s >= P.B) {
-            // the chunk loop of the host-pointer API launches the next chunk's kernels when this one's tail begins
-            if (s == P.B && tid == 0 && bpc_args()->tail_flag) *(volatile int*)bpc_args()->tail_flag = 1;
-            break;
-        }
+        const long long s0 = __builtin_amdgcn_readfirstlane(sh[2]);
+        // the chunk loop of the host-pointer API launches the next chunk's kernels when this one's tail begins: the flag
+        // is set by whoever takes the last syndrome or first finds the queue empty (setting it twice is harmless)
+        if (s0 <= P.B && s0 + qb >= P.B && tid == 0 && bpc_args()->tail_flag) *(volatile int*)bpc_args()->tail_flag = 1;
+        if (s0 >= P.B) break;
+        s_seen = s0;
+        const long long s1 = (s0 + qb < P.B) ? s0 + qb : P.B;
+#pragma clang loop unroll(disable)
+        for (long long s = s0; s < s1; ++s) {
 
         // ---- syndrome bits of my checks; the mismatch bitmap (indexed by check) starts as the syndrome
         bool sbit[CPT];
@@ -382,8 +392,12 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
             }
             if (bpc_args()->out_conv) bpc_args()->out_conv[s] = conv ? 1 : 0;
             if (bpc_args()->out_iters) bpc_args()->out_iters[s] = it_done;
-            if (it_done) atomicAdd(bpc_args()->iter_total, (unsigned long long)it_done);
+            int zero = 0;  // the two convergence flags start the next syndrome at 0 (nobody reads them any more)
+            asm volatile("" : "+v"(zero));
+            sh[0] = zero;
+            sh[1] = zero;
         }
+        it_acc += (unsigned long long)it_done;
         __syncthreads();
         const int slot = to_osd ? sh[3] : 0;
 #pragma unroll
@@ -403,7 +417,9 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
             }
         }
         __syncthreads();
+        }  // syndromes of this batch
     }
+    if (tid == 0 && it_acc) atomicAdd(bpc_args()->iter_total, it_acc);
 #undef BPC_AT
 #undef BPC_BIT
 #undef BPC_L0

@@ -782,6 +782,13 @@ int launch_bp_class_t(bposd_handle* h, const BpClassParams& C) {
     if (rc) return rc;
     BpClassParams Cq = C;
     Cq.llr_tmp = (double*)h->cur->bpl_llr.p;
+    // syndromes per queue atomic: (what is left) / (2 x grid), at most eight, one at the end (guided self-scheduling)
+    // -- for codes of up to 160 checks only, where the queue atomic is the bound (surface code d = 5: 0.93 -> 0.61 ms per
+    // 65536 syndromes); larger codes lose 4-6 % to the coarser tail (tools/bp_iteration_cost.py, A/B in one run)
+    Cq.queue_batch = h->m <= 160 ? 8 : 1;
+    Cq.queue_shift = 1;
+    while ((1ll << Cq.queue_shift) < grid * 2) Cq.queue_shift++;
+    if (const char* e = getenv("BPOSD_CLASS_QUEUE_BATCH")) Cq.queue_batch = std::max(1, std::min(64, atoi(e)));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->cur->stream, Cq);
     HIP_TRY(h, hipGetLastError());
     return 0;

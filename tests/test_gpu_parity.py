@@ -855,6 +855,26 @@ def test_class_kernel_other_degree_families(gpu_ready, family):
         _compare_exact(ra, OracleDecoder(H, **kw).decode_batch(syn))
 
 
+def test_small_surface_code_large_batch_queue_batches(gpu_ready):
+    """A distance-7 surface code (42 checks) with 60000 syndromes: bp_class_kernel takes several syndromes from the queue
+    per atomic here (guided batch sizes, 8 down to 1) -- every output equal to the oracle, the iteration total too; the
+    host-pointer path with its tail-gated chunks on the same batch."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp, rep_code
+    from oracle import OracleDecoder
+
+    H = hgp(rep_code(7), compute_logicals=False).hz
+    q = 0.08
+    _, syn = _syndromes(H, q, 60000, 77)
+    kw = dict(error_rate=q, max_iter=30, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=5)
+    dec = BpOsdDecoder(H, **kw)
+    got = _gpu_decode(dec, syn)
+    assert dec.bp_kernel_info()["kernel"] == "bp_class_kernel"
+    ref = OracleDecoder(H, **kw).decode_batch(syn)
+    _compare_exact(got, ref)
+    assert dec.last_timing()["bp_iterations"] == int(ref["iters"].sum())
+
+
 @pytest.mark.parametrize("seed_file", ["mkmn_16_4_6.txt", "mkmn_20_5_8.txt", "mkmn_24_6_10.txt", None])
 def test_osd_wave_kernel_equals_workgroup_kernel_and_oracle(gpu_ready, surface13, seed_file):
     """osd_wave_kernel (one wave per elimination: the reference's three example codes and the [[13,1,3]] surface code) against
