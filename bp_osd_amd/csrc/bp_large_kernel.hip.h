@@ -75,6 +75,10 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
     double* msg = P.msg_ws + (size_t)blockIdx.x * DC * MP;
     double* llrt = P.llr_tmp + (size_t)blockIdx.x * n;
 
+#ifdef BPOSD_BPLARGE_DIAG  // phase clocks of the first workgroups, printed at exit (tools/bp_large_probe.py with a -D build)
+    unsigned long long dg_chk = 0, dg_bit = 0, dg_all = __builtin_readcyclecounter(), dg_t = 0;
+    int dg_its = 0;
+#endif
     for (;;) {
         if (tid == 0) {
             sh[0] = 0;
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                     break;
                 }
                 // ---------------- check pass
+#ifdef BPOSD_BPLARGE_DIAG
+                dg_t = __builtin_readcyclecounter();
+#endif
                 const double alpha = alpha_for_iteration(P.ms_scaling, it);
 #pragma clang loop unroll(disable)
                 for (int c = tid; c < m; c += NT) {
@@ -196,6 +203,11 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                     }
                 }
                 __syncthreads();
+#ifdef BPOSD_BPLARGE_DIAG
+                dg_chk += __builtin_readcyclecounter() - dg_t;
+                dg_t = __builtin_readcyclecounter();
+                ++dg_its;
+#endif
                 if (sh[fi] == 0) {
                     conv = true;
                     it_done = it - 1;
@@ -246,6 +258,9 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                     }
                 }
                 __syncthreads();
+#ifdef BPOSD_BPLARGE_DIAG
+                dg_bit += __builtin_readcyclecounter() - dg_t;
+#endif
             }
         }
 
@@ -276,6 +291,11 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
         }
         __syncthreads();
     }
+#ifdef BPOSD_BPLARGE_DIAG
+    if (tid == 0 && (blockIdx.x & 63) == 0)
+        printf("bp_large wg %d: %d check passes, check pass %.1f Mclk, bit pass %.1f Mclk, all %.1f Mclk\n", (int)blockIdx.x, dg_its, dg_chk * 1e-6,
+               dg_bit * 1e-6, (__builtin_readcyclecounter() - dg_all) * 1e-6);
+#endif
 }
 
 }  // namespace bposd

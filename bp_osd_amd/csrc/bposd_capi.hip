@@ -902,6 +902,7 @@ int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
         int rc_occ = cached_occupancy(h, kq, 512, lds, &wg_per_cu); if (rc_occ) return rc_occ;
     }
     wg_per_cu = std::max(1, std::min(wg_per_cu, 4));
+    if (const char* e = getenv("BPOSD_LARGE_WG_CAP")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));
     const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
     int rc;
     if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * DC * P.mp))) return rc;
