@@ -144,6 +144,18 @@ typedef const volatile __attribute__((address_space(3))) unsigned long long* osd
 typedef const unsigned long long* osdl_lds_ptr;
 #endif
 #define OSDL_AT(type, base, byteoff) (*(type*)((char*)(base) + (size_t)(unsigned int)(byteoff)))
+// matrix words of the apply pass: streamed once per pass (60 MB per workgroup, no reuse any cache could catch) -- non-temporal,
+// so that what IS re-read (the rows' combination masks, once per 8-word chunk) stays in the L2 / Infinity Cache
+#ifndef OSDL_NT_ROWS
+#define OSDL_NT_ROWS 0  // measured (tools/ab_libs_l29k.sh): 179.8 vs 180.5 ms per 252 eliminations -- no effect, off
+#endif
+#if OSDL_NT_ROWS
+#define OSDL_ROW_LD(base, byteoff) __builtin_nontemporal_load((const unsigned long long*)((const char*)(base) + (size_t)(unsigned int)(byteoff)))
+#define OSDL_ROW_ST(base, byteoff, val) __builtin_nontemporal_store((unsigned long long)(val), (unsigned long long*)((char*)(base) + (size_t)(unsigned int)(byteoff)))
+#else
+#define OSDL_ROW_LD(base, byteoff) OSDL_AT(unsigned long long, base, byteoff)
+#define OSDL_ROW_ST(base, byteoff, val) (OSDL_AT(unsigned long long, base, byteoff) = (val))
+#endif
 
 // ---- E2c: the panel phase on a compacted list (Gaussian mode: every unfrozen row with a non-zero panel word; Gauss-Jordan:
 // the unused ones, see the Jordan fix-up at the call site).  A row whose panel word is zero after E1 stays zero for
@@ -648,7 +660,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     const unsigned int ro = osdl_opaque((unsigned int)rown * 8u);
 #pragma unroll
                     for (int xx = 0; xx < OSDL_CW; ++xx)
-                        vn[xx] = (xx < cw) ? OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) : 0ull;
+                        vn[xx] = (xx < cw) ? OSDL_ROW_LD(M + (size_t)(x0 + xx) * MRL, ro) : 0ull;
 #pragma unroll
                     for (int g = 0; g < OSDL_K; ++g)
                         mkn[g] = (g < ng) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro) : 0ull;
@@ -669,7 +681,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         const unsigned int rn = osdl_opaque((unsigned int)rown * 8u);
 #pragma unroll
                         for (int xx = 0; xx < OSDL_CW; ++xx)
-                            vn[xx] = (xx < cw) ? OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, rn) : 0ull;
+                            vn[xx] = (xx < cw) ? OSDL_ROW_LD(M + (size_t)(x0 + xx) * MRL, rn) : 0ull;
 #pragma unroll
                         for (int g = 0; g < OSDL_K; ++g)
                             mkn[g] = (g < ng) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, rn) : 0ull;
@@ -721,7 +733,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     }
 #pragma unroll
                     for (int xx = 0; xx < OSDL_CW; ++xx)
-                        if (xx < cw && live) OSDL_AT(unsigned long long, M + (size_t)(x0 + xx) * MRL, ro) = v[xx];
+                        if (xx < cw && live) OSDL_ROW_ST(M + (size_t)(x0 + xx) * MRL, ro, v[xx]);
                 }
             }
             __syncthreads();

@@ -1527,3 +1527,40 @@ def test_large_osd_panel_forms_vs_oracle(gpu_ready, hgp4050, q, max_iter, osd, t
     r = _gpu_decode(g, syn, want_llr=False)
     assert (~r["converged"]).sum() >= 32
     _compare_exact(r, OracleDecoder(H, **kw).decode_batch(syn))
+
+
+def test_create_destroy_cycles_release_device_memory(gpu_ready, h1922, hgp400, hgp4050):
+    """Decoders are created per run by the reference's harness (css_decode_sim.py:192-205): twelve create -> decode ->
+    destroy cycles over the three code regimes (local-edge + workgroup OSD, class + wave OSD, HBM path with its
+    per-lane workspaces) leave the device's free memory where it was (within 64 MB), and a decoder made afterwards
+    still decodes like the first one."""
+    import gc
+
+    import torch
+
+    from bp_osd_amd import BpOsdDecoder
+
+    cases = [(h1922.hz, dict(error_rate=0.05, max_iter=30, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=7), 0.07, 512),
+             (hgp400.hz, dict(error_rate=0.05, max_iter=20, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=10), 0.08, 8192),
+             (hgp4050.hz, dict(error_rate=0.05, max_iter=8, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=6), 0.06, 48)]
+    syn = [_syndromes(H, q, B, 5)[1] for H, _, q, B in cases]
+
+    def cycle(k):
+        H, kw, _, _ = cases[k]
+        dec = BpOsdDecoder(H, **kw)
+        out = dec.decode_batch(syn[k], want_osd0=True).copy()
+        del dec
+        gc.collect()
+        return out
+
+    first = [cycle(k) for k in range(3)]  # warm: code objects loaded, allocator pools settled
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for rep in range(4):
+        for k in range(3):
+            cycle(k)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 * 2**20, f"device memory not returned: {(free0 - free1) / 2**20:.0f} MB after 12 cycles"
+    for k in range(3):
+        assert (cycle(k) == first[k]).all()
