@@ -162,12 +162,15 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
                 if (!found) continue;
                 if (lane == 0) pivrow[64 * w + b] = (short)(64 * pslot + psrc);
                 ++nrank;
+                // under the execution mask of the rows that have the column set: one v_xor with the (scalar) pivot word per
+                // register, against a select + xor per register in the branch-free form (half the vector instructions)
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
                     const bool hit = (row[q][w] & mask) != 0ull && !(q == pslot && lane == psrc);
-                    const unsigned long long sel = hit ? ~0ull : 0ull;
+                    if (hit) {
 #pragma unroll
-                    for (int x = 0; x < W; ++x) row[q][x] ^= piv[x] & sel;
+                        for (int x = 0; x < W; ++x) row[q][x] ^= piv[x];
+                    }
                 }
             }
         }
