@@ -26,6 +26,9 @@
 
 #include "bp_kernel.hip.h"
 
+#ifndef BPOSD_BPL_SIGN_ON_MAG
+#define BPOSD_BPL_SIGN_ON_MAG 0
+#endif
 namespace bposd {
 
 struct BpLocalParams {
@@ -311,6 +314,28 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                     // signs: a message counts as negative when b2c <= 0 (a zero too, as in the reference); the outgoing
                     // message is mag * ((-1)^(syndrome + #negatives + own) * alpha).  The sign rides on the multiplier:
                     // one select of alpha's high word per edge (mag * (-alpha) == -(mag * alpha) bit for bit).
+#if BPOSD_BPL_SIGN_ON_MAG
+                    // the sign as a lane mask in scalar registers; it lands on the magnitude's high word through one select
+                    // with a negated source (an instruction the compiler does not form from C), alpha is a scalar operand
+                    unsigned long long negm[6];
+                    unsigned long long parm = __ballot(sbit[j]);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        negm[k] = __ballot(v[k] <= 0.0);
+                        parm ^= negm[k];
+                    }
+                    const double alpha_d = __hiloint2double(alpha_hi, alpha_lo);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const double mag = (k == 0) ? suf[0] : (k == 5 ? pre[5] : min_pos(pre[k], suf[k]));
+                        const unsigned long long selm = parm ^ negm[k];
+                        int mh = __double2hiint(mag);
+                        asm("v_cndmask_b32_e64 %0, %1, -%1, %2" : "=v"(mh) : "v"(mh), "s"(selm));
+                        const double o = __hiloint2double(mh, __double2loint(mag)) * alpha_d;
+                        if (k < 4) mc[k * MP] = o;
+                        else loc[2 * j + (k - 4)] = o;
+                    }
+#else
                     bool neg[6];
                     bool par = sbit[j];
 #pragma unroll
@@ -326,6 +351,7 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
                         if (k < 4) mc[k * MP] = o;
                         else loc[2 * j + (k - 4)] = o;
                     }
+#endif
                 }
                 __syncthreads();
                 if (sh[fi] == 0) {
