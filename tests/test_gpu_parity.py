@@ -1564,3 +1564,53 @@ def test_create_destroy_cycles_release_device_memory(gpu_ready, h1922, hgp400, h
     assert free0 - free1 < 64 * 2**20, f"device memory not returned: {(free0 - free1) / 2**20:.0f} MB after 12 cycles"
     for k in range(3):
         assert (cycle(k) == first[k]).all()
+
+
+def test_degree_class_codes_randomized_settings_vs_oracle(gpu_ready):
+    """The code families bp_class_kernel / osd_wave_kernel serve (surface, toric, products of (3,4)-, (3,6)- and
+    (4,4)-regular seeds of random size) x random decoder settings (method, scaling, iteration cap, OSD method / order,
+    tie policy, OSD-E bit order, uniform / per-bit / per-shot channel): every integer output and the LLR bits equal the
+    oracle's; the kernels that ran are the ones the families are built for."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp, regular_ldpc_seed, rep_code, ring_code
+    from oracle import OracleDecoder
+
+    rng = np.random.default_rng(31337)
+    families = [lambda: rep_code(int(rng.integers(3, 12))), lambda: ring_code(int(rng.integers(4, 11))),
+                lambda: regular_ldpc_seed(3 * (k := int(rng.integers(2, 5))), 4 * k, 3, 4, seed=int(rng.integers(1, 99))),
+                lambda: regular_ldpc_seed(2 * (k := int(rng.integers(3, 7))), 4 * k, 3, 6, seed=int(rng.integers(1, 99))),
+                lambda: regular_ldpc_seed(k := int(rng.integers(5, 10)), k, 4, 4, seed=int(rng.integers(1, 99)))]
+    seen_class = seen_wave = 0
+    for trial in range(40):
+        code = hgp(families[trial % 5](), compute_logicals=False)
+        H = code.hz if rng.random() < 0.5 else code.hx
+        m, n = H.shape
+        q = float(rng.choice([0.04, 0.08, 0.12]))
+        bp = "ms" if trial % 4 else "ps"
+        osd = [("osd0", 0), ("osd_cs", int(rng.integers(1, 30))), ("osd_e", int(rng.integers(1, 9)))][trial % 3]
+        osd = (osd[0], min(osd[1], n - m))  # (k' >= n - m)
+        if osd[0] != "osd0" and osd[1] == 0:
+            osd = ("osd0", 0)
+        chan = trial % 3
+        probs = rng.uniform(0.02, 0.2, size=n)
+        kw = dict(max_iter=int(rng.integers(1, 40)), bp_method=bp, ms_scaling_factor=float(rng.choice([0.0, 0.625, 0.9])),
+                  ps_clip=12.0 if bp == "ps" else 0.0, osd_method=osd[0], osd_order=osd[1], sort_tie_policy=int(rng.integers(0, 2)),
+                  osd_e_bit_order=int(rng.integers(0, 2)), **(dict(channel_probs=probs) if chan == 1 else dict(error_rate=q)))
+        _, syn = _syndromes(H, q, 120, trial)
+        g = BpOsdDecoder(H, **kw)
+        g.set_osd_variant(2 if rng.random() < 0.7 else 1)  # (auto would keep batches this small on the workgroup kernel)
+        o = OracleDecoder(H, ps_math=1, **kw)
+        if chan == 2:  # per-shot two-valued channel (the harness's channel_update)
+            sel = (rng.random((len(syn), n)) < 0.15).astype(np.uint8)
+            alt = np.full(n, 0.3)
+            got = g.decode_batch(syn, prior_select=sel, alt_channel_probs=alt, want_osd0=True, want_llr=True)
+            for b in range(0, len(syn), 4):
+                o.update_channel_probs(np.where(sel[b] != 0, alt, np.full(n, q)))
+                r = o.decode(syn[b])
+                assert (got[b] == r["osdw"]).all() and (g.batch_osd0[b] == r["osd0"]).all(), (trial, b)
+                assert (g.batch_llr[b].view(np.uint64) == r["llr"].view(np.uint64)).all(), (trial, b)
+        else:
+            _compare_exact(_gpu_decode(g, syn), o.decode_batch(syn))
+        seen_class += g.bp_kernel_info()["kernel"] in ("bp_class_kernel", "bp_local_kernel")
+        seen_wave += g.last_osd_kernel() == "osd_wave_kernel"
+    assert seen_class >= 28 and seen_wave >= 10, (seen_class, seen_wave)  # (the (3,6)-seed products have check degree 9: generic kernel)
