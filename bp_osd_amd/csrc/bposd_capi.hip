@@ -28,6 +28,7 @@
 #include "bp_large_kernel.hip.h"
 #include "bp_local_kernel.hip.h"
 #include "bp_class_kernel.hip.h"
+#include "bp_anydeg_kernel.hip.h"
 // occupancy targets of the class kernel instances (minimum waves per SIMD the register allocation must allow)
 #ifndef BPOSD_CLASS7_MINW
 #define BPOSD_CLASS7_MINW 8
@@ -134,6 +135,7 @@ struct bposd_handle {
     long long local_wcycles = 0; // modelled ds_write_b64 cycles of the bit pass (floor: 6 * 4 * MP / 64)
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
     // class BP kernel (bp_class_kernel.hip.h): every check has the same degree, bit degrees inside one compiled range
+    bool bp_any = false;  // degrees beyond the compiled kernels: bp_anydeg_kernel.hip.h (run-time degree loops, messages in HBM)
     bool class_ok = false;
     int class_dclo = 0, class_dc = 0, class_dvlo = 0, class_dvhi = 0, class_mp = 0, class_nt = 0;
     long class_read_cycles = 0, class_write_cycles = 0, class_read_floor = 0, class_write_floor = 0;  // modelled, one bit pass
@@ -994,6 +996,30 @@ int launch_bp_serial(bposd_handle* h, const BpParams& P) {
     return 0;
 }
 
+// ------------------------------------------------------------------ any-degree BP (check degree > 16 or bit degree > 8)
+int launch_bp_any(bposd_handle* h, const BpParams& P) {
+    BpAnyParams A{};
+    A.m = P.m; A.n = P.n; A.E = h->E; A.B = P.B; A.max_iter = P.max_iter; A.bp_method = h->cfg.bp_method;
+    A.ms_scaling = P.ms_scaling; A.ps_clip = P.ps_clip; A.osd_enabled = P.osd_enabled;
+    A.synd = P.synd; A.llr0 = P.llr0; A.sel = P.sel; A.llr0_alt = P.llr0_alt;
+    A.rp = h->d_rp; A.ci = h->d_ci; A.cp = h->d_cp; A.ce = h->d_ce;
+    A.out_bp = P.out_bp; A.out_osd0 = P.out_osd0; A.out_osdw = P.out_osdw; A.out_conv = P.out_conv; A.out_iters = P.out_iters;
+    A.out_llr = P.out_llr; A.llr_ws = P.llr_ws; A.osd_list = P.osd_list; A.counters = P.counters; A.iter_total = P.iter_total;
+    A.tail_flag = P.tail_flag;
+    const size_t lds = bp_anydeg_lds_bytes(h->n);
+    const int wg_per_cu = std::max<int>(1, std::min<size_t>(8, h->lds_per_cu / std::max<size_t>(lds, 1)));
+    const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
+    int rc;
+    if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * 3 * h->E))) return rc;
+    if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
+    A.msg_ws = (double*)h->cur->bpl_msg.p;
+    A.llr_tmp = (double*)h->cur->bpl_llr.p;
+    { int rc_lds = set_max_lds(h, (const void*)bp_anydeg_kernel, lds); if (rc_lds) return rc_lds; }
+    hipLaunchKernelGGL(bp_anydeg_kernel, dim3((unsigned)grid), dim3(BPA_NT), lds, h->cur->stream, A);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
 // ----------------------------------------------------------------------------- OSD launch
 template <int W>
 int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
@@ -1395,19 +1421,14 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     }
     h->regular = (dc_min == h->dc_max) && (dv_min == h->dv_max);
 
-    DegPair pair;
+    DegPair pair{16, 8};
     if (is_reg63(h)) pair = {6, 3};
-    else if (!pick_pair(h->dc_max, h->dv_max, &pair)) {
-        fail(nullptr, BPOSD_ERR_UNSUPPORTED, "check degree %d / bit degree %d exceed the built kernels (16 / 8)",
-             h->dc_max, h->dv_max);
-        bposd_destroy(h);
-        return BPOSD_ERR_UNSUPPORTED;
-    }
+    else if (!pick_pair(h->dc_max, h->dv_max, &pair)) h->bp_any = true;  // beyond the compiled degrees: run-time degree loops
     // small path: messages in LDS, OSD rows in registers.  Anything beyond goes to the HBM-resident kernels.
     // BP in LDS whenever a workgroup shape holds the messages (up to 2048 checks); OSD in registers up to m = 1024 /
     // n = 2047.  Anything beyond goes to the HBM-resident kernels, BP and OSD independently.
-    const int shp = pick_shape(h);
-    h->bp_hbm = !shp || bp_lds_bytes(pair.dc, shape_threads(h, shp) * shape_cpt(shp)) > h->lds_per_cu;
+    const int shp = h->bp_any ? 0 : pick_shape(h);
+    h->bp_hbm = !h->bp_any && (!shp || bp_lds_bytes(pair.dc, shape_threads(h, shp) * shape_cpt(shp)) > h->lds_per_cu);
     h->large = (m > 1024) || (osd_words(n) == 0) || h->bp_hbm;
     if (h->large) {
         h->nlanes = 2;
@@ -1467,16 +1488,17 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     CREATE_TRY(hipMalloc((void**)&h->d_cost, sizeof(double) * n));
     CREATE_TRY(hipMalloc((void**)&h->d_llr0_alt, sizeof(double) * n));
     CREATE_TRY(hipMalloc((void**)&h->d_cost_alt, sizeof(double) * n));
-    if (h->bp_hbm) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
+    if (h->bp_any) CREATE_RC(build_tables_serial(h));  // (its CSC edge map is what the any-degree kernel walks)
+    else if (h->bp_hbm) CREATE_RC(build_tables_large(h, h->dv_max <= 6 ? 6 : 8, (m + 63) / 64 * 64));
     else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, shp) * shape_cpt(shp), shape_threads(h, shp), 2 * shape_cpt(shp)));
-    if (!h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
-    if (!h->bp_hbm && (!(h->local_ok && cfg->bp_method == BPOSD_BP_MIN_SUM) || getenv("BPOSD_CLASS_ALWAYS"))) CREATE_RC(build_tables_class(h));
+    if (!h->bp_any && !h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
+    if (!h->bp_any && !h->bp_hbm && (!(h->local_ok && cfg->bp_method == BPOSD_BP_MIN_SUM) || getenv("BPOSD_CLASS_ALWAYS"))) CREATE_RC(build_tables_class(h));
     if (cfg->schedule == 1) {
         if (h->dv_max > BPS_MAXDV) {
             fail(h, BPOSD_ERR_UNSUPPORTED, "serial schedule: bit degree %d exceeds %d", h->dv_max, BPS_MAXDV);
             CREATE_RC(BPOSD_ERR_UNSUPPORTED);
         }
-        CREATE_RC(build_tables_serial(h));
+        if (!h->bp_any) CREATE_RC(build_tables_serial(h));
     }
     CREATE_RC(upload_priors(h));
     if (h->large) {
@@ -1657,6 +1679,9 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     if (h->cfg.schedule == 1) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_SERIAL;
         if ((rc = launch_bp_serial(h, P))) return rc;
+    } else if (h->bp_any) {
+        h->last_bp_kernel = BPOSD_BP_KERNEL_ANYDEG;
+        if ((rc = launch_bp_any(h, P))) return rc;
     } else if (h->bp_hbm) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_LARGE;
         BpLargeParams L{};

@@ -1614,3 +1614,54 @@ def test_degree_class_codes_randomized_settings_vs_oracle(gpu_ready):
         seen_class += g.bp_kernel_info()["kernel"] in ("bp_class_kernel", "bp_local_kernel")
         seen_wave += g.last_osd_kernel() == "osd_wave_kernel"
     assert seen_class >= 28 and seen_wave >= 10, (seen_class, seen_wave)  # (the (3,6)-seed products have check degree 9: generic kernel)
+
+
+def test_any_degree_codes_vs_oracle(gpu_ready):
+    """Parity-check matrices beyond the tuned kernels' degrees (check degree > 16 or bit degree > 8; the reference's
+    decoder has no such limit): the Hamming [63,57] code (check degree 32), a (3,24)-regular LDPC matrix, a random dense
+    matrix (bit degree up to 13, rank deficient), and a 1100 x 2400 matrix with check degree 20 (HBM-resident OSD) run on
+    bp_anydeg_kernel -- min-sum and product-sum, uniform / per-bit / per-shot channels, every OSD method: all integer
+    outputs and the LLR bits equal the oracle's."""
+    import scipy.sparse as sp
+
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import regular_ldpc_seed
+    from oracle import OracleDecoder
+
+    rng = np.random.default_rng(99)
+    ham = np.array([[(j >> b) & 1 for j in range(1, 64)] for b in range(6)], dtype=np.uint8)
+    dense = (rng.random((40, 90)) < 0.18).astype(np.uint8)
+    dense[-1] = dense[0] ^ dense[1]
+    big = np.zeros((1100, 2400), dtype=np.uint8)
+    for c in range(1100):
+        big[c, rng.choice(2400, size=20, replace=False)] = 1
+    cases = [(ham, 0.03, 200), (regular_ldpc_seed(32, 256, 3, 24, seed=5), 0.02, 200), (dense, 0.05, 200), (big, 0.01, 10)]
+    for H, q, B in cases:
+        Hs = sp.csr_matrix(H)
+        m, n = H.shape
+        assert np.diff(Hs.indptr).max() > 16 or H.sum(axis=0).max() > 8
+        _, syn = _syndromes(Hs, q, B, 3)
+        syn[0] = 0
+        probs = rng.uniform(0.5 * q, 2 * q, size=n)
+        settings = [dict(error_rate=q, max_iter=12, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_cs", osd_order=4),
+                    dict(channel_probs=probs, max_iter=7, bp_method="ms", ms_scaling_factor=0.75, osd_method="osd_e", osd_order=3),
+                    dict(error_rate=q, max_iter=9, bp_method="ps", ps_clip=25.0, osd_method="osd0"),
+                    dict(error_rate=q, max_iter=1, bp_method="ms", ms_scaling_factor=1.0, osd_method="osd_off")]
+        for kw in settings if m < 1000 else settings[:2]:
+            g = BpOsdDecoder(Hs, **kw)
+            r = _gpu_decode(g, syn)
+            assert g.bp_kernel_info()["kernel"] == "bp_anydeg_kernel"
+            _compare_exact(r, OracleDecoder(Hs, ps_math=1, **kw).decode_batch(syn))
+            assert r["iters"][0] == 0 and r["converged"][0]
+        if m < 1000:  # per-shot two-valued channel
+            sel = (rng.random((B, n)) < 0.2).astype(np.uint8)
+            alt = np.full(n, 0.25)
+            kw = dict(error_rate=q, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=2)
+            g = BpOsdDecoder(Hs, **kw)
+            got = g.decode_batch(syn, prior_select=sel, alt_channel_probs=alt, want_osd0=True, want_llr=True)
+            o = OracleDecoder(Hs, **kw)
+            for b in range(0, B, 8):
+                o.update_channel_probs(np.where(sel[b] != 0, alt, np.full(n, q)))
+                ref = o.decode(syn[b])
+                assert (got[b] == ref["osdw"]).all() and (g.batch_osd0[b] == ref["osd0"]).all(), b
+                assert (g.batch_llr[b].view(np.uint64) == ref["llr"].view(np.uint64)).all(), b
