@@ -1081,7 +1081,10 @@ int osd_wave_shape(const bposd_handle* h, const OsdParams& P, long long B) {
     if (m <= 128 && n1 <= 256) return 2;
     if (m <= 192 && n1 <= 448) return 3;
     if (m <= 320 && n1 <= 640) return 4;
-    if (m <= 448 && n1 <= 960) return 5;
+    // seven rows x fifteen words per lane hold 256 VGPRs + 51 AGPRs, one wave per SIMD: slower than one workgroup per
+    // elimination (tools/surface_probe.py, 32 k eliminations: surface d = 21 22.9 against 17.7 ms, [[900,36,10]] 13.5 against
+    // 10.2 ms) -- only when asked for
+    if (m <= 448 && n1 <= 960) return h->osd_variant == 2 ? 5 : 0;
     return 0;
 }
 

@@ -15,7 +15,9 @@ for spec in (sys.argv[1:] or ["surface:9", "surface:13", "surface:17", "surface:
     err = (rng.random((B, n)) < q).astype(np.uint8)
     syn = np.ascontiguousarray((np.asarray(H @ err.T) % 2).T.astype(np.uint8))
     for osd, order in (("osd_cs", 10), ("osd_e", 8), ("osd0", 0)):
-        dec = BpOsdDecoder(H, error_rate=q, max_iter=n, bp_method="ms", ms_scaling_factor=0, osd_method=osd, osd_order=order)
+        dec = BpOsdDecoder(H, error_rate=q, max_iter=int(os.environ.get("MAX_ITER", n)), bp_method="ms", ms_scaling_factor=0, osd_method=osd, osd_order=order)
+        if os.environ.get("OSD_VARIANT"):
+            dec.set_osd_variant(int(os.environ["OSD_VARIANT"]))
         dec.decode_batch(syn); dec.decode_batch(syn)
         t = dec.last_timing()
         print(f"{spec} {m}x{n} q={q} {osd}{order}: bp {t['bp_ms']:.2f} ms ({dec.bp_kernel_info()['kernel']}), osd {t['osd_ms']:.2f} ms "
