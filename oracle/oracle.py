@@ -64,6 +64,11 @@ def _load():
     return _lib
 
 
+# Threads decode_batch spreads a batch over (each on a handle of its own; the C code holds per-handle scratch).  1 by
+# default -- bench.py's one-core CPU baseline times this class as it is; tests/conftest.py raises it so that the parity
+# suites, whose run time is this oracle's, use the host's cores.
+DEFAULT_THREADS = 1
+
 _BP = {"product_sum": 0, "prod_sum": 0, "ps": 0, "0": 0, "minimum_sum": 1, "min_sum": 1, "ms": 1, "1": 1}
 _OSD = {"osd_off": 0, "off": 0, "osd_0": 1, "osd0": 1, "0": 1, "osd_e": 2, "e": 2, "exhaustive": 2,
         "osd_cs": 3, "cs": 3, "combination_sweep": 3}
@@ -98,6 +103,9 @@ class OracleDecoder:
         cfg = _Cfg(_BP[str(bp_method).lower()], float(ms_scaling_factor), int(max_iter),
                    _OSD[str(osd_method).lower()], int(osd_order), int(sort_tie_policy), int(weight_fn), float(ps_clip),
                    {"parallel": 0, "serial": 1}[str(schedule).lower()], int(ps_math), int(osd_e_bit_order))
+        self._cfg = cfg
+        self._probs = probs.copy()
+        self._extra = []  # further handles of the same decoder, one per additional thread of decode_batch
         self._h = C.c_void_p()
         rc = lib.oracle_create(C.byref(cfg), self._indptr.ctypes.data, self._indices.ctypes.data,
                                self.m, self.n, probs.ctypes.data, C.byref(self._h))
@@ -107,6 +115,9 @@ class OracleDecoder:
         self.num_candidates = lib.oracle_num_candidates(self._h)
 
     def __del__(self):
+        for h in getattr(self, "_extra", []):
+            _load().oracle_destroy(h)
+        self._extra = []
         if getattr(self, "_h", None) is not None and self._h.value:
             _load().oracle_destroy(self._h)
             self._h = None
@@ -114,7 +125,19 @@ class OracleDecoder:
     def update_channel_probs(self, probs):
         probs = np.ascontiguousarray(probs, dtype=np.float64)
         assert probs.shape == (self.n,)
-        _load().oracle_update_channel_probs(self._h, probs.ctypes.data)
+        self._probs = probs.copy()
+        for h in [self._h] + self._extra:
+            _load().oracle_update_channel_probs(h, probs.ctypes.data)
+
+    def _handles(self, k):
+        while len(self._extra) < k - 1:
+            h = C.c_void_p()
+            rc = _load().oracle_create(C.byref(self._cfg), self._indptr.ctypes.data, self._indices.ctypes.data,
+                                       self.m, self.n, self._probs.ctypes.data, C.byref(h))
+            if rc != 0:
+                raise ValueError(f"oracle_create failed ({rc})")
+            self._extra.append(h)
+        return [self._h] + self._extra[:k - 1]
 
     def decode_batch(self, syndromes, want_llr=True, want_diag=False):
         s = np.ascontiguousarray(np.asarray(syndromes) & 1, dtype=np.uint8)
@@ -139,6 +162,24 @@ class OracleDecoder:
                 out["bp"].ctypes.data, out["converged"].ctypes.data, out["iters"].ctypes.data,
                 out["llr"].ctypes.data if want_llr else None, out["first_nonfinite_iter"].ctypes.data,
                 out["final_has_inf"].ctypes.data, out["final_has_nan"].ctypes.data)
+        elif DEFAULT_THREADS > 1 and B >= 4 * DEFAULT_THREADS:
+            # contiguous slices, one handle and one thread each (ctypes releases the GIL for the call); per shot the
+            # computation is the same function on the same inputs, so the result does not depend on the split
+            from concurrent.futures import ThreadPoolExecutor
+
+            k = int(DEFAULT_THREADS)
+            hs = self._handles(k)
+            cuts = [B * j // k for j in range(k + 1)]
+
+            def run(j):
+                lo, hi = cuts[j], cuts[j + 1]
+                return _load().oracle_decode_batch(
+                    hs[j], s[lo:hi].ctypes.data, hi - lo, out["osdw"][lo:hi].ctypes.data, out["osd0"][lo:hi].ctypes.data,
+                    out["bp"][lo:hi].ctypes.data, out["converged"][lo:hi].ctypes.data, out["iters"][lo:hi].ctypes.data,
+                    out["llr"][lo:hi].ctypes.data if want_llr else None)
+
+            with ThreadPoolExecutor(max_workers=k) as ex:
+                rc = max(ex.map(run, range(k)), key=abs)
         else:
             rc = _load().oracle_decode_batch(
                 self._h, s.ctypes.data, B, out["osdw"].ctypes.data, out["osd0"].ctypes.data,

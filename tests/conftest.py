@@ -15,6 +15,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the parity suites' run time is the CPU oracle's: let its batch decodes use the host's cores (one handle per thread;
+    # bench.py's one-core baseline does not go through here)
+    import oracle.oracle as _oracle
+
+    _oracle.DEFAULT_THREADS = max(1, min(8, (os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")
