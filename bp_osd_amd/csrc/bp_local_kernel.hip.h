@@ -221,7 +221,6 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
         bool sbit[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int p = tid + j * NT;
             const int c = bpl_table_load(bpl_args()->pos_chk, (unsigned int)tid * 4u, (unsigned int)(j * NT * 4));
             sbit[j] = (c >= 0) ? ((bpl_args()->synd[(size_t)s * m + c] & 1) != 0) : false;
             const unsigned long long bal = __ballot(sbit[j]);
