@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libbposd_mi355x.so")
 SOURCES = ["bposd_capi.hip"]
-HEADERS = ["portable_math.h", "local_layout.h", "class_layout.h", "bp_class_kernel.hip.h", "bp_anydeg_kernel.hip.h", "osd_wave_kernel.hip.h", "bp_kernel.hip.h", "bp_local_kernel.hip.h", "bp_serial_kernel.hip.h", "bp_large_kernel.hip.h", "osd_kernel.hip.h", "osd_large_kernel.hip.h", os.path.join("..", "..", "include", "bposd_mi355x.h")]
+HEADERS = ["portable_math.h", "local_layout.h", "class_layout.h", "bp_class_kernel.hip.h", "bp_anydeg_kernel.hip.h", "bp_own_kernel.hip.h", "own_layout.h", "osd_wave_kernel.hip.h", "bp_kernel.hip.h", "bp_local_kernel.hip.h", "bp_serial_kernel.hip.h", "bp_large_kernel.hip.h", "osd_kernel.hip.h", "osd_large_kernel.hip.h", os.path.join("..", "..", "include", "bposd_mi355x.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread"]
 
 

@@ -392,14 +392,20 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
             }
             if (bpc_args()->out_conv) bpc_args()->out_conv[s] = conv ? 1 : 0;
             if (bpc_args()->out_iters) bpc_args()->out_iters[s] = it_done;
-            int zero = 0;  // the two convergence flags start the next syndrome at 0 (nobody reads them any more)
-            asm volatile("" : "+v"(zero));
-            sh[0] = zero;
-            sh[1] = zero;
         }
         it_acc += (unsigned long long)it_done;
         __syncthreads();
         const int slot = to_osd ? sh[3] : 0;
+        if (tid == 0) {
+            // the two convergence flags start the next syndrome at 0.  Only HERE: every wave has read its `conv` from them
+            // before the barrier above (zeroing them in the block before it let a late wave read 0 -- "converged" -- for a
+            // syndrome the others sent to OSD: its 64 bits' LLRs never reached the OSD workspace; found as a run-to-run
+            // wobble of the logical error rate, 3 shots in 131072), and the next syndrome sets them after the barrier below.
+            int zero = 0;
+            asm volatile("" : "+v"(zero));
+            sh[0] = zero;
+            sh[1] = zero;
+        }
 #pragma unroll
         for (int r = 0; r < VPT; ++r) {
             const int i = BPC_BIT(r);

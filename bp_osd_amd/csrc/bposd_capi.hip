@@ -29,6 +29,7 @@
 #include "bp_local_kernel.hip.h"
 #include "bp_class_kernel.hip.h"
 #include "bp_anydeg_kernel.hip.h"
+#include "bp_own_kernel.hip.h"
 // occupancy targets of the class kernel instances (minimum waves per SIMD the register allocation must allow)
 #ifndef BPOSD_CLASS7_MINW
 #define BPOSD_CLASS7_MINW 8
@@ -45,6 +46,7 @@
 #include "osd_wave_kernel.hip.h"
 #include "local_layout.h"
 #include "class_layout.h"
+#include "own_layout.h"
 
 using namespace bposd;
 
@@ -135,6 +137,12 @@ struct bposd_handle {
     long long local_wcycles = 0; // modelled ds_write_b64 cycles of the bit pass (floor: 6 * 4 * MP / 64)
     int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
     // class BP kernel (bp_class_kernel.hip.h): every check has the same degree, bit degrees inside one compiled range
+    // owned-edge BP kernel (bp_own_kernel.hip.h): one check degree, bit degrees 3 / 4, every check owns two bits; min-sum
+    bool own_ok = false;
+    int own_dc = 0, own_mp = 0, own_nt = 0, own_zero = 0, own_priv0 = 0;
+    long own_read_cycles = 0, own_write_cycles = 0, own_read_floor = 0, own_write_floor = 0;
+    int *d_o_pos_chk = nullptr, *d_o_own_bit = nullptr, *d_o_own_rd = nullptr, *d_o_own_wr = nullptr, *d_o_own_dl = nullptr,
+        *d_o_x_bit = nullptr, *d_o_x_slot = nullptr, *d_o_x_deg = nullptr;
     bool bp_any = false;  // degrees beyond the compiled kernels: bp_anydeg_kernel.hip.h (run-time degree loops, messages in HBM)
     bool class_ok = false;
     int class_dclo = 0, class_dc = 0, class_dvlo = 0, class_dvhi = 0, class_mp = 0, class_nt = 0;
@@ -834,6 +842,86 @@ int launch_bp_class(bposd_handle* h, const BpParams& P) {
     return fail(h, BPOSD_ERR_UNSUPPORTED, "no class BP kernel for check degree %d", h->class_dc);
 }
 
+// ------------------------------------------------------------------ owned-edge BP kernel: tables + launch
+int build_tables_own(bposd_handle* h) {
+    h->own_ok = false;
+    if (h->bp_hbm || h->bp_any || h->m > 1024 || h->cfg.bp_method != BPOSD_BP_MIN_SUM || h->n < 2 * h->m) return 0;
+    const int dc = h->rp[1] - h->rp[0];
+    if (dc != 7) return 0;  // (instances: check degree 7 -- the reference's example codes)
+    own_layout::Tables T;
+    bool ok = false;
+    const int iters = getenv("BPOSD_LAYOUT_ITERS") ? atoi(getenv("BPOSD_LAYOUT_ITERS")) : 60000;
+    for (int mp : {256, 512, 1024}) {
+        if (h->m > mp) continue;
+        if (own_layout::build(h->rp, h->ci, h->m, h->n, dc, mp, mp, iters, T)) { ok = true; break; }
+        break;  // (a larger stride does not make an unmatched code matchable)
+    }
+    if (!ok) return 0;
+    if (getenv("BPOSD_DEBUG_OCC"))
+        fprintf(stderr, "[bposd] owned-edge BP layout: %d threads, stride %d, bit pass %ld read cycles (floor %ld) + %ld write cycles (floor %ld)\n",
+                T.NT, T.MP, T.read_cycles, T.read_floor, T.write_cycles, T.write_floor);
+    auto up = [&](int** dst, const std::vector<int>& v) -> int {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        HIP_TRY(h, hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1)));
+        HIP_TRY(h, hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc;
+    if ((rc = up(&h->d_o_pos_chk, T.pos_chk))) return rc;
+    if ((rc = up(&h->d_o_own_bit, T.own_bit))) return rc;
+    if ((rc = up(&h->d_o_own_rd, T.own_rd))) return rc;
+    if ((rc = up(&h->d_o_own_wr, T.own_wr))) return rc;
+    if ((rc = up(&h->d_o_own_dl, T.own_dl))) return rc;
+    if ((rc = up(&h->d_o_x_bit, T.x_bit))) return rc;
+    if ((rc = up(&h->d_o_x_slot, T.x_slot))) return rc;
+    if ((rc = up(&h->d_o_x_deg, T.x_deg))) return rc;
+    h->own_dc = dc; h->own_mp = T.MP; h->own_nt = T.NT; h->own_zero = T.zero_slot; h->own_priv0 = T.priv0;
+    h->own_read_cycles = T.read_cycles; h->own_write_cycles = T.write_cycles;
+    h->own_read_floor = T.read_floor; h->own_write_floor = T.write_floor;
+    h->own_ok = true;
+    return 0;
+}
+
+template <int DC, int MP, int MINW, bool UPRIOR>
+int launch_bp_own_t(bposd_handle* h, const BpOwnParams& C) {
+    auto k = bp_own_kernel<DC, MP, MINW, UPRIOR>;
+    const int nt = h->own_nt;
+    const size_t lds = bp_own_lds_bytes(DC, MP, MP);
+    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
+    int wg_per_cu = 1;
+    { int rc_occ = cached_occupancy(h, (const void*)k, nt, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
+    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] owned-edge BP kernel <%d> stride %d: %d threads, %zu B LDS, %d workgroups per CU\n", DC, MP, nt, lds, wg_per_cu);
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 16));
+    long long grid = std::min<long long>(C.B, (long long)h->num_cu * wg_per_cu);
+    if (grid < 1) grid = 1;
+    int rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n);
+    if (rc) return rc;
+    BpOwnParams Cq = C;
+    Cq.llr_tmp = (double*)h->cur->bpl_llr.p;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->cur->stream, Cq);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_bp_own(bposd_handle* h, const BpParams& P) {
+    BpOwnParams C{};
+    C.m = P.m; C.n = P.n; C.B = P.B; C.max_iter = P.max_iter; C.ms_scaling = P.ms_scaling; C.osd_enabled = P.osd_enabled;
+    C.zero_slot = h->own_zero; C.priv0 = h->own_priv0;
+    C.synd = P.synd; C.llr0 = P.llr0; C.sel = P.sel; C.llr0_alt = P.llr0_alt;
+    C.pos_chk = h->d_o_pos_chk; C.own_bit = h->d_o_own_bit; C.own_rd = h->d_o_own_rd; C.own_wr = h->d_o_own_wr; C.own_dl = h->d_o_own_dl;
+    C.x_bit = h->d_o_x_bit; C.x_slot = h->d_o_x_slot; C.x_deg = h->d_o_x_deg;
+    C.out_bp = P.out_bp; C.out_osd0 = P.out_osd0; C.out_osdw = P.out_osdw; C.out_conv = P.out_conv; C.out_iters = P.out_iters;
+    C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total; C.tail_flag = P.tail_flag;
+    const bool uprior = h->probs_uniform && P.sel == nullptr && h->probs[0] > 0.0 && h->probs[0] < 0.5;
+#define BPOSD_OWN_MP(MPV)                                                                                                \
+    if (h->own_mp == MPV) return uprior ? launch_bp_own_t<7, MPV, 8, true>(h, C) : launch_bp_own_t<7, MPV, 8, false>(h, C);
+    BPOSD_OWN_MP(256)
+    BPOSD_OWN_MP(512)
+    BPOSD_OWN_MP(1024)
+#undef BPOSD_OWN_MP
+    return fail(h, BPOSD_ERR_UNSUPPORTED, "no owned-edge BP kernel for stride %d", h->own_mp);
+}
+
 int launch_bp_local(bposd_handle* h, const BpParams& P) {
     BpLocalParams L{};
     L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling; L.osd_enabled = P.osd_enabled;
@@ -1300,6 +1388,8 @@ void bposd_destroy(bposd_handle* h) {
                     (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
                     (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl,
                     (void*)h->d_cpos_chk, (void*)h->d_cpos_bit, (void*)h->d_cbit_slot, (void*)h->d_cgrp_deg, (void*)h->d_cgrp_cdeg,
+                    (void*)h->d_o_pos_chk, (void*)h->d_o_own_bit, (void*)h->d_o_own_rd, (void*)h->d_o_own_wr, (void*)h->d_o_own_dl,
+                    (void*)h->d_o_x_bit, (void*)h->d_o_x_slot, (void*)h->d_o_x_deg,
                     (void*)h->d_cp, (void*)h->d_ce, (void*)h->d_erow, (void*)h->d_lvl_ptr, (void*)h->d_lvl_bits})
         if (p) (void)hipFree(p);
     for (CallRecord* rs : {h->rec, h->lane_rec})
@@ -1496,6 +1586,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, shp) * shape_cpt(shp), shape_threads(h, shp), 2 * shape_cpt(shp)));
     if (!h->bp_any && !h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
     if (!h->bp_any && !h->bp_hbm && (!(h->local_ok && cfg->bp_method == BPOSD_BP_MIN_SUM) || getenv("BPOSD_CLASS_ALWAYS"))) CREATE_RC(build_tables_class(h));
+    if (!h->local_ok) CREATE_RC(build_tables_own(h));
     if (cfg->schedule == 1) {
         if (h->dv_max > BPS_MAXDV) {
             fail(h, BPOSD_ERR_UNSUPPORTED, "serial schedule: bit degree %d exceeds %d", h->dv_max, BPS_MAXDV);
@@ -1534,8 +1625,10 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32)
-        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel) or 32 (class kernel)");
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32 && variant != 48)
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel), 32 (class kernel) or 48 (owned-edge kernel)");
+    if (variant == 48 && !h->own_ok)
+        return fail(h, BPOSD_ERR_UNSUPPORTED, "the owned-edge BP kernel needs min-sum, check degree 7, bit degrees 3 / 4 and a perfect two-bits-per-check matching");
     if (variant == 32 && !h->class_ok)
         return fail(h, BPOSD_ERR_UNSUPPORTED, "the class BP kernel needs one check degree and bit degrees of a compiled range");
     if (variant >= 16 && variant <= 26 && !(h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM))
@@ -1605,6 +1698,9 @@ int bposd_bp_kernel_info(bposd_handle* h, int32_t* kernel, int64_t* lds_model) {
         } else if (h->last_bp_kernel == BPOSD_BP_KERNEL_CLASS) {
             lds_model[0] = h->class_read_cycles; lds_model[1] = h->class_read_floor;
             lds_model[2] = h->class_write_cycles; lds_model[3] = h->class_write_floor;
+        } else if (h->last_bp_kernel == BPOSD_BP_KERNEL_OWN) {
+            lds_model[0] = h->own_read_cycles; lds_model[1] = h->own_read_floor;
+            lds_model[2] = h->own_write_cycles; lds_model[3] = h->own_write_floor;
         }
     }
     return BPOSD_OK;
@@ -1699,6 +1795,9 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || (h->bp_variant >= 16 && h->bp_variant <= 26))) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_LOCAL;
         if ((rc = launch_bp_local(h, P))) return rc;
+    } else if (h->own_ok && h->bp_variant == 48) {
+        h->last_bp_kernel = BPOSD_BP_KERNEL_OWN;
+        if ((rc = launch_bp_own(h, P))) return rc;
     } else if (h->class_ok && (h->bp_variant == 32 || (h->bp_variant == 0 && class_preferred(h)))) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_CLASS;
         if ((rc = launch_bp_class(h, P))) return rc;

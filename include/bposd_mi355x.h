@@ -224,6 +224,7 @@ int bposd_last_osd_kernel(bposd_handle *h);
 #define BPOSD_BP_KERNEL_LARGE 3  /* bp_large_kernel: messages in HBM */
 #define BPOSD_BP_KERNEL_SERIAL 4 /* bp_serial_kernel: schedule = serial */
 #define BPOSD_BP_KERNEL_ANYDEG 5 /* bp_anydeg_kernel: check degree > 16 or bit degree > 8 (run-time degree loops) */
+#define BPOSD_BP_KERNEL_OWN 6    /* bp_own_kernel: every check owns two bits whose edge messages stay in registers */
 int bposd_bp_kernel_info(bposd_handle *h, int32_t *kernel, int64_t *lds_model);
 
 /* Diagnostics, host only (needs no device): the ownership / position layout the local-edge BP kernel would use for a
