@@ -1586,7 +1586,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, shp) * shape_cpt(shp), shape_threads(h, shp), 2 * shape_cpt(shp)));
     if (!h->bp_any && !h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
     if (!h->bp_any && !h->bp_hbm && (!(h->local_ok && cfg->bp_method == BPOSD_BP_MIN_SUM) || getenv("BPOSD_CLASS_ALWAYS"))) CREATE_RC(build_tables_class(h));
-    if (!h->local_ok) CREATE_RC(build_tables_own(h));
+    // (bp_own_kernel's tables are built when the variant is asked for: bposd_set_bp_variant(h, 48))
     if (cfg->schedule == 1) {
         if (h->dv_max > BPS_MAXDV) {
             fail(h, BPOSD_ERR_UNSUPPORTED, "serial schedule: bit degree %d exceeds %d", h->dv_max, BPS_MAXDV);
@@ -1627,6 +1627,13 @@ int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
     if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32 && variant != 48)
         return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel), 32 (class kernel) or 48 (owned-edge kernel)");
+    if (variant == 48 && !h->own_ok) {  // experimental kernel: its layout search (~1-2 s) runs here, not in every constructor
+        DeviceGuard dev_guard(h->device);
+        HIP_TRY(h, dev_guard.err);
+        int rc_own = sync_all_lanes(h);
+        if (!rc_own && !h->local_ok) rc_own = build_tables_own(h);
+        if (rc_own) return rc_own;
+    }
     if (variant == 48 && !h->own_ok)
         return fail(h, BPOSD_ERR_UNSUPPORTED, "the owned-edge BP kernel needs min-sum, check degree 7, bit degrees 3 / 4 and a perfect two-bits-per-check matching");
     if (variant == 32 && !h->class_ok)
