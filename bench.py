@@ -293,6 +293,29 @@ def main():
     dec.synchronize()
     t_last = dec.last_timing()
 
+    # ---- cross-kernel check (rank 0, outside the timed region): the whole batch once more on the OTHER kernel path -- the
+    # generic LDS BP kernel and the workgroup OSD kernel, each pinned to the CPU oracle by tests/ -- must give the same
+    # five outputs bit for bit.  (This is what would have shown the 3-in-131072 race of DESIGN.md 4.8 at once.)
+    cross = None
+    if rank == 0 and not large and kw.get("bp_method") == "ms" and args.variant == 0:
+        try:
+            other = BpOsdDecoder(H, device=local_rank, **kw)
+            other.set_bp_variant(1)
+            other.set_osd_variant(1)
+            if other.num_lanes:
+                o2 = dict(osdw=mk(B, n), osd0=mk(B, n), bp=mk(B, n), conv=mk(B), iters=mk(B, dtype=torch.int32))
+                other.decode_batch_device(d_syn[0].data_ptr(), B, o2["osdw"].data_ptr(), o2["osd0"].data_ptr(), o2["bp"].data_ptr(),
+                                          o2["conv"].data_ptr(), o2["iters"].data_ptr(), None)
+                other.synchronize()
+                same = {k: bool(torch.equal(a, b)) for k, (a, b) in dict(osdw=(d_osdw, o2["osdw"]), osd0=(d_osd0, o2["osd0"]), bp=(d_bp, o2["bp"]),
+                                                                         converged=(d_conv, o2["conv"]), iters=(d_iters, o2["iters"])).items()}
+                cross = {"identical": all(same.values()), "outputs": same, "shots": int(B),
+                         "against": other.bp_kernel_info()["kernel"] + " + " + (other.last_osd_kernel() or "osd_kernel")}
+                del o2
+            del other
+        except Exception as e:  # the check must never take the bench line down
+            cross = {"identical": None, "error": str(e)[:200]}
+
     # ---- host-to-host leg (rank 0, N = 1): the same batches through the host-pointer API from page-locked buffers
     host = None
     if rank == 0 and world == 1 and args.host_steps > 0:
@@ -408,6 +431,7 @@ def main():
             "bp_logical_error_rate": ler_bp,
             "bp_logical_error_rate_eb": None if ler_bp is None else float(np.sqrt(ler_bp * (1 - ler_bp) / B)),
             "corrections_reproduce_syndromes": synd_ok,
+            "cross_kernel_check": cross,
             "bp_converged_fraction": conv_frac,
             "bp_iterations_mean": float(it_cpu.mean()),
             "bp_iterations_p50_p99_max": [float(np.percentile(it_cpu, 50)), float(np.percentile(it_cpu, 99)),

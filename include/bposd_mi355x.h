@@ -247,7 +247,8 @@ int bposd_debug_class_layout(const int32_t *csr_indptr, const int32_t *csr_indic
  * messages in registers; (3,6)-regular codes with n = 2m and min-sum only, BPOSD_ERR_UNSUPPORTED otherwise):
  * 2 checks per thread at <= 80 / <= 64 VGPRs, 1 check per thread.  Auto picks 16 where it applies.  All variants
  * return identical results.  32 = class kernel (one check degree, bit degrees of a compiled range; auto picks it where it
- * applies and the local-edge kernel does not). */
+ * applies and the local-edge kernel does not).  48 = owned-edge kernel (experimental, never picked by auto: check degree
+ * 7, bit degrees 3 / 4, min-sum; its layout search runs in this call). */
 int bposd_set_bp_variant(bposd_handle *h, int32_t variant);
 
 /* Message for the last error on this handle (h == NULL: last create() failure). */
