@@ -1674,22 +1674,24 @@ def test_class_kernel_large_batch_equals_generic_kernel_without_llr_output(gpu_r
     for converged -- its 64 bits' LLRs never reached the OSD kernel.  65536 syndromes, most of them through OSD, three
     times, against the generic LDS kernel (itself pinned to the oracle by the other tests): every output identical."""
     from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp, rep_code, ring_code
 
-    H = hgp400.hz
-    _, syn = _syndromes(H, 0.08, 65536, 2024)
-    kw = dict(error_rate=0.08, max_iter=20, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=6)
-    g = BpOsdDecoder(H, **kw)
-    g.set_bp_variant(1)
-    want = dict(osdw=g.decode_batch(syn, want_osd0=True, want_bp=True).copy(), osd0=g.batch_osd0.copy(), bp=g.batch_bp.copy(),
-                conv=g.batch_converge.copy(), iters=g.batch_iter.copy())
-    assert g.bp_kernel_info()["kernel"] == "bp_kernel" and (~want["conv"]).mean() > 0.3
-    for variant in (0, 48):
-        for rep in range(3):
-            d = BpOsdDecoder(H, **kw)
-            d.set_bp_variant(variant)
-            got = dict(osdw=d.decode_batch(syn, want_osd0=True, want_bp=True), osd0=d.batch_osd0, bp=d.batch_bp,
-                       conv=d.batch_converge, iters=d.batch_iter)
-            assert d.bp_kernel_info()["kernel"] == ("bp_class_kernel" if variant == 0 else "bp_own_kernel")
-            for k in want:
-                bad = np.flatnonzero((got[k] != want[k]).reshape(len(syn), -1).any(axis=1))
-                assert len(bad) == 0, (variant, rep, k, len(bad), bad[:5])
+    cases = [(hgp400.hz, (0, 48)), (hgp(rep_code(13), compute_logicals=False).hz, (0,)), (hgp(ring_code(12), compute_logicals=False).hx, (0,))]
+    for H, variants in cases:  # (the surface / toric codes: the degree-class instances with queue batches and check-degree classes)
+        _, syn = _syndromes(H, 0.08, 65536, 2024)
+        kw = dict(error_rate=0.08, max_iter=20, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=6)
+        g = BpOsdDecoder(H, **kw)
+        g.set_bp_variant(1)
+        want = dict(osdw=g.decode_batch(syn, want_osd0=True, want_bp=True).copy(), osd0=g.batch_osd0.copy(), bp=g.batch_bp.copy(),
+                    conv=g.batch_converge.copy(), iters=g.batch_iter.copy())
+        assert g.bp_kernel_info()["kernel"] == "bp_kernel" and (~want["conv"]).mean() > 0.3
+        for variant in variants:
+            for rep in range(3):
+                d = BpOsdDecoder(H, **kw)
+                d.set_bp_variant(variant)
+                got = dict(osdw=d.decode_batch(syn, want_osd0=True, want_bp=True), osd0=d.batch_osd0, bp=d.batch_bp,
+                           conv=d.batch_converge, iters=d.batch_iter)
+                assert d.bp_kernel_info()["kernel"] == ("bp_class_kernel" if variant == 0 else "bp_own_kernel")
+                for k in want:
+                    bad = np.flatnonzero((got[k] != want[k]).reshape(len(syn), -1).any(axis=1))
+                    assert len(bad) == 0, (H.shape, variant, rep, k, len(bad), bad[:5])
