@@ -294,14 +294,17 @@ def main():
     t_last = dec.last_timing()
 
     # ---- cross-kernel check (rank 0, outside the timed region): the whole batch once more on the OTHER kernel path -- the
-    # generic LDS BP kernel and the workgroup OSD kernel, each pinned to the CPU oracle by tests/ -- must give the same
-    # five outputs bit for bit.  (This is what would have shown the 3-in-131072 race of DESIGN.md 4.8 at once.)
+    # generic LDS BP kernel and the workgroup OSD kernel (large codes: the any-degree BP kernel), each pinned to the CPU
+    # oracle by tests/ -- must give the same five outputs bit for bit.  (This is what would have shown the 3-in-131072 race of DESIGN.md 4.8 at once.)
     cross = None
-    if rank == 0 and not large and kw.get("bp_method") == "ms" and args.variant == 0:
+    if rank == 0 and kw.get("bp_method") == "ms" and args.variant == 0:
         try:
             other = BpOsdDecoder(H, device=local_rank, **kw)
-            other.set_bp_variant(1)
-            other.set_osd_variant(1)
+            if large:  # the HBM-resident BP kernel against the any-degree kernel (run-time degree loops); one OSD kernel exists there
+                other.set_bp_variant(64)
+            else:
+                other.set_bp_variant(1)
+                other.set_osd_variant(1)
             if other.num_lanes:
                 o2 = dict(osdw=mk(B, n), osd0=mk(B, n), bp=mk(B, n), conv=mk(B), iters=mk(B, dtype=torch.int32))
                 other.decode_batch_device(d_syn[0].data_ptr(), B, o2["osdw"].data_ptr(), o2["osd0"].data_ptr(), o2["bp"].data_ptr(),

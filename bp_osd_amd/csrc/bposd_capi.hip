@@ -1625,8 +1625,15 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32 && variant != 48)
-        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel), 32 (class kernel) or 48 (owned-edge kernel)");
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32 && variant != 48 && variant != 64)
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel), 32 (class kernel), 48 (owned-edge kernel) or 64 (any-degree kernel)");
+    if (variant == 64 && !h->d_cp) {  // the any-degree kernel as a second implementation for cross-checks: its CSC edge map
+        DeviceGuard dev_guard(h->device);
+        HIP_TRY(h, dev_guard.err);
+        int rc_any = sync_all_lanes(h);
+        if (!rc_any) rc_any = build_tables_serial(h);
+        if (rc_any) return rc_any;
+    }
     if (variant == 48 && !h->own_ok) {  // experimental kernel: its layout search (~1-2 s) runs here, not in every constructor
         DeviceGuard dev_guard(h->device);
         HIP_TRY(h, dev_guard.err);
@@ -1785,7 +1792,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     if (h->cfg.schedule == 1) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_SERIAL;
         if ((rc = launch_bp_serial(h, P))) return rc;
-    } else if (h->bp_any) {
+    } else if (h->bp_any || h->bp_variant == 64) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_ANYDEG;
         if ((rc = launch_bp_any(h, P))) return rc;
     } else if (h->bp_hbm) {

@@ -248,7 +248,8 @@ int bposd_debug_class_layout(const int32_t *csr_indptr, const int32_t *csr_indic
  * 2 checks per thread at <= 80 / <= 64 VGPRs, 1 check per thread.  Auto picks 16 where it applies.  All variants
  * return identical results.  32 = class kernel (one check degree, bit degrees of a compiled range; auto picks it where it
  * applies and the local-edge kernel does not).  48 = owned-edge kernel (experimental, never picked by auto: check degree
- * 7, bit degrees 3 / 4, min-sum; its layout search runs in this call). */
+ * 7, bit degrees 3 / 4, min-sum; its layout search runs in this call).  64 = the any-degree kernel on any code (slow; a
+ * second implementation for cross-checks, also of the HBM-resident BP kernel). */
 int bposd_set_bp_variant(bposd_handle *h, int32_t variant);
 
 /* Message for the last error on this handle (h == NULL: last create() failure). */

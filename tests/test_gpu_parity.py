@@ -1695,3 +1695,28 @@ def test_class_kernel_large_batch_equals_generic_kernel_without_llr_output(gpu_r
                 for k in want:
                     bad = np.flatnonzero((got[k] != want[k]).reshape(len(syn), -1).any(axis=1))
                     assert len(bad) == 0, (H.shape, variant, rep, k, len(bad), bad[:5])
+
+
+def test_any_degree_kernel_as_second_implementation(gpu_ready, hgp4050, h1922, hgp400):
+    """bposd_set_bp_variant(h, 64) runs the any-degree BP kernel on any code: a second implementation to cross-check the
+    tuned kernels at batch sizes the oracle does not reach -- the HBM-resident bp_large_kernel on a 3844 x 7688 code (1024
+    syndromes, LLR bits included), bp_local_kernel on the 2025 x 4050 and [[1922,50]] codes, bp_class_kernel on [[400,16,6]]."""
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import circulant, hgp
+
+    big = hgp(circulant(62, (0, 2, 5)), compute_logicals=False).hz  # 3844 x 7688: messages in HBM
+    for H, B, q, kernel in ((big, 1024, 0.04, "bp_large_kernel"), (hgp4050.hz, 2048, 0.04, "bp_local_kernel"), (h1922.hz, 16384, 0.06, "bp_local_kernel"),
+                            (hgp400.hz, 16384, 0.07, "bp_class_kernel")):
+        _, syn = _syndromes(H, q, B, 12)
+        kw = dict(error_rate=q, max_iter=25, bp_method="ms", ms_scaling_factor=0.0, osd_method="osd_off")
+        a = BpOsdDecoder(H, **kw)
+        ra = _gpu_decode(a, syn)
+        assert a.bp_kernel_info()["kernel"] == kernel
+        b = BpOsdDecoder(H, **kw)
+        b.set_bp_variant(64)
+        rb = _gpu_decode(b, syn)
+        assert b.bp_kernel_info()["kernel"] == "bp_anydeg_kernel"
+        assert 0.02 < (~ra["converged"]).mean() < 0.98
+        for k in ("bp", "converged", "iters"):
+            assert (ra[k] == rb[k]).all(), (kernel, k)
+        assert (ra["llr"].view(np.uint64) == rb["llr"].view(np.uint64)).all(), kernel
