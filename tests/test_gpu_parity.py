@@ -1676,10 +1676,12 @@ def test_class_kernel_large_batch_equals_generic_kernel_without_llr_output(gpu_r
     from bp_osd_amd import BpOsdDecoder
     from bp_osd_amd.codes import hgp, rep_code, ring_code
 
-    cases = [(hgp400.hz, (0, 48)), (hgp(rep_code(13), compute_logicals=False).hz, (0,)), (hgp(ring_code(12), compute_logicals=False).hx, (0,))]
-    for H, variants in cases:  # (the surface / toric codes: the degree-class instances with queue batches and check-degree classes)
+    ms = dict(bp_method="ms", ms_scaling_factor=0)
+    cases = [(hgp400.hz, (0, 48), ms), (hgp(rep_code(13), compute_logicals=False).hz, (0,), ms), (hgp(ring_code(12), compute_logicals=False).hx, (0,), ms),
+             (hgp400.hx, (0,), dict(bp_method="ps", ps_clip=20.0))]
+    for H, variants, method in cases:  # (the surface / toric codes: the degree-class instances with queue batches and check-degree classes)
         _, syn = _syndromes(H, 0.08, 65536, 2024)
-        kw = dict(error_rate=0.08, max_iter=20, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=6)
+        kw = dict(error_rate=0.08, max_iter=20, osd_method="osd_cs", osd_order=6, **method)
         g = BpOsdDecoder(H, **kw)
         g.set_bp_variant(1)
         want = dict(osdw=g.decode_batch(syn, want_osd0=True, want_bp=True).copy(), osd0=g.batch_osd0.copy(), bp=g.batch_bp.copy(),
