@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = (
     "bposd_last_osd_kernel",
     "bposd_debug_local_layout",
     "bposd_debug_class_layout",
+    "bposd_debug_own_layout",
     "bposd_last_error",
     "bposd_destroy",
 )
@@ -133,6 +134,8 @@ def load():
     lib.bposd_debug_local_layout.restype = C.c_int
     lib.bposd_debug_class_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.bposd_debug_class_layout.restype = C.c_int
+    lib.bposd_debug_own_layout.argtypes = [vp, vp, C.c_int32, C.c_int32] + [vp] * 9
+    lib.bposd_debug_own_layout.restype = C.c_int
     lib.bposd_set_osd_variant.argtypes = [vp, C.c_int32]
     lib.bposd_set_osd_variant.restype = C.c_int
     lib.bposd_last_osd_kernel.argtypes = [vp]

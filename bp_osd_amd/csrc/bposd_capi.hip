@@ -2287,6 +2287,29 @@ int bposd_debug_class_layout(const int32_t* indptr, const int32_t* indices, int3
     return BPOSD_OK;
 }
 
+int bposd_debug_own_layout(const int32_t* indptr, const int32_t* indices, int32_t m, int32_t n, int32_t* pos_chk, int32_t* own_bit,
+                           int32_t* own_rd, int32_t* own_wr, int32_t* own_dl, int32_t* x_bit, int32_t* x_slot, int32_t* x_deg, int64_t* info) {
+    // host-only: the tables bp_own_kernel would be launched with (tests check their invariants without a GPU).
+    // info[0..9]: DC, MP (= NTMAX), threads per workgroup, zero slot, first private slot, modelled read cycles, their floor,
+    // modelled write cycles, their floor, 0
+    if (!indptr || !indices || !info || m < 1 || n < 1) return BPOSD_ERR_INVALID;
+    std::vector<int> rp(indptr, indptr + m + 1), ci(indices, indices + indptr[m]);
+    for (int e : ci)
+        if (e < 0 || e >= n) return BPOSD_ERR_INVALID;
+    const int dc = rp[1] - rp[0];
+    if (m > 1024) return BPOSD_ERR_UNSUPPORTED;
+    own_layout::Tables T;
+    int mp = 256;
+    while (mp < m) mp *= 2;
+    if (!own_layout::build(rp, ci, m, n, dc, mp, mp, 5000, T)) return BPOSD_ERR_UNSUPPORTED;
+    info[0] = dc; info[1] = T.MP; info[2] = T.NT; info[3] = T.zero_slot; info[4] = T.priv0;
+    info[5] = T.read_cycles; info[6] = T.read_floor; info[7] = T.write_cycles; info[8] = T.write_floor; info[9] = 0;
+    auto put = [](int32_t* dst, const std::vector<int>& v) { if (dst) std::copy(v.begin(), v.end(), dst); };
+    put(pos_chk, T.pos_chk); put(own_bit, T.own_bit); put(own_rd, T.own_rd); put(own_wr, T.own_wr); put(own_dl, T.own_dl);
+    put(x_bit, T.x_bit); put(x_slot, T.x_slot); put(x_deg, T.x_deg);
+    return BPOSD_OK;
+}
+
 void* bposd_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;

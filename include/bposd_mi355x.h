@@ -242,6 +242,15 @@ int bposd_debug_local_layout(const int32_t *csr_indptr, const int32_t *csr_indic
 int bposd_debug_class_layout(const int32_t *csr_indptr, const int32_t *csr_indices, int32_t m, int32_t n, int32_t *pos_chk,
                              int32_t *pos_bit, int32_t *bit_slot, int32_t *grp_deg, int32_t *grp_cdeg, int64_t *info);
 
+/* Diagnostics, host only: the tables bp_own_kernel (variant 48) would run with -- one check degree, bit degrees 3 / 4, a
+ * perfect two-bits-per-check matching; BPOSD_ERR_UNSUPPORTED otherwise.  info[10]: check degree, LDS stride MP (= table
+ * stride), threads per workgroup, zero slot, first private slot, modelled read cycles of one bit pass and their floor,
+ * modelled write cycles and their floor, 0.  Nullable outputs sized for MP = 1024: pos_chk [MP], own_bit [2 MP],
+ * own_rd [6 MP], own_wr [2 MP], own_dl [2 MP], x_bit [MP], x_slot [4 MP], x_deg [MP / 64]. */
+int bposd_debug_own_layout(const int32_t *csr_indptr, const int32_t *csr_indices, int32_t m, int32_t n, int32_t *pos_chk,
+                           int32_t *own_bit, int32_t *own_rd, int32_t *own_wr, int32_t *own_dl, int32_t *x_bit, int32_t *x_slot,
+                           int32_t *x_deg, int64_t *info);
+
 /* Tuning knob (not part of the reference surface): which BP kernel / workgroup shape runs.
  * 0 = auto; 1, 2, 4 = LDS kernel with 1 / 2 / 4 checks per thread; 16, 17, 18 = local-edge kernel (a third of the
  * messages in registers; (3,6)-regular codes with n = 2m and min-sum only, BPOSD_ERR_UNSUPPORTED otherwise):
