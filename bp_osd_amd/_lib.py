@@ -40,16 +40,19 @@ EXPORTED_SYMBOLS = (
     "bposd_last_timing",
     "bposd_info",
     "bposd_posterior_llr",
-    "bposd_layout_info",
-    "bposd_bp_kernel_info",
     "bposd_set_bp_variant",
     "bposd_set_osd_variant",
     "bposd_last_osd_kernel",
-    "bposd_debug_local_layout",
-    "bposd_debug_class_layout",
-    "bposd_debug_own_layout",
     "bposd_last_error",
     "bposd_destroy",
+)
+
+# include/bposd_mi355x_debug.h: diagnostics (which kernel ran, LDS layout models and tables)
+DEBUG_SYMBOLS = (
+    "bposd_layout_info",
+    "bposd_bp_kernel_info",
+    "bposd_debug_local_layout",
+    "bposd_debug_class_layout",
 )
 
 
@@ -134,8 +137,6 @@ def load():
     lib.bposd_debug_local_layout.restype = C.c_int
     lib.bposd_debug_class_layout.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.bposd_debug_class_layout.restype = C.c_int
-    lib.bposd_debug_own_layout.argtypes = [vp, vp, C.c_int32, C.c_int32] + [vp] * 9
-    lib.bposd_debug_own_layout.restype = C.c_int
     lib.bposd_set_osd_variant.argtypes = [vp, C.c_int32]
     lib.bposd_set_osd_variant.restype = C.c_int
     lib.bposd_last_osd_kernel.argtypes = [vp]

@@ -24,167 +24,20 @@
 #include <mutex>
 #include <vector>
 
-#include "bp_kernel.hip.h"
-#include "bp_large_kernel.hip.h"
-#include "bp_local_kernel.hip.h"
-#include "bp_class_kernel.hip.h"
-#include "bp_anydeg_kernel.hip.h"
-#include "bp_own_kernel.hip.h"
-// occupancy targets of the class kernel instances (minimum waves per SIMD the register allocation must allow)
-#ifndef BPOSD_CLASS7_MINW
-#define BPOSD_CLASS7_MINW 8
-#endif
-#ifndef BPOSD_CLASS7_MINW_PS
-#define BPOSD_CLASS7_MINW_PS 7  // (8 would cap the SGPRs at 80 and spill them)
-#endif
-#ifndef BPOSD_CLASS6_MINW_PS
-#define BPOSD_CLASS6_MINW_PS 7
-#endif
-#include "bp_serial_kernel.hip.h"
-#include "osd_large_kernel.hip.h"
-#include "osd_kernel.hip.h"
-#include "osd_wave_kernel.hip.h"
+#include "internal.h"
 #include "local_layout.h"
 #include "class_layout.h"
-#include "own_layout.h"
 
 using namespace bposd;
+using namespace bposd_host;
 
 namespace {
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-
 }  // namespace
 
-// Per-call state.  A handle owns BPOSD_LANES of these and alternates between them: consecutive decode calls (and the
-// chunks of one host-pointer call) run on different HIP streams with their own workspaces, so the persistent
-// workgroups of call k + 1 pick up the CUs that call k's last max_iter stragglers and its OSD kernel leave idle.
-constexpr int BPOSD_LANES = 4;  // large codes (HBM-resident workspaces of several GB per lane) use two of them
-constexpr int BPOSD_MAX_CHUNKS = 16;  // chunks of one host-pointer call (bposd_decode_batch)
-
-struct Lane {
-    hipStream_t stream = nullptr;
-    // The OSD kernel of a call runs on a stream of its own at the highest priority (ordered behind the call's BP kernel
-    // and in front of whatever follows on `stream` by events): its few, fat workgroups otherwise queue behind the full
-    // grid of the NEXT call's BP kernel for every CU that frees up and take many times their own run time.
-    hipStream_t osd_stream = nullptr;
-    hipEvent_t ev_bp = nullptr, ev_osd = nullptr;
-    void* h_stage = nullptr;     // page-locked, device-visible staging for small host-pointer calls (zero-copy path)
-    size_t h_stage_bytes = 0;
-    hipEvent_t ev_up = nullptr;  // host-pointer calls: this lane's chunk has been uploaded (uploads go one at a time, in
-                                 // chunk order: the first chunk's kernels then start after one chunk's copy time)
-    DevBuf bpl_msg, bpl_llr;  // large BP workspaces (bpl_llr also serves the local-edge kernel: LLRs of the current syndrome)
-    DevBuf osdl_ws;           // large OSD workspaces (matrix, sort keys, pivots, weights) carved from one allocation
-    DevBuf osd_rows_ws;       // OSD kernel's per-workgroup spill area for finished row words
-    DevBuf llr_ws, osd_list, io_synd, io_osdw, io_osd0, io_bp, io_conv, io_iters, io_llr, io_sel;
-    // host-pointer calls: the outputs are downloaded on a copy stream of the lane's own right after the BP kernel (event-
-    // ordered), the rows the OSD kernel rewrites come from compact copies [list slot][n] once it has run
-    DevBuf io_cmp0, io_cmpw;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copy = nullptr;    // the chunk's downloads have left the lane's io buffers
-    int* h_list = nullptr;           // page-locked copy of the chunk's OSD list (syndrome index per slot)
-    size_t h_list_cap = 0;
-    bool copy_pending = false;
-    long long* d_osd_dbg = nullptr;  // diagnostics (BPOSD_OSD_DEBUG=1): phase timestamps
-    int* d_counters = nullptr;       // 4 ints
-    // per-shot channel of a device-pointer call (bposd_decode_batch_select_device): priors and weights of the alternative
-    // channel, 2n doubles, copied from a page-locked staging block on the lane's own stream -- consecutive select calls
-    // overlap like plain ones (the first version drained every lane and made two blocking copies per call)
-    double* d_alt = nullptr;
-    double* h_alt = nullptr;
-    hipEvent_t ev_alt = nullptr;     // the staging block has been read
-    bool alt_busy = false;
-    int* h_tail = nullptr;           // page-locked, device-visible: the BP kernel of this lane's current call has entered its tail
-};
-
-// What bposd_last_timing reports: one record per kernel pair launched by the last call (one per chunk for a
-// host-pointer call).  Events and the pinned counter copies live in the handle so that records outlive lane reuse.
-struct CallRecord {
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    int* h_counters = nullptr;               // pinned: 4 ints
-    unsigned long long* h_iter_total = nullptr;  // pinned
-    bool ran_osd = false;
-    bool recorded = false;  // the counters (and, when timed, the events) have been recorded at least once
-    bool timed = false;     // the three events bracket the kernels of this record (not on the lean small-call path)
-};
-
-struct bposd_handle {
-    bposd_config cfg{};
-    int device = 0;
-    Lane lanes[BPOSD_LANES];
-    Lane* cur = nullptr;      // lane of the call being enqueued
-    int nlanes = BPOSD_LANES; // lanes this handle cycles through
-    int next_lane = 0;
-    CallRecord lane_rec[BPOSD_LANES];  // device-pointer calls: the record of the last call queued on each lane
-    CallRecord rec[BPOSD_MAX_CHUNKS];  // host-pointer calls: one record per chunk
-    CallRecord* currec = nullptr;
-    int nrec = 0;             // > 0: the last call was a host-pointer call of that many chunks
-    int last_lane = 0;        // lane of the last device-pointer call
-    int num_cu = 0;
-    size_t lds_per_cu = 160 * 1024;
-    int m = 0, n = 0, E = 0;
-    int dc_max = 0, dv_max = 0;
-    bool regular = false;
-    // local-edge BP kernel (bp_local_kernel.hip.h): available for (3,6)-regular codes with n = 2m, min-sum
-    bool local_ok = false;
-    int local_mp = 0;
-    long long local_passes = 0;  // modelled ds_read_b64 cycles of the bit pass in the chosen layout (floor: 4 * MP / 32)
-    long long local_wcycles = 0; // modelled ds_write_b64 cycles of the bit pass (floor: 6 * 4 * MP / 64)
-    int *d_lpos_chk = nullptr, *d_lpos_bit = nullptr, *d_lpos_alo = nullptr, *d_lpos_ahi = nullptr, *d_lgrp_dl = nullptr, *d_lpos_dl = nullptr;
-    // class BP kernel (bp_class_kernel.hip.h): every check has the same degree, bit degrees inside one compiled range
-    // owned-edge BP kernel (bp_own_kernel.hip.h): one check degree, bit degrees 3 / 4, every check owns two bits; min-sum
-    bool own_ok = false;
-    int own_dc = 0, own_mp = 0, own_nt = 0, own_zero = 0, own_priv0 = 0;
-    long own_read_cycles = 0, own_write_cycles = 0, own_read_floor = 0, own_write_floor = 0;
-    int *d_o_pos_chk = nullptr, *d_o_own_bit = nullptr, *d_o_own_rd = nullptr, *d_o_own_wr = nullptr, *d_o_own_dl = nullptr,
-        *d_o_x_bit = nullptr, *d_o_x_slot = nullptr, *d_o_x_deg = nullptr;
-    bool bp_any = false;  // degrees beyond the compiled kernels: bp_anydeg_kernel.hip.h (run-time degree loops, messages in HBM)
-    bool class_ok = false;
-    int class_dclo = 0, class_dc = 0, class_dvlo = 0, class_dvhi = 0, class_mp = 0, class_nt = 0;
-    long class_read_cycles = 0, class_write_cycles = 0, class_read_floor = 0, class_write_floor = 0;  // modelled, one bit pass
-    int *d_cpos_chk = nullptr, *d_cpos_bit = nullptr, *d_cbit_slot = nullptr, *d_cgrp_deg = nullptr, *d_cgrp_cdeg = nullptr;
-    bool large = false;   // beyond the register-resident OSD kernel: HBM-resident matrix, device rank probe
-    bool bp_hbm = false;  // BP messages do not fit one CU's LDS either: HBM-resident BP kernel
-    int max_iter = 0;
-    int rank = 0, kprime = 0, ncand = 0;
-    bool probs_uniform = true;
-    int bp_variant = 0;
-    int last_bp_kernel = -1;  // BPOSD_BP_KERNEL_* of the last BP launch
-    int osd_variant = 0;      // 0 auto, 1 = one workgroup per elimination (osd_kernel), 2 = one wave per elimination where it applies
-    int last_osd_kernel = -1; // 0 none yet, 1 osd_kernel, 2 osd_wave_kernel, 3 osd_large_kernel
-    // host copies
-    std::vector<int> rp, ci;
-    std::vector<double> probs;
-    // device tables
-    int *d_rp = nullptr, *d_ci = nullptr;
-    int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr, *d_pos_bit = nullptr;
-    int tab_np = 0;
-    long layout_cost = 0, layout_cost_natural = 0, layout_cost_ideal = 0;  // simulated LDS cycles of the bit pass
-    double* d_llr0 = nullptr;
-    double* d_cost = nullptr;  // log(1/p_i): OSD-W weights of the ldpc-v2 weight function
-    double *d_llr0_alt = nullptr, *d_cost_alt = nullptr;  // alternative channel of the two-valued per-shot form
-    bool fp_weights = false;   // non-uniform (or degenerate) channel: candidate weights need the fp64 sums
-    // serial schedule (cfg.schedule == 1): CSC view and level lists
-    int *d_cp = nullptr, *d_ce = nullptr, *d_erow = nullptr, *d_lvl_ptr = nullptr, *d_lvl_bits = nullptr;
-    int nlevels = 0;
-    int tab_dc = 0, tab_dv = 0, tab_mp = 0;  // layout the tables were built for
-    bool have_timing = false;
-    long long batch_hint = 0;          // > 0 while a chunked host call is being enqueued: its whole batch size
-    bool async_pending = false;        // a device-pointer call may still be running on some lane
-    hipStream_t osd_now = nullptr;     // stream the OSD kernel of the call being enqueued goes to
-    uint8_t *cmp_osd0 = nullptr, *cmp_osdw = nullptr;  // compact OSD rows of the chunk being enqueued (host-pointer calls)
-    bool bp_only = false;              // the call being enqueued wants BP's outputs only (bposd_posterior_llr): no OSD kernel
-    bool lane_alt = false;             // the call being enqueued takes the alternative channel from its lane's buffers
-    bool tail_gate = false;            // the call being enqueued is a chunk of a host-pointer call: its BP kernel reports its tail
-    std::string err;
-};
-
-namespace {
+namespace bposd_host {
 
 int fail(bposd_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -196,15 +49,6 @@ int fail(bposd_handle* h, int code, const char* fmt, ...) {
     else g_create_error = buf;
     return code;
 }
-
-#define HIP_TRY(h, expr)                                                                       \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess)                                                                  \
-            return fail(h, BPOSD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-                        __FILE__, __LINE__);                                                   \
-    } while (0)
-
 // Every entry point works on the handle's device and puts the caller's current device back on exit (a process that
 // also drives torch, or handles on other GPUs, must not find its thread's device changed by a decode call).
 struct DeviceGuard {
@@ -220,7 +64,6 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
-
 int sync_all_lanes(bposd_handle* h) {
     for (auto& l : h->lanes) {
         if (l.stream) HIP_TRY(h, hipStreamSynchronize(l.stream));
@@ -291,7 +134,6 @@ void release(DevBuf& b) {
     b.p = nullptr;
     b.bytes = 0;
 }
-
 // GF(2) rank of the pcm by packed elimination (ctor-time, host).  a1: upstream's ctor
 // eliminates H once to learn rank and k' = n - rank.
 int gf2_rank_host(int m, int n, const std::vector<int>& rp, const std::vector<int>& ci) {
@@ -345,7 +187,6 @@ int upload_priors(bposd_handle* h) {
                     !(h->probs_uniform && h->probs[0] > 0.0 && h->probs[0] < 1.0);
     return 0;
 }
-
 // ---------------------------------------------------------------------------------------------
 // Bit-pass layout.  The check pass is bank-conflict free by construction (lane c <-> slot k*MP + c).
 // The bit pass gathers/scatters slot (k*MP + c) for the d-th edge of each of 64 lanes; its conflicts
@@ -509,110 +350,6 @@ int build_tables(bposd_handle* h, int DC, int DV, int MP, int NT, int VPT) {
     h->tab_np = NP;
     return 0;
 }
-
-// ------------------------------------------------------------------------------ BP launch
-template <int DC, int DV, int CPT, int VPT, int MAXNT, int MINW, bool REG, int MPT>
-int launch_bp_t(bposd_handle* h, const BpParams& P, int NT) {
-    const size_t lds = bp_lds_bytes(DC, P.mp);
-    int wg_per_cu = (int)std::min<size_t>(h->lds_per_cu / lds, (size_t)(2048 / NT));
-    wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
-    long long grid = std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu);
-    if (grid < 1) grid = 1;
-    if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
-        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 1, MPT>;
-        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
-    } else {
-        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 0, MPT>;
-        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-int pow2_at_least(int x) {
-    int p = 64;
-    while (p < x) p <<= 1;
-    return p;
-}
-
-// shape id: 1 -> (CPT 1, VPT 2, <=1024 threads), 2 -> (2, 4, <=512), 4 -> (4, 8, <=256).
-// Threads per workgroup are a power of two so that the check stride MP = threads * CPT is one.
-// The regular (6,3) kernels are compiled for MP = 1024 exactly (H1922: 961 checks, 1922 bits).
-bool is_reg63(const bposd_handle* h) { return h->regular && h->dc_max == 6 && h->dv_max == 3; }
-
-// shape 8 = "mid-size": 2 checks / 4 bits per thread with 1024 threads (1024 < m <= 2048, n <= 4096): one workgroup per CU
-int shape_cpt(int shape) { return shape == 8 ? 2 : shape; }
-
-int shape_threads(const bposd_handle* h, int shape) {
-    const int cpt = shape_cpt(shape), vpt = 2 * cpt;
-    int nt = pow2_at_least(std::max((h->m + cpt - 1) / cpt, (h->n + vpt - 1) / vpt));
-    if (is_reg63(h) && shape != 8 && nt <= 1024 / shape) nt = 1024 / shape;
-    return nt;
-}
-
-int pick_shape(const bposd_handle* h) {
-    const int caps[3][2] = {{1, 1024}, {2, 512}, {4, 256}};
-    if (h->bp_variant) {
-        for (auto& c : caps)
-            if (c[0] == h->bp_variant && shape_threads(h, c[0]) <= c[1] && (c[0] != 4 || is_reg63(h))) return c[0];
-    }
-    if (is_reg63(h) && shape_threads(h, 2) <= 512) return 2;
-    // generic kernels: one check per thread when that fits, else two
-    if (shape_threads(h, 1) <= 1024) return 1;
-    if (shape_threads(h, 2) <= 512) return 2;
-    if (shape_threads(h, 8) <= 1024) return 8;
-    return 0;
-}
-
-template <int DC, int DV, bool REG>
-int launch_bp_shape(bposd_handle* h, const BpParams& P, int shape, int NT) {
-    // occupancy targets: LDS admits 3 workgroups per CU for H1922 (46 KB each); the regular
-    // (6,3) kernels are register-capped for that (2 x 1024, 3 x 512 or 3 x 256 threads per CU)
-    if (shape == 1) return launch_bp_t<DC, DV, 1, 2, 1024, (REG ? 8 : 4), REG, (REG ? 1024 : 0)>(h, P, NT);
-#ifndef BPOSD_SHAPE2_MINW
-#define BPOSD_SHAPE2_MINW 6
-#endif
-    if (shape == 2) return launch_bp_t<DC, DV, 2, 4, 512, (REG ? BPOSD_SHAPE2_MINW : 2), REG, (REG ? 1024 : 0)>(h, P, NT);
-    if constexpr (REG) {
-        if (shape == 4) return launch_bp_t<DC, DV, 4, 8, 256, 3, REG, 1024>(h, P, NT);
-    } else {
-        if (shape == 8) return launch_bp_t<DC, DV, 2, 4, 1024, 4, false, 0>(h, P, NT);
-    }
-    return fail(h, BPOSD_ERR_UNSUPPORTED, "no BP kernel shape %d for this code", shape);
-}
-
-int launch_bp(bposd_handle* h, BpParams& P) {
-    int shape = pick_shape(h);
-    if (!shape) return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the LDS-resident BP kernel (m=%d n=%d)", h->m, h->n);
-    const int NT = shape_threads(h, shape);
-    const int MP = NT * shape_cpt(shape);
-    const int NPOS = NT * 2 * shape_cpt(shape);
-    if (MP != h->tab_mp || NPOS != h->tab_np) {
-        { int rcs = sync_all_lanes(h); if (rcs) return rcs; }  // kernels in flight still read the old tables
-        int rc = build_tables(h, h->tab_dc, h->tab_dv, MP, NT, 2 * shape_cpt(shape));
-        if (rc) return rc;
-        P.chk_deg = h->d_chk_deg;
-        P.var_deg = h->d_var_deg;
-        P.var_pos = h->d_var_pos;
-        P.pos_bit = h->d_pos_bit;
-    }
-    P.mp = MP;
-    P.np = NPOS;
-    if (bp_lds_bytes(h->tab_dc, MP) > h->lds_per_cu)
-        return fail(h, BPOSD_ERR_UNSUPPORTED, "BP messages (%zu B) exceed one CU's LDS", bp_lds_bytes(h->tab_dc, MP));
-    if (is_reg63(h) && MP == 1024) return launch_bp_shape<6, 3, true>(h, P, shape, NT);
-    switch (h->tab_dc) {
-        case 4: return launch_bp_shape<4, 2, false>(h, P, shape, NT);
-        case 6: return launch_bp_shape<6, 3, false>(h, P, shape, NT);
-        case 8: return launch_bp_shape<8, 4, false>(h, P, shape, NT);
-        case 12: return launch_bp_shape<12, 6, false>(h, P, shape, NT);
-        case 16: return launch_bp_shape<16, 8, false>(h, P, shape, NT);
-    }
-    return fail(h, BPOSD_ERR_UNSUPPORTED, "no BP kernel for check degree %d / bit degree %d", h->dc_max, h->dv_max);
-}
-
 int build_tables_local(bposd_handle* h) {
     using namespace local_layout;
     h->local_ok = false;
@@ -694,28 +431,6 @@ int build_tables_local(bposd_handle* h) {
     h->local_ok = true;
     return 0;
 }
-
-template <int CPT, int MP, int MINW, bool EARLY, bool UPRIOR = false>
-int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
-    auto k = bp_local_kernel<CPT, MP, MINW, EARLY, UPRIOR>;
-    const int nt = MP / CPT;
-    const size_t lds = bp_local_lds_bytes(L.mp);
-    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-    int wg_per_cu = 1;
-    { int rc_occ = cached_occupancy(h, (const void*)k, nt, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
-    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] local-edge BP kernel: %d threads, %zu B LDS, %d workgroups per CU\n", nt, lds, wg_per_cu);
-    wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
-    long long grid = std::min<long long>(L.B, (long long)h->num_cu * wg_per_cu);
-    if (grid < 1) grid = 1;
-    int rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n);
-    if (rc) return rc;
-    BpLocalParams Lq = L;
-    Lq.llr_tmp = (double*)h->cur->bpl_llr.p;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->cur->stream, Lq);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
 // ------------------------------------------------------------------ class BP kernel: tables + launch
 // Instances: (check degrees; bit degrees) = (7; 3..4) -- the reference's three example codes --, (6; 3) -- H1922 with
 // product-sum, other (3,6)-regular codes --, (4; 2) -- toric codes, hgp(ring_code) --, (8; 4), and (3..4; 1..2) -- surface
@@ -774,186 +489,6 @@ int build_tables_class(bposd_handle* h) {
     h->class_ok = true;
     return 0;
 }
-
-template <int DCLO, int DC, int DVLO, int DVHI, int MP, int MINW, int METHOD, bool UPRIOR>
-int launch_bp_class_t(bposd_handle* h, const BpClassParams& C) {
-    auto k = bp_class_kernel<DCLO, DC, DVLO, DVHI, 1, kClassVPT, MP, MP, MINW, METHOD, UPRIOR>;
-    const int nt = h->class_nt;
-    const size_t lds = bp_class_lds_bytes(DC, MP, MP);
-    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-    int wg_per_cu = 1;
-    { int rc_occ = cached_occupancy(h, (const void*)k, nt, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
-    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] class BP kernel <%d..%d;%d..%d> stride %d: %d threads, %zu B LDS, %d workgroups per CU\n", DCLO, DC, DVLO, DVHI, MP, nt, lds, wg_per_cu);
-    wg_per_cu = std::max(1, std::min(wg_per_cu, 16));
-    if (const char* e = getenv("BPOSD_CLASS_WG_CAP")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));
-    long long grid = std::min<long long>(C.B, (long long)h->num_cu * wg_per_cu);
-    if (grid < 1) grid = 1;
-    int rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n);
-    if (rc) return rc;
-    BpClassParams Cq = C;
-    Cq.llr_tmp = (double*)h->cur->bpl_llr.p;
-    // syndromes per queue atomic: (what is left) / (2 x grid), at most eight, one at the end (guided self-scheduling)
-    // -- for codes of up to 160 checks only, where the queue atomic is the bound (surface code d = 5: 0.93 -> 0.61 ms per
-    // 65536 syndromes); larger codes lose 4-6 % to the coarser tail (tools/bp_iteration_cost.py, A/B in one run)
-    Cq.queue_batch = h->m <= 160 ? 8 : 1;
-    Cq.queue_shift = 1;
-    while ((1ll << Cq.queue_shift) < grid * 2) Cq.queue_shift++;
-    if (const char* e = getenv("BPOSD_CLASS_QUEUE_BATCH")) Cq.queue_batch = std::max(1, std::min(64, atoi(e)));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->cur->stream, Cq);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-template <int DCLO, int DC, int DVLO, int DVHI, int MINW_MS, int MINW_PS>
-int launch_bp_class_shape(bposd_handle* h, const BpClassParams& C, bool uprior) {
-    const bool ms = h->cfg.bp_method == BPOSD_BP_MIN_SUM;
-#define BPOSD_CLASS_MP(MPV)                                                                                              \
-    if (h->class_mp == MPV) {                                                                                            \
-        if (ms) return uprior ? launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_MS, 1, true>(h, C) : launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_MS, 1, false>(h, C); \
-        return uprior ? launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 0, true>(h, C) : launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 0, false>(h, C); \
-    }
-    BPOSD_CLASS_MP(256)
-    BPOSD_CLASS_MP(512)
-    BPOSD_CLASS_MP(1024)
-#undef BPOSD_CLASS_MP
-    return fail(h, BPOSD_ERR_UNSUPPORTED, "no class BP kernel for stride %d", h->class_mp);
-}
-
-// Measured (tools/bp_iteration_cost.py): the class kernel wins everywhere except product-sum on a (3,6)-regular code of
-// ~1000 checks (H1922: 8.3 against 6.4 ps per edge-iteration) -- VALU-bound, and the two-checks-per-thread shape of the
-// regular LDS kernel interleaves two division chains per thread.
-bool class_preferred(const bposd_handle* h) {
-    return !(h->cfg.bp_method != BPOSD_BP_MIN_SUM && is_reg63(h) && h->class_mp == 1024);
-}
-
-int launch_bp_class(bposd_handle* h, const BpParams& P) {
-    BpClassParams C{};
-    C.m = P.m; C.n = P.n; C.B = P.B; C.max_iter = P.max_iter; C.ms_scaling = P.ms_scaling; C.ps_clip = P.ps_clip; C.osd_enabled = P.osd_enabled;
-    C.synd = P.synd; C.llr0 = P.llr0; C.sel = P.sel; C.llr0_alt = P.llr0_alt;
-    C.pos_chk = h->d_cpos_chk; C.pos_bit = h->d_cpos_bit; C.bit_slot = h->d_cbit_slot; C.grp_deg = h->d_cgrp_deg; C.grp_cdeg = h->d_cgrp_cdeg;
-    C.out_bp = P.out_bp; C.out_osd0 = P.out_osd0; C.out_osdw = P.out_osdw; C.out_conv = P.out_conv; C.out_iters = P.out_iters;
-    C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total; C.tail_flag = P.tail_flag;
-    const bool uprior = h->probs_uniform && P.sel == nullptr && h->probs[0] > 0.0 && h->probs[0] < 0.5;
-    if (h->class_dc == 7) return launch_bp_class_shape<7, 7, 3, 4, BPOSD_CLASS7_MINW, BPOSD_CLASS7_MINW_PS>(h, C, uprior);
-    if (h->class_dc == 6) return launch_bp_class_shape<6, 6, 3, 3, 8, BPOSD_CLASS6_MINW_PS>(h, C, uprior);
-    if (h->class_dc == 4 && h->class_dclo == 4) return launch_bp_class_shape<4, 4, 2, 2, 8, 7>(h, C, uprior);
-    if (h->class_dc == 4 && h->class_dclo == 3) return launch_bp_class_shape<3, 4, 1, 2, 8, 7>(h, C, uprior);
-    if (h->class_dc == 8) return launch_bp_class_shape<8, 8, 4, 4, 7, 6>(h, C, uprior);
-    return fail(h, BPOSD_ERR_UNSUPPORTED, "no class BP kernel for check degree %d", h->class_dc);
-}
-
-// ------------------------------------------------------------------ owned-edge BP kernel: tables + launch
-int build_tables_own(bposd_handle* h) {
-    h->own_ok = false;
-    if (h->bp_hbm || h->bp_any || h->m > 1024 || h->cfg.bp_method != BPOSD_BP_MIN_SUM || h->n < 2 * h->m) return 0;
-    const int dc = h->rp[1] - h->rp[0];
-    if (dc != 7) return 0;  // (instances: check degree 7 -- the reference's example codes)
-    own_layout::Tables T;
-    bool ok = false;
-    const int iters = getenv("BPOSD_LAYOUT_ITERS") ? atoi(getenv("BPOSD_LAYOUT_ITERS")) : 60000;
-    for (int mp : {256, 512, 1024}) {
-        if (h->m > mp) continue;
-        if (own_layout::build(h->rp, h->ci, h->m, h->n, dc, mp, mp, iters, T)) { ok = true; break; }
-        break;  // (a larger stride does not make an unmatched code matchable)
-    }
-    if (!ok) return 0;
-    if (getenv("BPOSD_DEBUG_OCC"))
-        fprintf(stderr, "[bposd] owned-edge BP layout: %d threads, stride %d, bit pass %ld read cycles (floor %ld) + %ld write cycles (floor %ld)\n",
-                T.NT, T.MP, T.read_cycles, T.read_floor, T.write_cycles, T.write_floor);
-    auto up = [&](int** dst, const std::vector<int>& v) -> int {
-        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
-        HIP_TRY(h, hipMalloc((void**)dst, sizeof(int) * std::max<size_t>(v.size(), 1)));
-        HIP_TRY(h, hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
-        return 0;
-    };
-    int rc;
-    if ((rc = up(&h->d_o_pos_chk, T.pos_chk))) return rc;
-    if ((rc = up(&h->d_o_own_bit, T.own_bit))) return rc;
-    if ((rc = up(&h->d_o_own_rd, T.own_rd))) return rc;
-    if ((rc = up(&h->d_o_own_wr, T.own_wr))) return rc;
-    if ((rc = up(&h->d_o_own_dl, T.own_dl))) return rc;
-    if ((rc = up(&h->d_o_x_bit, T.x_bit))) return rc;
-    if ((rc = up(&h->d_o_x_slot, T.x_slot))) return rc;
-    if ((rc = up(&h->d_o_x_deg, T.x_deg))) return rc;
-    h->own_dc = dc; h->own_mp = T.MP; h->own_nt = T.NT; h->own_zero = T.zero_slot; h->own_priv0 = T.priv0;
-    h->own_read_cycles = T.read_cycles; h->own_write_cycles = T.write_cycles;
-    h->own_read_floor = T.read_floor; h->own_write_floor = T.write_floor;
-    h->own_ok = true;
-    return 0;
-}
-
-template <int DC, int MP, int MINW, bool UPRIOR>
-int launch_bp_own_t(bposd_handle* h, const BpOwnParams& C) {
-    auto k = bp_own_kernel<DC, MP, MINW, UPRIOR>;
-    const int nt = h->own_nt;
-    const size_t lds = bp_own_lds_bytes(DC, MP, MP);
-    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-    int wg_per_cu = 1;
-    { int rc_occ = cached_occupancy(h, (const void*)k, nt, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
-    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] owned-edge BP kernel <%d> stride %d: %d threads, %zu B LDS, %d workgroups per CU\n", DC, MP, nt, lds, wg_per_cu);
-    wg_per_cu = std::max(1, std::min(wg_per_cu, 16));
-    long long grid = std::min<long long>(C.B, (long long)h->num_cu * wg_per_cu);
-    if (grid < 1) grid = 1;
-    int rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n);
-    if (rc) return rc;
-    BpOwnParams Cq = C;
-    Cq.llr_tmp = (double*)h->cur->bpl_llr.p;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(nt), lds, h->cur->stream, Cq);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-int launch_bp_own(bposd_handle* h, const BpParams& P) {
-    BpOwnParams C{};
-    C.m = P.m; C.n = P.n; C.B = P.B; C.max_iter = P.max_iter; C.ms_scaling = P.ms_scaling; C.osd_enabled = P.osd_enabled;
-    C.zero_slot = h->own_zero; C.priv0 = h->own_priv0;
-    C.synd = P.synd; C.llr0 = P.llr0; C.sel = P.sel; C.llr0_alt = P.llr0_alt;
-    C.pos_chk = h->d_o_pos_chk; C.own_bit = h->d_o_own_bit; C.own_rd = h->d_o_own_rd; C.own_wr = h->d_o_own_wr; C.own_dl = h->d_o_own_dl;
-    C.x_bit = h->d_o_x_bit; C.x_slot = h->d_o_x_slot; C.x_deg = h->d_o_x_deg;
-    C.out_bp = P.out_bp; C.out_osd0 = P.out_osd0; C.out_osdw = P.out_osdw; C.out_conv = P.out_conv; C.out_iters = P.out_iters;
-    C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total; C.tail_flag = P.tail_flag;
-    const bool uprior = h->probs_uniform && P.sel == nullptr && h->probs[0] > 0.0 && h->probs[0] < 0.5;
-#define BPOSD_OWN_MP(MPV)                                                                                                \
-    if (h->own_mp == MPV) return uprior ? launch_bp_own_t<7, MPV, 8, true>(h, C) : launch_bp_own_t<7, MPV, 8, false>(h, C);
-    BPOSD_OWN_MP(256)
-    BPOSD_OWN_MP(512)
-    BPOSD_OWN_MP(1024)
-#undef BPOSD_OWN_MP
-    return fail(h, BPOSD_ERR_UNSUPPORTED, "no owned-edge BP kernel for stride %d", h->own_mp);
-}
-
-int launch_bp_local(bposd_handle* h, const BpParams& P) {
-    BpLocalParams L{};
-    L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling; L.osd_enabled = P.osd_enabled;
-    L.mp = h->local_mp;
-    L.synd = P.synd; L.llr0 = P.llr0; L.sel = P.sel; L.llr0_alt = P.llr0_alt;
-    L.pos_chk = h->d_lpos_chk; L.pos_bit = h->d_lpos_bit; L.pos_alo = h->d_lpos_alo; L.pos_ahi = h->d_lpos_ahi;
-    L.grp_dl = h->d_lgrp_dl; L.pos_dl = h->d_lpos_dl;
-    L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv; L.out_iters = P.out_iters;
-    L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list; L.counters = P.counters; L.iter_total = P.iter_total; L.tail_flag = P.tail_flag;
-    if (h->local_mp == 2048) return launch_bp_local_t<2, 2048, 4, false>(h, L);  // 1024 threads, one workgroup per CU
-    if (h->bp_variant == 17) return launch_bp_local_t<2, 1024, 8, false>(h, L);   // 512 threads, <= 64 VGPRs: 4 workgroups per CU
-    if (h->bp_variant == 18) return launch_bp_local_t<1, 1024, 8, false>(h, L);   // 1024 threads, <= 64 VGPRs: 2 workgroups per CU
-    if (h->bp_variant == 19) return launch_bp_local_t<4, 1024, 4, true>(h, L);    // 256 threads, <= 128 VGPRs: 4 workgroups per CU
-    if (h->bp_variant == 20) return launch_bp_local_t<2, 1024, 6, true>(h, L);    // as the default with early check-pass loads
-    if (h->bp_variant == 21) return launch_bp_local_t<4, 1024, 3, true>(h, L);    // 256 threads, <= 168 VGPRs: 3 workgroups per CU
-    // one finite positive prior for every bit: it can live in scalar registers (positive: the padding positions share it)
-    const bool uprior = h->probs_uniform && !L.sel && h->probs[0] > 0.0 && h->probs[0] < 0.5;
-    // Small calls are latency-bound (a max_iter straggler runs ~2000 dependent iterations, a lone syndrome ~60): one check
-    // per thread (16 waves per syndrome) iterates 25-30 % faster per syndrome, two checks per thread (4 workgroups per
-    // CU) have the higher throughput.  Measured crossover on the [[1922,50]] code: 32768 syndromes per call (2048: 2.5
-    // against 3.3 ms, 8192: 4.1 / 5.1, 32768: 9.6 / 10.0, 131072: 31.0 / 28.2).  A chunked host call counts as a whole.
-    const long long work = h->batch_hint > 0 ? h->batch_hint : L.B;
-    const bool small_call = h->bp_variant == 0 && work <= 40000;
-    if (small_call) return uprior ? launch_bp_local_t<1, 1024, 8, false, true>(h, L) : launch_bp_local_t<1, 1024, 8, false>(h, L);
-    if ((h->bp_variant == 22 || h->bp_variant == 0) && uprior) return launch_bp_local_t<2, 1024, 8, false, true>(h, L);  // <= 64 VGPRs: 4 workgroups per CU
-    if (h->bp_variant == 23 && uprior) return launch_bp_local_t<2, 1024, 6, true, true>(h, L);
-    if (h->bp_variant == 24 && uprior) return launch_bp_local_t<2, 1024, 6, false, true>(h, L);
-    if (h->bp_variant == 25 && uprior) return launch_bp_local_t<2, 1024, 8, true, true>(h, L);   // 22 with early check-pass loads
-    if (h->bp_variant == 26 && uprior) return launch_bp_local_t<1, 1024, 8, false, true>(h, L);  // 18 with the scalar prior
-    return launch_bp_local_t<2, 1024, 6, false>(h, L);                            // 512 threads, <= 80 VGPRs: 3 workgroups per CU
-}
-
 // ------------------------------------------------------------------------ large-code BP launch
 int build_tables_large(bposd_handle* h, int DV, int MP) {
     const int m = h->m, n = h->n;
@@ -980,44 +515,6 @@ int build_tables_large(bposd_handle* h, int DV, int MP) {
     h->tab_mp = MP;
     return 0;
 }
-
-template <int DC, int DV>
-int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
-    const size_t lds = bp_large_lds_bytes(h->m, h->n);
-    // persistent workgroups: what registers and LDS admit per CU (the message workspace is per workgroup)
-    int wg_per_cu = 1;
-    {
-        const void* kq = h->cfg.bp_method == BPOSD_BP_MIN_SUM ? (const void*)bp_large_kernel<DC, DV, 1> : (const void*)bp_large_kernel<DC, DV, 0>;
-        int rc_lds = set_max_lds(h, kq, lds); if (rc_lds) return rc_lds;
-        int rc_occ = cached_occupancy(h, kq, 512, lds, &wg_per_cu); if (rc_occ) return rc_occ;
-    }
-    wg_per_cu = std::max(1, std::min(wg_per_cu, 4));
-    if (const char* e = getenv("BPOSD_LARGE_WG_CAP")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));
-    const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
-    int rc;
-    if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * DC * P.mp))) return rc;
-    if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
-    P.msg_ws = (double*)h->cur->bpl_msg.p;
-    P.llr_tmp = (double*)h->cur->bpl_llr.p;
-    if (h->cfg.bp_method == BPOSD_BP_MIN_SUM) {
-        auto k = bp_large_kernel<DC, DV, 1>;
-        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->cur->stream, P);
-    } else {
-        auto k = bp_large_kernel<DC, DV, 0>;
-        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->cur->stream, P);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-int launch_bp_large(bposd_handle* h, BpLargeParams& P) {
-    if (h->dc_max <= 12 && h->dv_max <= 6) return launch_bp_large_t<12, 6>(h, P);
-    if (h->dc_max <= 16 && h->dv_max <= 8) return launch_bp_large_t<16, 8>(h, P);
-    return fail(h, BPOSD_ERR_UNSUPPORTED, "check degree %d / bit degree %d exceed the built kernels (16 / 8)", h->dc_max, h->dv_max);
-}
-
 // ------------------------------------------------------------------ serial-schedule BP: tables + launch
 int build_tables_serial(bposd_handle* h) {
     const int m = h->m, n = h->n, E = h->E;
@@ -1060,232 +557,6 @@ int build_tables_serial(bposd_handle* h) {
     h->nlevels = nlev;
     return 0;
 }
-
-int launch_bp_serial(bposd_handle* h, const BpParams& P) {
-    BpSerialParams S{};
-    S.m = P.m; S.n = P.n; S.E = h->E; S.B = P.B; S.max_iter = P.max_iter; S.bp_method = h->cfg.bp_method;
-    S.ms_scaling = P.ms_scaling; S.ps_clip = P.ps_clip; S.osd_enabled = P.osd_enabled; S.nlevels = h->nlevels;
-    S.synd = P.synd; S.llr0 = P.llr0; S.sel = P.sel; S.llr0_alt = P.llr0_alt;
-    S.rp = h->d_rp; S.ci = h->d_ci; S.cp = h->d_cp; S.ce = h->d_ce; S.erow = h->d_erow;
-    S.lvl_ptr = h->d_lvl_ptr; S.lvl_bits = h->d_lvl_bits;
-    S.out_bp = P.out_bp; S.out_osd0 = P.out_osd0; S.out_osdw = P.out_osdw; S.out_conv = P.out_conv; S.out_iters = P.out_iters;
-    S.out_llr = P.out_llr; S.llr_ws = P.llr_ws; S.osd_list = P.osd_list; S.counters = P.counters; S.iter_total = P.iter_total;
-    const size_t lds = bp_serial_lds_bytes(h->n);
-    const int wg_per_cu = std::max<int>(1, std::min<size_t>(8, h->lds_per_cu / std::max<size_t>(lds, 1)));
-    const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
-    int rc;
-    if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * h->E))) return rc;
-    if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
-    S.msg_ws = (double*)h->cur->bpl_msg.p;
-    S.llr_tmp = (double*)h->cur->bpl_llr.p;
-    { int rc_lds = set_max_lds(h, (const void*)bp_serial_kernel, lds); if (rc_lds) return rc_lds; }
-    hipLaunchKernelGGL(bp_serial_kernel, dim3((unsigned)grid), dim3(BPS_NT), lds, h->cur->stream, S);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-// ------------------------------------------------------------------ any-degree BP (check degree > 16 or bit degree > 8)
-int launch_bp_any(bposd_handle* h, const BpParams& P) {
-    BpAnyParams A{};
-    A.m = P.m; A.n = P.n; A.E = h->E; A.B = P.B; A.max_iter = P.max_iter; A.bp_method = h->cfg.bp_method;
-    A.ms_scaling = P.ms_scaling; A.ps_clip = P.ps_clip; A.osd_enabled = P.osd_enabled;
-    A.synd = P.synd; A.llr0 = P.llr0; A.sel = P.sel; A.llr0_alt = P.llr0_alt;
-    A.rp = h->d_rp; A.ci = h->d_ci; A.cp = h->d_cp; A.ce = h->d_ce;
-    A.out_bp = P.out_bp; A.out_osd0 = P.out_osd0; A.out_osdw = P.out_osdw; A.out_conv = P.out_conv; A.out_iters = P.out_iters;
-    A.out_llr = P.out_llr; A.llr_ws = P.llr_ws; A.osd_list = P.osd_list; A.counters = P.counters; A.iter_total = P.iter_total;
-    A.tail_flag = P.tail_flag;
-    const size_t lds = bp_anydeg_lds_bytes(h->n);
-    const int wg_per_cu = std::max<int>(1, std::min<size_t>(8, h->lds_per_cu / std::max<size_t>(lds, 1)));
-    const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
-    int rc;
-    if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * 3 * h->E))) return rc;
-    if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
-    A.msg_ws = (double*)h->cur->bpl_msg.p;
-    A.llr_tmp = (double*)h->cur->bpl_llr.p;
-    { int rc_lds = set_max_lds(h, (const void*)bp_anydeg_kernel, lds); if (rc_lds) return rc_lds; }
-    hipLaunchKernelGGL(bp_anydeg_kernel, dim3((unsigned)grid), dim3(BPA_NT), lds, h->cur->stream, A);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-// ----------------------------------------------------------------------------- OSD launch
-template <int W>
-int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
-    // OSD_RPT rows per thread: 4 waves cover 1024 rows
-    const int rows_per_thread = OSD_RPT;
-    const int NT = std::min(64 * OSD_MAXW, std::max(64, ((h->m + rows_per_thread - 1) / rows_per_thread + 63) / 64 * 64));
-    const size_t lds = osd_lds_bytes(W, NT * OSD_RPT);
-    auto k = osd_kernel<W>;
-    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-    // persistent workgroups: as many per CU as registers and LDS admit (H1922: one 8-wave workgroup; the reference's
-    // [[400,16,6]] code: four 2-wave workgroups -- with one per CU its 32 k eliminations per batch took longer than BP)
-    int wg_per_cu = 1;
-    { int rc_occ = cached_occupancy(h, (const void*)k, NT, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
-    wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
-    long long grid = std::min<long long>(B, (long long)h->num_cu * wg_per_cu);
-    if (grid < 1) grid = 1;
-    int rc = ensure_lanes(h, &Lane::osd_rows_ws, sizeof(unsigned long long) * (size_t)grid * W * NT * OSD_RPT);
-    if (rc) return rc;
-    OsdParams Q = P;
-    Q.rows_ws = (unsigned long long*)h->cur->osd_rows_ws.p;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->osd_now ? h->osd_now : h->cur->osd_stream, Q);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-int osd_words(int n) {
-    const int need = (n + 1 + 63) / 64;
-    for (int w : {1, 2, 4, 8, 16, 31, 32})
-        if (w >= need) return w;
-    return 0;
-}
-
-// one wave per elimination (osd_wave_kernel.hip.h): small codes, integer weights
-template <int RPL, int W>
-int launch_osd_wave_t(bposd_handle* h, const OsdParams& P, long long B) {
-    auto k = osd_wave_kernel<RPL, W>;
-    const size_t lds = OSDW_WAVES * osdw_lds_per_wave(osdw_nsort(h->n), RPL, W);
-    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-    int wg_per_cu = 1;
-    { int rc_occ = cached_occupancy(h, (const void*)k, 64 * OSDW_WAVES, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
-    wg_per_cu = std::max(1, std::min(wg_per_cu, 8));
-    long long grid = std::min<long long>((B + OSDW_WAVES - 1) / OSDW_WAVES, (long long)h->num_cu * wg_per_cu);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * OSDW_WAVES), lds, h->osd_now ? h->osd_now : h->cur->osd_stream, P);
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
-// 0 = the code / configuration stays on osd_kernel.  A lone elimination is faster on a workgroup of its own (measured,
-// tools/latency_reference_codes.py: a decode() that needs OSD 1.23 against 1.92 ms on [[900,36,10]], 0.50 / 0.57 ms on
-// [[400,16,6]]); the wave kernel is for throughput, so auto takes it for calls of at least 4096 syndromes.
-int osd_wave_shape(const bposd_handle* h, const OsdParams& P, long long B) {
-    static const bool on = !(getenv("BPOSD_OSD_WAVE") && getenv("BPOSD_OSD_WAVE")[0] == '0');
-    if (!on || h->osd_variant == 1 || P.cost != nullptr || P.dbg != nullptr) return 0;  // switched off; fp64 weights; diagnostics
-    if (h->osd_variant == 0 && std::max<long long>(B, h->batch_hint) < 4096) return 0;
-    if (P.osd_method == BPOSD_OSD_E && P.osd_order > OSDW_MAX_E) return 0;
-    const int m = h->m, n1 = h->n + 1;
-    if (m <= 64 && n1 <= 128) return 1;
-    if (m <= 128 && n1 <= 256) return 2;
-    if (m <= 192 && n1 <= 448) return 3;
-    if (m <= 320 && n1 <= 640) return 4;
-    // seven rows x fifteen words per lane hold 256 VGPRs + 51 AGPRs, one wave per SIMD: slower than one workgroup per
-    // elimination (tools/surface_probe.py, 32 k eliminations: surface d = 21 22.9 against 17.7 ms, [[900,36,10]] 13.5 against
-    // 10.2 ms) -- only when asked for
-    if (m <= 448 && n1 <= 960) return h->osd_variant == 2 ? 5 : 0;
-    return 0;
-}
-
-int launch_osd(bposd_handle* h, const OsdParams& P, long long B) {
-    h->last_osd_kernel = osd_wave_shape(h, P, B) ? 2 : 1;
-    switch (osd_wave_shape(h, P, B)) {
-        case 1: return launch_osd_wave_t<1, 2>(h, P, B);
-        case 2: return launch_osd_wave_t<2, 4>(h, P, B);
-        case 3: return launch_osd_wave_t<3, 7>(h, P, B);
-        case 4: return launch_osd_wave_t<5, 10>(h, P, B);
-        case 5: return launch_osd_wave_t<7, 15>(h, P, B);
-    }
-    switch (osd_words(h->n)) {
-        case 1: return launch_osd_t<1>(h, P, B);
-        case 2: return launch_osd_t<2>(h, P, B);
-        case 4: return launch_osd_t<4>(h, P, B);
-        case 8: return launch_osd_t<8>(h, P, B);
-        case 16: return launch_osd_t<16>(h, P, B);
-        case 31: return launch_osd_t<31>(h, P, B);
-        case 32: return launch_osd_t<32>(h, P, B);
-    }
-    return fail(h, BPOSD_ERR_UNSUPPORTED, "code too large for the register-resident OSD kernel (n=%d)", h->n);
-}
-
-// ------------------------------------------------------------------ large-code OSD launch
-static int osdl_rpt(int m) {
-    for (int r : {2, 4, 8, 16})
-        if (m <= OSDL_NT * r) return r;
-    return 0;
-}
-
-int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_rank_out) {
-    const int RPT = osdl_rpt(h->m);
-    if (!RPT) return fail(h, BPOSD_ERR_UNSUPPORTED, "m=%d beyond the HBM-resident OSD kernel (16384)", h->m);
-    OsdLargeParams Q{};
-    Q.m = h->m; Q.n = h->n; Q.W = (h->n + 1 + 63) / 64;
-    Q.rank = P.rank; Q.osd_method = P.osd_method; Q.osd_order = P.osd_order; Q.tie_policy = P.tie_policy; Q.e_msb_first = P.e_msb_first;
-    Q.nsort = 1;
-    while (Q.nsort < h->n) Q.nsort <<= 1;
-    Q.mrl = OSDL_NT * RPT;
-    Q.synd = P.synd; Q.rp = P.rp; Q.ci = P.ci; Q.llr_ws = P.llr_ws; Q.osd_list = P.osd_list; Q.counters = P.counters;
-    Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.cmp_osd0 = P.cmp_osd0; Q.cmp_osdw = P.cmp_osdw; Q.rank_out = d_rank_out; Q.dbg = P.dbg;
-    // fp64 index-order candidate weights (non-uniform channel) -- only OSD-E / OSD-CS rank candidates
-    const bool fpw = P.cost != nullptr && Q.osd_method >= BPOSD_OSD_E && Q.osd_order > 0;
-    Q.cost = fpw ? P.cost : nullptr; Q.sel = fpw ? P.sel : nullptr; Q.cost_alt = P.cost_alt;
-    Q.wdn = std::max(64 * Q.W, 1 << OSDL_MAXSPAN);
-    long long grid = std::min<long long>(B, h->num_cu);
-    if (grid < 1) grid = 1;
-    auto a256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    // every sub-array is [grid][count], laid out back to back in one allocation
-    const size_t g = (size_t)grid;
-    const bool wide_cs = Q.osd_method == BPOSD_OSD_CS && Q.osd_order > OSDL_MAXSPAN;
-    if (wide_cs && fpw)
-        return fail(h, BPOSD_ERR_UNSUPPORTED, "osd_cs order %d > %d with a non-uniform or per-shot channel is not supported by the HBM-resident "
-                    "OSD kernel (m=%d n=%d)", Q.osd_order, OSDL_MAXSPAN, h->m, h->n);
-    const size_t sizes[15] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
-                             g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
-                             g * sizeof(int) * (size_t)Q.nsort,                    // kidx
-                             g * sizeof(int) * (size_t)h->n,                       // inv
-                             g * sizeof(int) * (size_t)64 * Q.W,                   // pivrow
-                             g * sizeof(int) * (size_t)Q.mrl,                      // rowpos
-                             g * sizeof(int) * (size_t)64 * Q.W,                   // wt
-                             g * (size_t)h->n,                                     // xout
-                             g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.mrl,        // tmo
-                             g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.W * 64,     // pro
-                             fpw ? g * sizeof(double) * (size_t)h->n : 0,                    // costs_ws
-                             fpw ? g * sizeof(double) * (size_t)Q.wdn : 0,                   // wd_ws
-                             fpw ? g * sizeof(unsigned short) * (size_t)Q.mrl : 0,           // am_ws
-                             g * sizeof(int) * (size_t)Q.mrl,                                // alist
-                             wide_cs ? g * sizeof(unsigned long long) * (size_t)OSDL_MAXSPAN_CS * RPT * OSDL_NW : 0};  // colvec_ws
-    size_t total = 0;
-    for (size_t b : sizes) total += a256(b);
-    int rc = ensure_lanes(h, &Lane::osdl_ws, total);
-    if (rc) return rc;
-    unsigned char* ptrs[15];
-    {
-        unsigned char* base = (unsigned char*)h->cur->osdl_ws.p;
-        for (int i = 0; i < 15; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
-    }
-    Q.alist = (int*)ptrs[13];
-    Q.colvec_ws = wide_cs ? (unsigned long long*)ptrs[14] : nullptr;
-    Q.costs_ws = (double*)ptrs[10];
-    Q.wd_ws = (double*)ptrs[11];
-    Q.am_ws = (unsigned short*)ptrs[12];
-    Q.mat = (unsigned long long*)ptrs[0];
-    Q.keys = (unsigned long long*)ptrs[1];
-    Q.kidx = (int*)ptrs[2];
-    Q.inv = (int*)ptrs[3];
-    Q.pivrow = (int*)ptrs[4];
-    Q.rowpos = (int*)ptrs[5];
-    Q.wt = (int*)ptrs[6];
-    Q.xout = (uint8_t*)ptrs[7];
-    Q.tmo = (unsigned long long*)ptrs[8];
-    Q.pro = (unsigned long long*)ptrs[9];
-    const size_t lds = osd_large_lds_bytes(Q.W, RPT, fpw ? h->n : 0);
-    if (lds > h->lds_per_cu) return fail(h, BPOSD_ERR_UNSUPPORTED, "large OSD kernel needs %zu bytes of LDS", lds);
-#define OSDL_LAUNCH(R)                                                                                      \
-    case R: {                                                                                               \
-        auto k = osd_large_kernel<R>;                                                                       \
-        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; } \
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(OSDL_NT), lds, h->osd_now ? h->osd_now : h->cur->osd_stream, Q); \
-    } break;
-    switch (RPT) {
-        OSDL_LAUNCH(2)
-        OSDL_LAUNCH(4)
-        OSDL_LAUNCH(8)
-        OSDL_LAUNCH(16)
-    }
-#undef OSDL_LAUNCH
-    HIP_TRY(h, hipGetLastError());
-    return 0;
-}
-
 // rank of a large code: one elimination of the zero syndrome on the device (the host routine is O(m^2 n / 64))
 int probe_rank_large(bposd_handle* h, int* rank) {
     DevBuf tmp;
@@ -1325,8 +596,7 @@ int num_candidates(const bposd_handle* h) {
     if (h->cfg.osd_method == BPOSD_OSD_E) return (1 << w) - 1;
     return h->kprime + w * (w - 1) / 2;
 }
-
-}  // namespace
+}  // namespace bposd_host
 
 __global__ void pack_rows_kernel(const uint8_t* __restrict__ in, long long B, int n, int wpr,
                                  unsigned long long* __restrict__ out) {
@@ -1388,8 +658,6 @@ void bposd_destroy(bposd_handle* h) {
                     (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
                     (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl,
                     (void*)h->d_cpos_chk, (void*)h->d_cpos_bit, (void*)h->d_cbit_slot, (void*)h->d_cgrp_deg, (void*)h->d_cgrp_cdeg,
-                    (void*)h->d_o_pos_chk, (void*)h->d_o_own_bit, (void*)h->d_o_own_rd, (void*)h->d_o_own_wr, (void*)h->d_o_own_dl,
-                    (void*)h->d_o_x_bit, (void*)h->d_o_x_slot, (void*)h->d_o_x_deg,
                     (void*)h->d_cp, (void*)h->d_ce, (void*)h->d_erow, (void*)h->d_lvl_ptr, (void*)h->d_lvl_bits})
         if (p) (void)hipFree(p);
     for (CallRecord* rs : {h->rec, h->lane_rec})
@@ -1526,12 +794,12 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     if (h->large) {
         h->nlanes = 2;
         if (const char* e = getenv("BPOSD_LARGE_LANES")) h->nlanes = std::max(1, std::min(BPOSD_LANES, atoi(e)));
-        if (n > 32767 || m > 16384 || (h->bp_hbm && bp_large_lds_bytes(m, n) > h->lds_per_cu)) {
+        if (n > 32767 || m > 16384 || (h->bp_hbm && bp_large_lds_need(m, n) > h->lds_per_cu)) {
             fail(nullptr, BPOSD_ERR_UNSUPPORTED, "code too large even for the HBM-resident kernels (m=%d n=%d; limits 16384 / 32767)", m, n);
             bposd_destroy(h);
             return BPOSD_ERR_UNSUPPORTED;
         }
-        const int span_cap = cfg->osd_method == BPOSD_OSD_CS ? OSDL_MAXSPAN_CS : OSDL_MAXSPAN;
+        const int span_cap = osd_large_maxspan(cfg->osd_method == BPOSD_OSD_CS);
         if (cfg->osd_method >= BPOSD_OSD_E && cfg->osd_order > span_cap) {
             fail(nullptr, BPOSD_ERR_UNSUPPORTED,
                  "osd order %d > %d is not supported by the HBM-resident OSD kernel (m=%d n=%d)", cfg->osd_order,
@@ -1586,10 +854,9 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     else CREATE_RC(build_tables(h, pair.dc, pair.dv, shape_threads(h, shp) * shape_cpt(shp), shape_threads(h, shp), 2 * shape_cpt(shp)));
     if (!h->bp_any && !h->bp_hbm && cfg->bp_method == BPOSD_BP_MIN_SUM) CREATE_RC(build_tables_local(h));
     if (!h->bp_any && !h->bp_hbm && (!(h->local_ok && cfg->bp_method == BPOSD_BP_MIN_SUM) || getenv("BPOSD_CLASS_ALWAYS"))) CREATE_RC(build_tables_class(h));
-    // (bp_own_kernel's tables are built when the variant is asked for: bposd_set_bp_variant(h, 48))
     if (cfg->schedule == 1) {
-        if (h->dv_max > BPS_MAXDV) {
-            fail(h, BPOSD_ERR_UNSUPPORTED, "serial schedule: bit degree %d exceeds %d", h->dv_max, BPS_MAXDV);
+        if (h->dv_max > bp_serial_max_dv()) {
+            fail(h, BPOSD_ERR_UNSUPPORTED, "serial schedule: bit degree %d exceeds %d", h->dv_max, bp_serial_max_dv());
             CREATE_RC(BPOSD_ERR_UNSUPPORTED);
         }
         if (!h->bp_any) CREATE_RC(build_tables_serial(h));
@@ -1625,8 +892,8 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32 && variant != 48 && variant != 64)
-        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel), 32 (class kernel), 48 (owned-edge kernel) or 64 (any-degree kernel)");
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32 && variant != 64)
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel), 32 (class kernel) or 64 (any-degree kernel)");
     if (variant == 64 && !h->d_cp) {  // the any-degree kernel as a second implementation for cross-checks: its CSC edge map
         DeviceGuard dev_guard(h->device);
         HIP_TRY(h, dev_guard.err);
@@ -1634,15 +901,6 @@ int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
         if (!rc_any) rc_any = build_tables_serial(h);
         if (rc_any) return rc_any;
     }
-    if (variant == 48 && !h->own_ok) {  // experimental kernel: its layout search (~1-2 s) runs here, not in every constructor
-        DeviceGuard dev_guard(h->device);
-        HIP_TRY(h, dev_guard.err);
-        int rc_own = sync_all_lanes(h);
-        if (!rc_own && !h->local_ok) rc_own = build_tables_own(h);
-        if (rc_own) return rc_own;
-    }
-    if (variant == 48 && !h->own_ok)
-        return fail(h, BPOSD_ERR_UNSUPPORTED, "the owned-edge BP kernel needs min-sum, check degree 7, bit degrees 3 / 4 and a perfect two-bits-per-check matching");
     if (variant == 32 && !h->class_ok)
         return fail(h, BPOSD_ERR_UNSUPPORTED, "the class BP kernel needs one check degree and bit degrees of a compiled range");
     if (variant >= 16 && variant <= 26 && !(h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM))
@@ -1712,9 +970,6 @@ int bposd_bp_kernel_info(bposd_handle* h, int32_t* kernel, int64_t* lds_model) {
         } else if (h->last_bp_kernel == BPOSD_BP_KERNEL_CLASS) {
             lds_model[0] = h->class_read_cycles; lds_model[1] = h->class_read_floor;
             lds_model[2] = h->class_write_cycles; lds_model[3] = h->class_write_floor;
-        } else if (h->last_bp_kernel == BPOSD_BP_KERNEL_OWN) {
-            lds_model[0] = h->own_read_cycles; lds_model[1] = h->own_read_floor;
-            lds_model[2] = h->own_write_cycles; lds_model[3] = h->own_write_floor;
         }
     }
     return BPOSD_OK;
@@ -1797,21 +1052,10 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         if ((rc = launch_bp_any(h, P))) return rc;
     } else if (h->bp_hbm) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_LARGE;
-        BpLargeParams L{};
-        L.m = P.m; L.n = P.n; L.B = P.B; L.max_iter = P.max_iter; L.ms_scaling = P.ms_scaling; L.ps_clip = P.ps_clip;
-        L.osd_enabled = P.osd_enabled; L.mp = h->tab_mp;
-        L.synd = P.synd; L.llr0 = P.llr0; L.sel = P.sel; L.llr0_alt = P.llr0_alt;
-        L.chk_deg = h->d_chk_deg; L.var_deg = h->d_var_deg; L.var_pos = h->d_var_pos;
-        L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv;
-        L.out_iters = P.out_iters; L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list;
-        L.counters = P.counters; L.iter_total = P.iter_total; L.tail_flag = P.tail_flag;
-        if ((rc = launch_bp_large(h, L))) return rc;
+        if ((rc = launch_bp_large(h, P))) return rc;
     } else if (h->local_ok && h->cfg.bp_method == BPOSD_BP_MIN_SUM && (h->bp_variant == 0 || (h->bp_variant >= 16 && h->bp_variant <= 26))) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_LOCAL;
         if ((rc = launch_bp_local(h, P))) return rc;
-    } else if (h->own_ok && h->bp_variant == 48) {
-        h->last_bp_kernel = BPOSD_BP_KERNEL_OWN;
-        if ((rc = launch_bp_own(h, P))) return rc;
     } else if (h->class_ok && (h->bp_variant == 32 || (h->bp_variant == 0 && class_preferred(h)))) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_CLASS;
         if ((rc = launch_bp_class(h, P))) return rc;
@@ -2284,29 +1528,6 @@ int bposd_debug_class_layout(const int32_t* indptr, const int32_t* indices, int3
     if (bit_slot) std::copy(T.bit_slot.begin(), T.bit_slot.end(), bit_slot);  // [DVHI * VPT * MP]
     if (grp_deg) std::copy(T.grp_deg.begin(), T.grp_deg.end(), grp_deg);    // [VPT * MP / 64]
     if (grp_cdeg) std::copy(T.grp_cdeg.begin(), T.grp_cdeg.end(), grp_cdeg);  // [MP / 64]
-    return BPOSD_OK;
-}
-
-int bposd_debug_own_layout(const int32_t* indptr, const int32_t* indices, int32_t m, int32_t n, int32_t* pos_chk, int32_t* own_bit,
-                           int32_t* own_rd, int32_t* own_wr, int32_t* own_dl, int32_t* x_bit, int32_t* x_slot, int32_t* x_deg, int64_t* info) {
-    // host-only: the tables bp_own_kernel would be launched with (tests check their invariants without a GPU).
-    // info[0..9]: DC, MP (= NTMAX), threads per workgroup, zero slot, first private slot, modelled read cycles, their floor,
-    // modelled write cycles, their floor, 0
-    if (!indptr || !indices || !info || m < 1 || n < 1) return BPOSD_ERR_INVALID;
-    std::vector<int> rp(indptr, indptr + m + 1), ci(indices, indices + indptr[m]);
-    for (int e : ci)
-        if (e < 0 || e >= n) return BPOSD_ERR_INVALID;
-    const int dc = rp[1] - rp[0];
-    if (m > 1024) return BPOSD_ERR_UNSUPPORTED;
-    own_layout::Tables T;
-    int mp = 256;
-    while (mp < m) mp *= 2;
-    if (!own_layout::build(rp, ci, m, n, dc, mp, mp, 5000, T)) return BPOSD_ERR_UNSUPPORTED;
-    info[0] = dc; info[1] = T.MP; info[2] = T.NT; info[3] = T.zero_slot; info[4] = T.priv0;
-    info[5] = T.read_cycles; info[6] = T.read_floor; info[7] = T.write_cycles; info[8] = T.write_floor; info[9] = 0;
-    auto put = [](int32_t* dst, const std::vector<int>& v) { if (dst) std::copy(v.begin(), v.end(), dst); };
-    put(pos_chk, T.pos_chk); put(own_bit, T.own_bit); put(own_rd, T.own_rd); put(own_wr, T.own_wr); put(own_dl, T.own_dl);
-    put(x_bit, T.x_bit); put(x_slot, T.x_slot); put(x_deg, T.x_deg);
     return BPOSD_OK;
 }
 

@@ -485,7 +485,7 @@ class BpOsdDecoder:
         _lib.check(self._lib, self._h, self._lib.bposd_layout_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"natural": a.value, "chosen": b.value, "ideal": c.value}
 
-    BP_KERNEL_NAMES = {0: "bp_kernel", 1: "bp_local_kernel", 2: "bp_class_kernel", 3: "bp_large_kernel", 4: "bp_serial_kernel", 5: "bp_anydeg_kernel", 6: "bp_own_kernel"}
+    BP_KERNEL_NAMES = {0: "bp_kernel", 1: "bp_local_kernel", 2: "bp_class_kernel", 3: "bp_large_kernel", 4: "bp_serial_kernel", 5: "bp_anydeg_kernel"}
 
     def bp_kernel_info(self):
         """Which BP kernel the last decode call launched, with the bank-conflict model of its bit pass (modelled LDS
@@ -507,7 +507,7 @@ class BpOsdDecoder:
         return self.OSD_KERNEL_NAMES.get(self._lib.bposd_last_osd_kernel(self._h), "none")
 
     def set_bp_variant(self, variant: int):
-        """Tuning / test knob: 0 auto; 1, 2, 4 LDS kernel shapes; 16 .. 26 local-edge kernel; 32 class kernel; 48 owned-edge kernel (experimental), 64 any-degree kernel (slow; cross-checks) -- see the C header."""
+        """Tuning / test knob: 0 auto; 1, 2, 4 LDS kernel shapes; 16 .. 26 local-edge kernel; 32 class kernel; 64 any-degree kernel (slow; cross-checks) -- see the C header."""
         _lib.check(self._lib, self._h, self._lib.bposd_set_bp_variant(self._h, int(variant)))
 
     # ------------------------------------------------------------------ mutators / attributes

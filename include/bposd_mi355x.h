@@ -24,6 +24,9 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#pragma GCC visibility push(default)
+
 typedef struct bposd_handle bposd_handle;
 
 /* Values of bposd_config fields. */
@@ -195,10 +198,6 @@ int bposd_last_timing(bposd_handle *h, double *bp_ms, double *osd_ms, int64_t *b
 int bposd_info(bposd_handle *h, int32_t *rank, int32_t *num_candidates, int32_t *max_iter,
                int32_t *nnz);
 
-/* Diagnostics: simulated LDS cycles of one bit pass (bank-conflict model) for the natural bit order, the
- * order the library chose, and the conflict-free ideal.  Any pointer may be NULL. */
-int bposd_layout_info(bposd_handle *h, int64_t *natural_cycles, int64_t *chosen_cycles, int64_t *ideal_cycles);
-
 /* BP only: posterior log-likelihood ratios (and, optionally, BP's hard decisions, converge flags and iteration counts) of
  * B host syndromes, without the OSD stage whatever osd_method the handle was created with.  This is what the
  * `log_prob_ratios` attribute of the reference's decoder object holds after a decode (SURVEY.md 8 b); the Python class
@@ -215,49 +214,12 @@ int bposd_posterior_llr(bposd_handle *h, const uint8_t *syndromes, int64_t B, do
 int bposd_set_osd_variant(bposd_handle *h, int32_t variant);
 int bposd_last_osd_kernel(bposd_handle *h);
 
-/* Diagnostics: which BP kernel the last decode call launched, and the bank-conflict model of its bit pass.
- * kernel: BPOSD_BP_KERNEL_*.  lds_model[4] (local-edge and class kernels, else zeros): modelled ds_read_b64 cycles of one
- * bit pass per workgroup, their conflict-free floor, modelled ds_write_b64 cycles, their floor.  Any pointer may be NULL. */
-#define BPOSD_BP_KERNEL_LDS 0    /* bp_kernel: every message in LDS, per-lane degree predicates */
-#define BPOSD_BP_KERNEL_LOCAL 1  /* bp_local_kernel: (3,6)-regular codes, a third of the messages in registers */
-#define BPOSD_BP_KERNEL_CLASS 2  /* bp_class_kernel: one check degree, bits sorted into degree classes */
-#define BPOSD_BP_KERNEL_LARGE 3  /* bp_large_kernel: messages in HBM */
-#define BPOSD_BP_KERNEL_SERIAL 4 /* bp_serial_kernel: schedule = serial */
-#define BPOSD_BP_KERNEL_ANYDEG 5 /* bp_anydeg_kernel: check degree > 16 or bit degree > 8 (run-time degree loops) */
-#define BPOSD_BP_KERNEL_OWN 6    /* bp_own_kernel: every check owns two bits whose edge messages stay in registers */
-int bposd_bp_kernel_info(bposd_handle *h, int32_t *kernel, int64_t *lds_model);
-
-/* Diagnostics, host only (needs no device): the ownership / position layout the local-edge BP kernel would use for a
- * (3,6)-regular pcm with n = 2m.  out[16]: modelled ds_read_b64 cycles of one bit pass, their conflict-free
- * floor, positions in select-free (uniform) groups, mixed (group, slot) pairs, positions, nine class sizes, modelled
- * ds_write_b64 cycles of one bit pass, their floor. */
-int bposd_debug_local_layout(const int32_t *csr_indptr, const int32_t *csr_indices, int32_t m, int32_t n, int64_t *out);
-
-/* Diagnostics, host only: the tables bp_class_kernel would run with for a pcm whose check and bit degrees fall inside one
- * compiled instance -- (check degrees; bit degrees) = (7; 3..4), (6; 3), (4; 2), (8; 4), (3..4; 1..2) -- and
- * BPOSD_ERR_UNSUPPORTED otherwise.  info[11]: highest check degree, lowest / highest bit degree, bit slots per thread, LDS
- * stride MP, threads per workgroup, modelled read cycles of one bit pass and their floor, modelled write cycles and their
- * floor, lowest check degree.  Nullable outputs: pos_chk [MP], pos_bit [slots * MP], bit_slot [DVHI * slots * MP],
- * grp_deg [slots * MP / 64], grp_cdeg [MP / 64] -- callers size them for MP = 1024, 2 slots, DVHI = 4. */
-int bposd_debug_class_layout(const int32_t *csr_indptr, const int32_t *csr_indices, int32_t m, int32_t n, int32_t *pos_chk,
-                             int32_t *pos_bit, int32_t *bit_slot, int32_t *grp_deg, int32_t *grp_cdeg, int64_t *info);
-
-/* Diagnostics, host only: the tables bp_own_kernel (variant 48) would run with -- one check degree, bit degrees 3 / 4, a
- * perfect two-bits-per-check matching; BPOSD_ERR_UNSUPPORTED otherwise.  info[10]: check degree, LDS stride MP (= table
- * stride), threads per workgroup, zero slot, first private slot, modelled read cycles of one bit pass and their floor,
- * modelled write cycles and their floor, 0.  Nullable outputs sized for MP = 1024: pos_chk [MP], own_bit [2 MP],
- * own_rd [6 MP], own_wr [2 MP], own_dl [2 MP], x_bit [MP], x_slot [4 MP], x_deg [MP / 64]. */
-int bposd_debug_own_layout(const int32_t *csr_indptr, const int32_t *csr_indices, int32_t m, int32_t n, int32_t *pos_chk,
-                           int32_t *own_bit, int32_t *own_rd, int32_t *own_wr, int32_t *own_dl, int32_t *x_bit, int32_t *x_slot,
-                           int32_t *x_deg, int64_t *info);
-
 /* Tuning knob (not part of the reference surface): which BP kernel / workgroup shape runs.
  * 0 = auto; 1, 2, 4 = LDS kernel with 1 / 2 / 4 checks per thread; 16, 17, 18 = local-edge kernel (a third of the
  * messages in registers; (3,6)-regular codes with n = 2m and min-sum only, BPOSD_ERR_UNSUPPORTED otherwise):
  * 2 checks per thread at <= 80 / <= 64 VGPRs, 1 check per thread.  Auto picks 16 where it applies.  All variants
  * return identical results.  32 = class kernel (one check degree, bit degrees of a compiled range; auto picks it where it
- * applies and the local-edge kernel does not).  48 = owned-edge kernel (experimental, never picked by auto: check degree
- * 7, bit degrees 3 / 4, min-sum; its layout search runs in this call).  64 = the any-degree kernel on any code (slow; a
+ * applies and the local-edge kernel does not).  64 = the any-degree kernel on any code (slow; a
  * second implementation for cross-checks, also of the HBM-resident BP kernel). */
 int bposd_set_bp_variant(bposd_handle *h, int32_t variant);
 
@@ -265,6 +227,8 @@ int bposd_set_bp_variant(bposd_handle *h, int32_t variant);
 const char *bposd_last_error(bposd_handle *h);
 
 void bposd_destroy(bposd_handle *h);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -20,14 +20,24 @@ def lib():
     return _lib.load()
 
 
-def test_library_exports_every_header_symbol(lib):
-    hdr = open(os.path.join(ROOT, "include", "bposd_mi355x.h")).read()
+@pytest.mark.parametrize("header,symbols", [("bposd_mi355x.h", "EXPORTED_SYMBOLS"), ("bposd_mi355x_debug.h", "DEBUG_SYMBOLS")])
+def test_library_exports_every_header_symbol(lib, header, symbols):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # strip comments
     declared = set(re.findall(r"\b(bposd_[a-z_0-9]+)\s*\(", code))
-    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert declared == set(getattr(_lib, symbols)), declared ^ set(getattr(_lib, symbols))
     for sym in declared:
         assert getattr(lib, sym) is not None
     assert b"gfx950" in lib.bposd_version()
+
+
+def test_library_exports_nothing_else(lib):
+    """Built with -fvisibility=hidden: the dynamic symbol table holds the two headers' functions (and HIP kernel handles)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T"}
+    assert funcs == set(_lib.EXPORTED_SYMBOLS) | set(_lib.DEBUG_SYMBOLS), funcs ^ (set(_lib.EXPORTED_SYMBOLS) | set(_lib.DEBUG_SYMBOLS))
 
 
 def test_config_struct_layout_matches_header():
@@ -189,83 +199,6 @@ def test_class_kernel_tables_are_consistent(lib, seed_file):
                 seen.add(int(bs[d, r, t]))
     assert len(seen) == H.nnz
     assert info[6] <= 2.1 * info[7] and info[8] <= 1.3 * info[9]
-
-
-@pytest.mark.parametrize("seed_file", ["mkmn_16_4_6.txt", "mkmn_20_5_8.txt", "mkmn_24_6_10.txt"])
-def test_own_kernel_tables_are_consistent(lib, seed_file):
-    """Host-side tables of bp_own_kernel (no GPU needed): every check sits at one position and owns exactly two of its own
-    neighbour bits, no bit has two owners, the unowned bits sit in one degree group per wave; an owned bit's other edges
-    are listed in ascending check order at the LDS slots (edge number - 2) * MP + position of that check, where a check's
-    owned bits are its edges 0 and 1 and the rest follow in ascending bit order; dl is the owner's rank among the bit's
-    checks; a degree-3 bit reads the zero slot and writes a private slot for its absent third edge; every LDS edge of the
-    code appears exactly once."""
-    import os
-
-    from bp_osd_amd.codes import hgp
-
-    seed = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", seed_file)).astype(np.uint8)
-    ip, ix, H = _csr32(hgp(seed, compute_logicals=False).hz)
-    m, n = H.shape
-    MPmax = 1024
-    a = {k: np.full(c * MPmax, -7, np.int32) for k, c in (("pos_chk", 1), ("own_bit", 2), ("own_rd", 6), ("own_wr", 2), ("own_dl", 2), ("x_bit", 1), ("x_slot", 4))}
-    x_deg = np.full(MPmax // 64, -7, np.int32)
-    info = np.zeros(10, np.int64)
-    rc = lib.bposd_debug_own_layout(ip.ctypes.data, ix.ctypes.data, m, n, a["pos_chk"].ctypes.data, a["own_bit"].ctypes.data, a["own_rd"].ctypes.data,
-                                    a["own_wr"].ctypes.data, a["own_dl"].ctypes.data, a["x_bit"].ctypes.data, a["x_slot"].ctypes.data,
-                                    x_deg.ctypes.data, info.ctypes.data)
-    assert rc == 0
-    DC, MP, NT, zero, priv0 = (int(x) for x in info[:5])
-    assert DC == 7 and MP >= m and NT % 64 == 0 and NT <= MP and zero == (DC - 2) * MP and priv0 == zero + 2
-    pc = a["pos_chk"][:MP]
-    assert sorted(pc[pc >= 0].tolist()) == list(range(m))
-    pos_of = np.empty(m, int)
-    pos_of[pc[pc >= 0]] = np.flatnonzero(pc >= 0)
-    ob = a["own_bit"][:2 * MP].reshape(2, MP)
-    rd = a["own_rd"][:6 * MP].reshape(2, 3, MP)
-    wr = a["own_wr"][:2 * MP].reshape(2, MP)
-    dl = a["own_dl"][:2 * MP].reshape(2, MP)
-    xb = a["x_bit"][:MP]
-    xs = a["x_slot"][:4 * MP].reshape(4, MP)
-    Hc = H.tocsc()
-    owner = {}
-    for t in np.flatnonzero(pc >= 0):
-        c = int(pc[t])
-        row = H.indices[H.indptr[c]:H.indptr[c + 1]]
-        assert ob[0, t] >= 0 and ob[1, t] >= 0 and ob[0, t] != ob[1, t] and ob[0, t] in row and ob[1, t] in row
-        for r in range(2):
-            assert int(ob[r, t]) not in owner
-            owner[int(ob[r, t])] = c
-    assert (ob[:, pc < 0] < 0).all()
-    unowned = sorted(set(range(n)) - set(owner))
-    assert sorted(xb[xb >= 0].tolist()) == unowned and len(owner) == 2 * m
-
-    def edge_slot(c, i):  # LDS slot of the (unowned) edge (c, i)
-        row = [b for b in H.indices[H.indptr[c]:H.indptr[c + 1]] if owner.get(int(b)) != c]
-        return row.index(i) * MP + pos_of[c]
-
-    seen = []
-    for t in np.flatnonzero(pc >= 0):
-        c = int(pc[t])
-        for r in range(2):
-            i = int(ob[r, t])
-            checks = sorted(Hc.indices[Hc.indptr[i]:Hc.indptr[i + 1]].tolist())
-            assert dl[r, t] == checks.index(c)
-            others = [c2 for c2 in checks if c2 != c]
-            for j, c2 in enumerate(others):
-                assert rd[r, j, t] == edge_slot(c2, i)
-                seen.append(int(rd[r, j, t]))
-            if len(others) == 3:
-                assert wr[r, t] == rd[r, 2, t]
-            else:
-                assert rd[r, 2, t] == zero and wr[r, t] >= priv0
-    for t in np.flatnonzero(xb >= 0):
-        i = int(xb[t])
-        checks = sorted(Hc.indices[Hc.indptr[i]:Hc.indptr[i + 1]].tolist())
-        assert x_deg[t // 64] == len(checks)
-        for d, c2 in enumerate(checks):
-            assert xs[d, t] == edge_slot(c2, i)
-            seen.append(int(xs[d, t]))
-    assert len(seen) == len(set(seen)) == H.nnz - 2 * m and max(seen) < zero
 
 
 def test_local_edge_layout_model_regression(lib):
