@@ -21,7 +21,9 @@
 #include <tuple>
 #include <functional>
 #include <map>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "internal.h"
@@ -614,6 +616,41 @@ __global__ void pack_rows_kernel(const uint8_t* __restrict__ in, long long B, in
     }
 }
 
+// the inverse: B rows of wpr little-endian 64-bit words -> B rows of n 0/1 bytes (the form the decode kernels read)
+__global__ void unpack_rows_kernel(const unsigned long long* __restrict__ in, long long B, int n, int wpr, uint8_t* __restrict__ out) {
+    const long long total = B * (long long)n;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const long long b = e / n;
+        const int i = (int)(e - b * n);
+        out[e] = (uint8_t)((in[b * wpr + (i >> 6)] >> (i & 63)) & 1ull);
+    }
+}
+
+namespace {
+
+int launch_pack(bposd_handle* h, hipStream_t st, const uint8_t* d_bytes, long long B, int n, unsigned long long* d_words) {
+    if (B <= 0) return 0;
+    const int wpr = (n + 63) / 64, threads = 256;
+    const long long want = ((long long)B * wpr * 64 + threads - 1) / threads;
+    const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 16);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(threads), 0, st, d_bytes, B, n, wpr, d_words);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+int launch_unpack(bposd_handle* h, hipStream_t st, const unsigned long long* d_words, long long B, int n, uint8_t* d_bytes) {
+    if (B <= 0) return 0;
+    const int wpr = (n + 63) / 64, threads = 256;
+    const long long want = ((long long)B * n + threads - 1) / threads;
+    const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 16);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid), dim3(threads), 0, st, d_words, B, n, wpr, d_bytes);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
 // ================================================================================ C-ABI
 extern "C" {
 
@@ -635,7 +672,7 @@ void bposd_destroy(bposd_handle* h) {
         if (l.h_list) (void)hipHostFree(l.h_list);
         if (l.ev_copy) (void)hipEventDestroy(l.ev_copy);
         if (l.copy_stream) (void)hipStreamDestroy(l.copy_stream);
-        for (DevBuf* b : {&l.io_cmp0, &l.io_cmpw}) release(*b);
+        for (DevBuf* b : {&l.io_cmp0, &l.io_cmpw, &l.io_psynd, &l.io_posdw, &l.io_posd0, &l.io_pbp, &l.io_pcmp}) release(*b);
         for (DevBuf* b : {&l.bpl_msg, &l.bpl_llr, &l.osdl_ws, &l.io_sel, &l.osd_rows_ws, &l.llr_ws, &l.osd_list, &l.io_synd, &l.io_osdw,
                           &l.io_osd0, &l.io_bp, &l.io_conv, &l.io_iters, &l.io_llr})
             release(*b);
@@ -1190,11 +1227,17 @@ int bposd_decode_batch_select_device(bposd_handle* h, const uint8_t* d_synd, int
 }
 
 static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, const uint8_t* sel, uint8_t* osdw,
-                            uint8_t* osd0, uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr);
+                            uint8_t* osd0, uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr, bool packed = false);
 
 int bposd_decode_batch(bposd_handle* h, const uint8_t* synd, int64_t B, uint8_t* osdw, uint8_t* osd0,
                        uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr) {
     return decode_host_impl(h, synd, B, nullptr, osdw, osd0, bp, conv, iters, llr);
+}
+
+int bposd_decode_batch_packed(bposd_handle* h, const uint64_t* synd_words, int64_t B, uint64_t* osdw_words, uint64_t* osd0_words,
+                              uint64_t* bp_words, uint8_t* conv, int32_t* iters) {
+    return decode_host_impl(h, (const uint8_t*)synd_words, B, nullptr, (uint8_t*)osdw_words, (uint8_t*)osd0_words, (uint8_t*)bp_words,
+                            conv, iters, nullptr, /*packed=*/true);
 }
 
 int bposd_posterior_llr(bposd_handle* h, const uint8_t* synd, int64_t B, double* llr, uint8_t* bp, uint8_t* conv, int32_t* iters) {
@@ -1224,8 +1267,22 @@ int bposd_decode_batch_select(bposd_handle* h, const uint8_t* synd, int64_t B, c
 // (upload, BP, OSD, downloads), so a lane's staging buffers are reused safely two chunks later.  Page-locked host
 // buffers (bposd_host_alloc) make the copies asynchronous; with pageable memory the host thread blocks inside each
 // copy while the other lane's kernels keep running.
+// (inside the chunk loop: what has been enqueued is drained before an error is returned -- downloads into the caller's
+// buffers, or into a buffer local to a caller of this function, may be in flight)
+#define HIP_TRY_DRAIN(h, expr)                                                                 \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (void)sync_all_lanes(h);                                                           \
+            return fail(h, BPOSD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                      \
+    } while (0)
+
+// packed: synd / osdw / osd0 / bp are rows of ceil(m / 64) resp. ceil(n / 64) little-endian 64-bit words (bit i & 63 of
+// word i >> 6 = entry i) -- one eighth of the bytes over PCIe; the device unpacks the syndromes in front of the BP kernel and
+// packs the result rows behind it (sel and llr are not offered in this form).
 static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, const uint8_t* sel, uint8_t* osdw,
-                            uint8_t* osd0, uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr) {
+                            uint8_t* osd0, uint8_t* bp, uint8_t* conv, int32_t* iters, double* llr, bool packed) {
     if (!h) return BPOSD_ERR_INVALID;
     if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
     if (B == 0) return BPOSD_OK;
@@ -1245,7 +1302,7 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
                      o_osd0 = o_osdw + a64(b8 * n8), o_bp = o_osd0 + (osd0 ? a64(b8 * n8) : 0),
                      o_conv = o_bp + (bp ? a64(b8 * n8) : 0), o_it = o_conv + a64(b8), o_llr = o_it + a64(b8 * 4),
                      total = o_llr + (llr ? a64(b8 * n8 * 8) : 0);
-        if (zero_copy && total <= (size_t)1 << 20) {
+        if (zero_copy && !packed && total <= (size_t)1 << 20) {
             Lane& L = h->lanes[0];
             h->cur = &L;
             if (L.h_stage_bytes < total) {
@@ -1301,10 +1358,11 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     struct HintScope { bposd_handle* h; ~HintScope() { h->batch_hint = 0; } } hint_scope{h};
     h->batch_hint = B;  // kernel variants are chosen for the call, not for a chunk
     const size_t n = (size_t)h->n, m = (size_t)h->m;
+    const size_t rsn = packed ? (n + 63) / 64 * 8 : n, rsm = packed ? (m + 63) / 64 * 8 : m;  // host row strides in bytes
     int rc;
     static const bool gate_env = !(getenv("BPOSD_HOST_GATE") && getenv("BPOSD_HOST_GATE")[0] == '0');
     const bool gate = gate_env && nchunks > 1 && h->cfg.schedule == 0;  // (the serial-schedule kernel does not report its tail)
-    const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF;
+    const bool osd_on = h->cfg.osd_method != BPOSD_OSD_OFF && !h->bp_only;  // (bposd_posterior_llr: no OSD stage, no OSD list)
     // rows of chunk c that the OSD kernel rewrote: from the compact copies into the caller's arrays (the lane is idle)
     auto patch_osd_rows = [&](int c) -> int {
         Lane& L = h->lanes[c % h->nlanes];
@@ -1315,12 +1373,20 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         const long long lo = clo[c];
         const int count = h->rec[c].h_counters[1];
         if (count <= 0) return 0;
-        std::vector<uint8_t> rows((size_t)count * n);
+        std::vector<uint8_t> rows((size_t)count * rsn);
         for (int which = 0; which < 2; ++which) {
             uint8_t* dst = which ? osd0 : osdw;
             if (!dst) continue;
-            HIP_TRY(h, hipMemcpy(rows.data(), which ? L.io_cmp0.p : L.io_cmpw.p, rows.size(), hipMemcpyDeviceToHost));
-            for (int k = 0; k < count; ++k) memcpy(dst + ((size_t)lo + (size_t)L.h_list[k]) * n, rows.data() + (size_t)k * n, n);
+            const void* src = which ? L.io_cmp0.p : L.io_cmpw.p;
+            if (packed) {  // the compact rows, packed on the (idle) lane's stream
+                int rcp = launch_pack(h, L.stream, (const uint8_t*)src, count, (int)n, (unsigned long long*)L.io_pcmp.p);
+                if (rcp) return rcp;
+                HIP_TRY(h, hipMemcpyAsync(rows.data(), L.io_pcmp.p, rows.size(), hipMemcpyDeviceToHost, L.stream));
+                HIP_TRY(h, hipStreamSynchronize(L.stream));
+            } else {
+                HIP_TRY(h, hipMemcpy(rows.data(), src, rows.size(), hipMemcpyDeviceToHost));
+            }
+            for (int k = 0; k < count; ++k) memcpy(dst + ((size_t)lo + (size_t)L.h_list[k]) * rsn, rows.data() + (size_t)k * rsn, rsn);
         }
         return 0;
     };
@@ -1332,36 +1398,63 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         h->cur = &L;
         const size_t bn = (size_t)cnt * n, bm = (size_t)cnt * m;
         if (c >= h->nlanes && (rc = patch_osd_rows(c - h->nlanes))) { (void)sync_all_lanes(h); return rc; }  // the lane's previous chunk
-        if ((rc = ensure(h, L.io_synd, (size_t)CH * m))) return rc;
-        if ((rc = ensure(h, L.io_osdw, (size_t)CH * n))) return rc;
-        if (osd0 && (rc = ensure(h, L.io_osd0, (size_t)CH * n))) return rc;
-        if (bp && (rc = ensure(h, L.io_bp, (size_t)CH * n))) return rc;
-        if (conv && (rc = ensure(h, L.io_conv, (size_t)CH))) return rc;
-        if (iters && (rc = ensure(h, L.io_iters, sizeof(int) * (size_t)CH))) return rc;
-        if (llr && (rc = ensure(h, L.io_llr, sizeof(double) * (size_t)CH * n))) return rc;
+        if ((rc = ensure(h, L.io_synd, (size_t)CH * m))) { (void)sync_all_lanes(h); return rc; }
+        if ((rc = ensure(h, L.io_osdw, (size_t)CH * n))) { (void)sync_all_lanes(h); return rc; }
+        if (osd0 && (rc = ensure(h, L.io_osd0, (size_t)CH * n))) { (void)sync_all_lanes(h); return rc; }
+        if (bp && (rc = ensure(h, L.io_bp, (size_t)CH * n))) { (void)sync_all_lanes(h); return rc; }
+        if (conv && (rc = ensure(h, L.io_conv, (size_t)CH))) { (void)sync_all_lanes(h); return rc; }
+        if (iters && (rc = ensure(h, L.io_iters, sizeof(int) * (size_t)CH))) { (void)sync_all_lanes(h); return rc; }
+        if (llr && (rc = ensure(h, L.io_llr, sizeof(double) * (size_t)CH * n))) { (void)sync_all_lanes(h); return rc; }
         if (osd_on) {
-            if ((rc = ensure(h, L.io_cmpw, (size_t)CH * n))) return rc;
-            if (osd0 && (rc = ensure(h, L.io_cmp0, (size_t)CH * n))) return rc;
+            if ((rc = ensure(h, L.io_cmpw, (size_t)CH * n))) { (void)sync_all_lanes(h); return rc; }
+            if (osd0 && (rc = ensure(h, L.io_cmp0, (size_t)CH * n))) { (void)sync_all_lanes(h); return rc; }
             if (L.h_list_cap < (size_t)CH) {
                 if (L.h_list) (void)hipHostFree(L.h_list);
                 L.h_list = nullptr; L.h_list_cap = 0;
-                HIP_TRY(h, hipHostMalloc((void**)&L.h_list, sizeof(int) * (size_t)CH, hipHostMallocDefault));
+                HIP_TRY_DRAIN(h, hipHostMalloc((void**)&L.h_list, sizeof(int) * (size_t)CH, hipHostMallocDefault));
                 L.h_list_cap = (size_t)CH;
             }
         }
-        if (c > 0) HIP_TRY(h, hipStreamWaitEvent(L.stream, h->lanes[(c - 1) % h->nlanes].ev_up, 0));
-        HIP_TRY(h, hipMemcpyAsync(L.io_synd.p, synd + (size_t)lo * m, bm, hipMemcpyHostToDevice, L.stream));
-        if (sel) {
-            if ((rc = ensure(h, L.io_sel, (size_t)CH * n))) return rc;
-            HIP_TRY(h, hipMemcpyAsync(L.io_sel.p, sel + (size_t)lo * n, bn, hipMemcpyHostToDevice, L.stream));
+        if (c > 0) HIP_TRY_DRAIN(h, hipStreamWaitEvent(L.stream, h->lanes[(c - 1) % h->nlanes].ev_up, 0));
+        if (packed) {
+            if ((rc = ensure(h, L.io_psynd, (size_t)CH * rsm))) { (void)sync_all_lanes(h); return rc; }
+            if ((rc = ensure(h, L.io_posdw, (size_t)CH * rsn))) { (void)sync_all_lanes(h); return rc; }
+            if (osd0 && (rc = ensure(h, L.io_posd0, (size_t)CH * rsn))) { (void)sync_all_lanes(h); return rc; }
+            if (bp && (rc = ensure(h, L.io_pbp, (size_t)CH * rsn))) { (void)sync_all_lanes(h); return rc; }
+            if (osd_on && (rc = ensure(h, L.io_pcmp, (size_t)CH * rsn))) { (void)sync_all_lanes(h); return rc; }
+            HIP_TRY_DRAIN(h, hipMemcpyAsync(L.io_psynd.p, synd + (size_t)lo * rsm, (size_t)cnt * rsm, hipMemcpyHostToDevice, L.stream));
+        } else {
+            HIP_TRY_DRAIN(h, hipMemcpyAsync(L.io_synd.p, synd + (size_t)lo * m, bm, hipMemcpyHostToDevice, L.stream));
         }
-        HIP_TRY(h, hipEventRecord(L.ev_up, L.stream));
+        if (sel) {
+            if ((rc = ensure(h, L.io_sel, (size_t)CH * n))) { (void)sync_all_lanes(h); return rc; }
+            HIP_TRY_DRAIN(h, hipMemcpyAsync(L.io_sel.p, sel + (size_t)lo * n, bn, hipMemcpyHostToDevice, L.stream));
+        }
+        HIP_TRY_DRAIN(h, hipEventRecord(L.ev_up, L.stream));
+        if (packed && (rc = launch_unpack(h, L.stream, (const unsigned long long*)L.io_psynd.p, cnt, (int)m, (uint8_t*)L.io_synd.p))) {
+            (void)sync_all_lanes(h);
+            return rc;
+        }
         // Chunk c's kernels are released when chunk c - 1's BP kernel has handed out its last syndrome (its tail begins; the
         // flag is written by that kernel into page-locked memory) or has ended: the chunks then run in order, each filling
         // the previous one's tail, instead of sharing the CUs from the start and all finishing at the end of the call.
         if (c > 0 && gate) {
             Lane& Pv = h->lanes[(c - 1) % h->nlanes];
-            while (*(volatile int*)Pv.h_tail == 0 && hipEventQuery(Pv.ev_bp) == hipErrorNotReady) {}
+            // poll the flag (a plain load from page-locked memory); the runtime is asked only every so often and the
+            // thread backs off after a short spin -- a chunk's BP kernel runs for milliseconds
+            hipError_t qe = hipErrorNotReady;
+            for (unsigned spins = 0; *(volatile int*)Pv.h_tail == 0; ++spins) {
+                if ((spins & 63) == 63) {
+                    qe = hipEventQuery(Pv.ev_bp);
+                    if (qe != hipErrorNotReady) break;
+                }
+                if (spins < 2000) __builtin_ia32_pause();
+                else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            if (qe != hipErrorNotReady && qe != hipSuccess) {
+                (void)sync_all_lanes(h);
+                return fail(h, BPOSD_ERR_HIP, "hipEventQuery failed while waiting for chunk %d: %s", c - 1, hipGetErrorString(qe));
+            }
         }
         *(volatile int*)L.h_tail = 0;
         h->tail_gate = true;  // (also makes the call record ev_bp, which the downloads below wait for)
@@ -1379,14 +1472,25 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         // on the lane's stream, as in the first version, a chunk's downloads started a whole chunk late: the OSD kernel
         // needs a drained CU and the next chunk's persistent BP workgroups take every slot that frees up.)
         hipStream_t cs = L.copy_stream;
-        HIP_TRY(h, hipStreamWaitEvent(cs, L.ev_bp, 0));
-        HIP_TRY(h, hipMemcpyAsync(osdw + (size_t)lo * n, L.io_osdw.p, bn, hipMemcpyDeviceToHost, cs));
-        if (osd0) HIP_TRY(h, hipMemcpyAsync(osd0 + (size_t)lo * n, L.io_osd0.p, bn, hipMemcpyDeviceToHost, cs));
-        if (bp) HIP_TRY(h, hipMemcpyAsync(bp + (size_t)lo * n, L.io_bp.p, bn, hipMemcpyDeviceToHost, cs));
-        if (conv) HIP_TRY(h, hipMemcpyAsync(conv + lo, L.io_conv.p, (size_t)cnt, hipMemcpyDeviceToHost, cs));
-        if (iters) HIP_TRY(h, hipMemcpyAsync(iters + lo, L.io_iters.p, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, cs));
-        if (llr) HIP_TRY(h, hipMemcpyAsync(llr + (size_t)lo * n, L.io_llr.p, sizeof(double) * bn, hipMemcpyDeviceToHost, cs));
-        if (osd_on) HIP_TRY(h, hipMemcpyAsync(L.h_list, L.osd_list.p, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, cs));
+        HIP_TRY_DRAIN(h, hipStreamWaitEvent(cs, L.ev_bp, 0));
+        if (packed) {
+            // (the pack kernels wait for a free workgroup slot like any kernel: with the next chunk's persistent BP grid
+            // resident that is that chunk's tail -- the rows then leave one eighth as large)
+            struct { uint8_t* host; const DevBuf* bytes; const DevBuf* words; } outs[3] = {{osdw, &L.io_osdw, &L.io_posdw}, {osd0, &L.io_osd0, &L.io_posd0}, {bp, &L.io_bp, &L.io_pbp}};
+            for (auto& o : outs) {
+                if (!o.host) continue;
+                if ((rc = launch_pack(h, cs, (const uint8_t*)o.bytes->p, cnt, (int)n, (unsigned long long*)o.words->p))) { (void)sync_all_lanes(h); return rc; }
+                HIP_TRY_DRAIN(h, hipMemcpyAsync(o.host + (size_t)lo * rsn, o.words->p, (size_t)cnt * rsn, hipMemcpyDeviceToHost, cs));
+            }
+        } else {
+            HIP_TRY_DRAIN(h, hipMemcpyAsync(osdw + (size_t)lo * n, L.io_osdw.p, bn, hipMemcpyDeviceToHost, cs));
+            if (osd0) HIP_TRY_DRAIN(h, hipMemcpyAsync(osd0 + (size_t)lo * n, L.io_osd0.p, bn, hipMemcpyDeviceToHost, cs));
+            if (bp) HIP_TRY_DRAIN(h, hipMemcpyAsync(bp + (size_t)lo * n, L.io_bp.p, bn, hipMemcpyDeviceToHost, cs));
+        }
+        if (conv) HIP_TRY_DRAIN(h, hipMemcpyAsync(conv + lo, L.io_conv.p, (size_t)cnt, hipMemcpyDeviceToHost, cs));
+        if (iters) HIP_TRY_DRAIN(h, hipMemcpyAsync(iters + lo, L.io_iters.p, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, cs));
+        if (llr) HIP_TRY_DRAIN(h, hipMemcpyAsync(llr + (size_t)lo * n, L.io_llr.p, sizeof(double) * bn, hipMemcpyDeviceToHost, cs));
+        if (osd_on) HIP_TRY_DRAIN(h, hipMemcpyAsync(L.h_list, L.osd_list.p, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, cs));
         L.copy_pending = true;
     }
     for (int c = std::max(0, nchunks - h->nlanes); c < nchunks; ++c)

@@ -45,6 +45,8 @@ struct Lane {
     // host-pointer calls: the outputs are downloaded on a copy stream of the lane's own right after the BP kernel (event-
     // ordered), the rows the OSD kernel rewrites come from compact copies [list slot][n] once it has run
     DevBuf io_cmp0, io_cmpw;
+    // bit-packed host I/O (bposd_decode_batch_packed): packed syndromes in, packed rows out, packed compact OSD rows
+    DevBuf io_psynd, io_posdw, io_posd0, io_pbp, io_pcmp;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copy = nullptr;    // the chunk's downloads have left the lane's io buffers
     int* h_list = nullptr;           // page-locked copy of the chunk's OSD list (syndrome index per slot)

@@ -179,17 +179,88 @@ class BpOsdDecoder:
             self._h = None
 
     # ------------------------------------------------------------------ decode
+    @staticmethod
+    def pack_rows(rows):
+        """uint8 0/1 rows [B, k] -> uint64 [B, ceil(k/64)]: bit (i & 63) of word (i >> 6) = entry i (the C-ABI's packed form)."""
+        a = np.ascontiguousarray(rows, dtype=np.uint8)
+        by = np.packbits(a, axis=1, bitorder="little")
+        w = (a.shape[1] + 63) // 64
+        out = np.zeros((a.shape[0], 8 * w), np.uint8)
+        out[:, :by.shape[1]] = by
+        return out.view("<u8")
+
+    @staticmethod
+    def unpack_rows(words, k):
+        """The inverse of :meth:`pack_rows`: uint64 [B, ceil(k/64)] -> uint8 [B, k]."""
+        w = np.ascontiguousarray(words, dtype="<u8")
+        return np.unpackbits(w.view(np.uint8), axis=1, bitorder="little")[:, :k]
+
+    def _decode_batch_packed(self, syndromes, want_osd0, want_bp):
+        """``decode_batch(..., packed=True)``: bit-packed rows across the host-device boundary (``bposd_decode_batch_packed``)."""
+        s = np.asarray(syndromes)
+        wm, wn = (self.m + 63) // 64, (self.n + 63) // 64
+        if s.ndim == 2 and s.dtype == np.uint64 and s.shape[1] == wm:
+            sw = np.ascontiguousarray(s)
+        elif s.ndim == 2 and s.shape[1] == self.m:
+            sw = self.pack_rows((s.astype(np.int64) & 1).astype(np.uint8) if s.dtype != np.uint8 else (s & 1))
+        else:
+            raise ValueError(f"packed decode takes syndromes of shape (B, {self.m}) or uint64 words of shape (B, {wm}). Not {s.shape}.")
+        B = sw.shape[0]
+        self.batch_osd0 = self.batch_bp = self.batch_llr = self.batch_osdw = None
+        osdw = np.empty((B, wn), np.uint64)
+        osd0 = np.empty((B, wn), np.uint64) if want_osd0 else None
+        bp = np.empty((B, wn), np.uint64) if want_bp else None
+        conv = np.empty(B, np.uint8)
+        iters = np.empty(B, np.int32)
+        self.decode_batch_packed_into(sw, osdw, osd0, bp, conv, iters)
+        self.batch_converge = conv.astype(bool)
+        self.batch_iter = iters
+        self.batch_osd0, self.batch_bp, self.batch_osdw = osd0, bp, osdw
+        return osdw
+
+    def decode_batch_packed_into(self, syndrome_words, osdw_words, osd0_words=None, bp_words=None, converged=None, iters=None):
+        """Host-pointer decode of bit-packed rows into caller-owned C-contiguous arrays: ``uint64 [B, ceil(m/64)]`` in,
+        ``uint64 [B, ceil(n/64)]`` out (page-locked arrays from :meth:`pinned_empty` make the copies asynchronous)."""
+        self._timing_override = None
+        wm, wn = (self.m + 63) // 64, (self.n + 63) // 64
+        s = syndrome_words
+        if s.dtype != np.uint64 or s.ndim != 2 or s.shape[1] != wm or not s.flags.c_contiguous:
+            raise ValueError(f"syndrome_words must be a C-contiguous uint64 array of shape (B, {wm})")
+        B = s.shape[0]
+        for name, a, dt, shp in (("osdw_words", osdw_words, np.uint64, (B, wn)), ("osd0_words", osd0_words, np.uint64, (B, wn)),
+                                 ("bp_words", bp_words, np.uint64, (B, wn)), ("converged", converged, np.uint8, (B,)),
+                                 ("iters", iters, np.int32, (B,))):
+            if a is None:
+                if name == "osdw_words":
+                    raise ValueError("osdw_words is required")
+                continue
+            if a.dtype != dt or a.shape != shp or not a.flags.c_contiguous:
+                raise ValueError(f"{name} must be a C-contiguous {np.dtype(dt).name} array of shape {shp}")
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        rc = self._lib.bposd_decode_batch_packed(self._h, s.ctypes.data, B, ptr(osdw_words), ptr(osd0_words), ptr(bp_words),
+                                                 ptr(converged), ptr(iters)) if B else 0
+        _lib.check(self._lib, self._h, rc)
+        return osdw_words
+
     def decode_batch(self, syndromes, want_osd0=True, want_bp=True, want_llr=False, prior_select=None,
-                     alt_channel_probs=None):
+                     alt_channel_probs=None, packed=False):
         """Decode B syndromes (array [B, m], any integer dtype).  Returns the OSD-W (or BP, when BP
         converged) corrections as uint8 [B, n]; per-row ``batch_converge``, ``batch_iter`` and, if
         requested, ``batch_osd0`` / ``batch_bp`` / ``batch_llr`` are left on the object.
+
+        ``packed=True``: rows cross the host-device boundary bit-packed (one eighth of the bytes).  The syndromes may be
+        given as uint64 words [B, ceil(m/64)] (:meth:`pack_rows`); the result and ``batch_osd0`` / ``batch_bp`` are
+        uint64 [B, ceil(n/64)] (:meth:`unpack_rows`).  Not combinable with ``want_llr`` / ``prior_select``.
 
         ``prior_select`` (uint8 [B, n]) with ``alt_channel_probs`` (n floats) gives every shot its own
         two-valued channel: bit i of shot b uses ``alt_channel_probs[i]`` where ``prior_select[b, i]`` is
         set and the decoder's ``channel_probs[i]`` elsewhere -- the batched form of the per-shot
         ``update_channel_probs`` of css_decode_sim.py:207-248."""
         self._timing_override = None
+        if packed:
+            if want_llr or prior_select is not None:
+                raise ValueError("packed=True offers the integer outputs only (no want_llr, no prior_select)")
+            return self._decode_batch_packed(syndromes, want_osd0, want_bp)
         s = np.asarray(syndromes)
         received = None
         if s.ndim == 2 and self._is_received(s.shape[1]):

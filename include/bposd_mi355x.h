@@ -110,6 +110,17 @@ int bposd_decode_batch(bposd_handle *h, const uint8_t *syndromes, int64_t B, uin
                        uint8_t *osd0, uint8_t *bp, uint8_t *converged, int32_t *iters, double *llr);
 
 /*
+ * The same call with bit-packed rows (host memory): syndromes as B rows of ceil(m/64) little-endian 64-bit words, osdw /
+ * osd0 / bp as B rows of ceil(n/64) words -- bit (i & 63) of word (i >> 6) of a row is entry i, padding bits are zero
+ * (numpy: np.packbits(rows, axis=1, bitorder="little") padded to a multiple of 8 bytes).  One eighth of the bytes cross
+ * PCIe; the device unpacks the syndromes in front of the BP kernel and packs the result rows behind it.  This is the
+ * form SURVEY.md 8(d)(i) / 8(e) recommend for the host-to-host metric.  osd0_words, bp_words, converged, iters may be
+ * NULL.  Synchronous.  Replaces the same call sites as bposd_decode_batch.
+ */
+int bposd_decode_batch_packed(bposd_handle *h, const uint64_t *syndrome_words, int64_t B, uint64_t *osdw_words,
+                              uint64_t *osd0_words, uint64_t *bp_words, uint8_t *converged, int32_t *iters);
+
+/*
  * Same, but every pointer is a DEVICE pointer on the handle's device (inputs already
  * resident in HBM).  Asynchronous on the handle's stream: call bposd_synchronize()
  * before reading the outputs.

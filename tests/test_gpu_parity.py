@@ -1741,3 +1741,116 @@ def test_osd_kernels_agree_on_large_batches(gpu_ready, hgp400):
                 res[v] = (d.decode_batch(syn, want_osd0=True).copy(), d.batch_osd0.copy(), d.last_osd_kernel(), (~d.batch_converge).mean())
             assert res[1][2] == "osd_kernel" and res[2][2] == "osd_wave_kernel" and res[1][3] > 0.8
             assert (res[1][0] == res[2][0]).all() and (res[1][1] == res[2][1]).all(), (H.shape, method, order)
+
+
+@pytest.mark.parametrize("case", ["local_2cpt", "local_1cpt", "lds", "class", "large"])
+def test_cross_kernel_stress_osd_bound_batches(gpu_ready, h1922, hgp400, case):
+    """Every tuned BP kernel on 2 x 32768 OSD-bound syndromes (error rate high, max_iter small: nearly every shot hands its
+    LLRs to OSD through the workspace -- the path a rare race lived on) against the any-degree kernel as a
+    second implementation, five outputs, no LLR output.  Sizes the CPU oracle does not reach; both implementations are
+    pinned to the oracle by the other tests."""
+    import scipy.sparse as sp
+
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import circulant, hgp
+
+    kw = dict(error_rate=0.085, max_iter=12, bp_method="ms", ms_scaling_factor=0, osd_method="osd0")
+    if case == "local_2cpt":
+        H, B, variant, kernel = h1922.hz, 32768, 17, "bp_local_kernel"
+    elif case == "local_1cpt":
+        H, B, variant, kernel = h1922.hx, 32768, 18, "bp_local_kernel"
+    elif case == "lds":
+        rng = np.random.default_rng(11)
+        irr = np.zeros((700, 1500), dtype=np.uint8)
+        for c in range(700):
+            irr[c, rng.choice(1500, size=int(rng.integers(3, 9)), replace=False)] = 1
+        H, B, variant, kernel = sp.csr_matrix(irr[:, np.asarray(irr.sum(axis=0)).ravel() <= 8]), 32768, 1, "bp_kernel"
+        kw = dict(error_rate=0.05, max_iter=10, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=4)
+    elif case == "class":
+        H, B, variant, kernel = hgp400.hz, 32768, 32, "bp_class_kernel"
+    else:
+        H, B, variant, kernel = hgp(circulant(62, (0, 2, 5)), compute_logicals=False).hz, 1024, 0, "bp_large_kernel"
+        kw = dict(error_rate=0.05, max_iter=10, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=4)
+    for rep in range(2):
+        _, syn = _syndromes(H, kw["error_rate"], B, 3 + rep)
+        g = BpOsdDecoder(H, **kw)
+        g.set_bp_variant(64)
+        want = dict(osdw=g.decode_batch(syn, want_osd0=True, want_bp=True).copy(), osd0=g.batch_osd0.copy(), bp=g.batch_bp.copy(),
+                    conv=g.batch_converge.copy(), iters=g.batch_iter.copy())
+        assert g.bp_kernel_info()["kernel"] == "bp_anydeg_kernel" and (~want["conv"]).mean() > 0.9
+        d = BpOsdDecoder(H, **kw)
+        d.set_bp_variant(variant)
+        got = dict(osdw=d.decode_batch(syn, want_osd0=True, want_bp=True), osd0=d.batch_osd0, bp=d.batch_bp, conv=d.batch_converge,
+                   iters=d.batch_iter)
+        assert d.bp_kernel_info()["kernel"] == kernel
+        for k in want:
+            bad = np.flatnonzero((got[k] != want[k]).reshape(B, -1).any(axis=1))
+            assert len(bad) == 0, (case, rep, k, len(bad), bad[:5])
+
+
+def test_posterior_llr_chunked_host_path_on_a_fresh_osd_handle(gpu_ready, h1922):
+    """bposd_posterior_llr with a batch beyond the 1 MB zero-copy staging path on a handle created WITH an OSD stage and
+    never used before: the chunked host path must neither touch the OSD list (never allocated for a BP-only call) nor run
+    the OSD kernel.  LLR bits, hard decisions, flags and iteration counts equal a decode_batch(want_llr=True) of a second
+    handle (itself pinned to the oracle elsewhere)."""
+    from bp_osd_amd import BpOsdDecoder, _lib
+
+    H = h1922.hz
+    m, n = H.shape
+    B = 6000
+    _, syn = _syndromes(H, 0.06, B, 77)
+    kw = dict(error_rate=0.06, max_iter=30, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=7)
+    fresh = BpOsdDecoder(H, **kw)
+    llr = np.full((B, n), np.nan)
+    bp = np.full((B, n), 9, np.uint8)
+    conv = np.full(B, 9, np.uint8)
+    iters = np.full(B, -1, np.int32)
+    for with_side_outputs in (True, False):  # (False: the library's own scratch buffer receives the hard decisions)
+        rc = gpu_ready.bposd_posterior_llr(fresh._h, syn.ctypes.data, B, llr.ctypes.data, bp.ctypes.data if with_side_outputs else None,
+                                           conv.ctypes.data if with_side_outputs else None, iters.ctypes.data if with_side_outputs else None)
+        _lib.check(gpu_ready, fresh._h, rc)
+        assert fresh.last_timing()["osd_invocations"] == 0
+        other = BpOsdDecoder(H, **kw)
+        other.decode_batch(syn, want_bp=True, want_llr=True)
+        assert (~other.batch_converge).sum() > 50
+        assert (llr.view(np.uint64) == other.batch_llr.view(np.uint64)).all()
+        assert (bp == other.batch_bp).all() and (conv.astype(bool) == other.batch_converge).all() and (iters == other.batch_iter).all()
+        llr[:] = np.nan
+    # and the handle still decodes with its OSD stage afterwards
+    assert (fresh.decode_batch(syn) == other.decode_batch(syn)).all()
+
+
+def test_packed_host_api_equals_byte_api(gpu_ready, h1922, hgp400, hgp4050):
+    """bposd_decode_batch_packed (bit-packed syndromes in, bit-packed osdw / osd0 / bp out) against the byte API on the same
+    batch: 65536 H1922 shots at the operating point (four tapered chunks, OSD rows patched from packed compact copies), the
+    reference's example code with a quarter of the shots through OSD, a one-chunk call, a batch that is no multiple of 64,
+    the HBM-resident path, nullable outputs."""
+    from bp_osd_amd import BpOsdDecoder
+
+    cases = [(h1922.hz, 65536, 0.05, dict(max_iter=0, osd_method="osd_cs", osd_order=7)),
+             (hgp400.hz, 40001, 0.05, dict(max_iter=0, osd_method="osd_cs", osd_order=42)),
+             (hgp400.hx, 77, 0.08, dict(max_iter=5, osd_method="osd_e", osd_order=6)),
+             (hgp4050.hz, 300, 0.06, dict(max_iter=6, osd_method="osd_cs", osd_order=5))]
+    for H, B, q, kw in cases:
+        m, n = H.shape
+        _, syn = _syndromes(H, q, B, 99)
+        d = BpOsdDecoder(H, error_rate=q, bp_method="ms", ms_scaling_factor=0, **kw)
+        want = dict(osdw=d.decode_batch(syn, want_osd0=True, want_bp=True).copy(), osd0=d.batch_osd0.copy(), bp=d.batch_bp.copy(),
+                    conv=d.batch_converge.copy(), iters=d.batch_iter.copy())
+        assert (~want["conv"]).sum() > 0
+        words = d.pack_rows(syn)
+        assert words.shape == (B, (m + 63) // 64) and (d.unpack_rows(words, m) == syn).all()
+        for given in (words, syn):  # packed words, or bytes that the Python layer packs
+            got = d.decode_batch(given, want_osd0=True, want_bp=True, packed=True)
+            assert got.dtype == np.uint64 and got.shape == (B, (n + 63) // 64)
+            assert (d.unpack_rows(got, n) == want["osdw"]).all()
+            assert (d.unpack_rows(d.batch_osd0, n) == want["osd0"]).all() and (d.unpack_rows(d.batch_bp, n) == want["bp"]).all()
+            assert (d.batch_converge == want["conv"]).all() and (d.batch_iter == want["iters"]).all()
+            if n % 64:
+                assert (got[:, -1] >> np.uint64(n % 64) == 0).all()  # padding bits are zero
+        only = d.decode_batch(words, want_osd0=False, want_bp=False, packed=True)
+        assert (only == got).all() and d.batch_osd0 is None
+    with pytest.raises(ValueError):
+        d.decode_batch(syn, packed=True, want_llr=True)
+    with pytest.raises(ValueError):
+        d.decode_batch(words[:, :-1], packed=True)
