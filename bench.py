@@ -39,6 +39,10 @@ CONFIGS = {
     # the reference's own stated workload, /root/reference/examples/qldpc_decode_example.py:5-23: [[400,16,6]] =
     # hgp(mkmn_16_4_6), min-sum with the variable scaling factor, max_iter = n, osd_cs order 42, error rate 0.05
     "hgp400_ms_cs42": ("ms", 0.0, 0, "osd_cs", 42, 131072, 0.0),
+    # the same script's settings on the reference's two larger example codes (examples/codes/classical_seed_codes/mkmn_20_5_8.txt,
+    # mkmn_24_6_10.txt -> [[625,25,8]], [[900,36,10]])
+    "hgp625_ms_cs42": ("ms", 0.0, 0, "osd_cs", 42, 131072, 0.0),
+    "hgp900_ms_cs42": ("ms", 0.0, 0, "osd_cs", 42, 131072, 0.0),
     "h1922_ms_osd0": ("ms", 0.0, 0, "osd0", 0, 65536, 0.0),      # configs[1]
     # configs[2] as the reference computes it: product-sum without clipping saturates (tanh -> 1, log -> inf, NaN)
     "h1922_ps_cs60": ("ps", 0.0, 0, "osd_cs", 60, 65536, 0.0),
@@ -50,7 +54,9 @@ CONFIGS = {
 }
 # syndromes timed on ONE CPU thread / per worker of the all-cores leg (the oracle needs ~1 ms per H1922 syndrome,
 # ~4.5 s per L29k elimination plus ~7 ms per OSD-E candidate)
-CPU_SAMPLE = {"l29k_ms_e15": (1, 0), "h1922_ps_cs60": (512, 128)}
+# (large code: 3 syndromes on one thread, 2 per worker of the all-cores leg -- a quarter of them go through a ~4.5-minute OSD-E sweep)
+CPU_SAMPLE = {"l29k_ms_e15": (3, 2), "h1922_ps_cs60": (512, 128), "h1922_ps_cs60_clip20": (1024, 256),
+              "hgp625_ms_cs42": (4096, 1024), "hgp900_ms_cs42": (2048, 512)}
 CPU_SAMPLE_DEFAULT = (8192, 2048)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 CLOCK_HZ = 2.4e9        # peak shader clock (MI355X_MICROARCH.md, chip-level parameters)
@@ -141,13 +147,15 @@ def main():
     from bp_osd_amd.codes import h1922, l29k, hgp
 
     large = args.config.startswith("l29k")
-    ref400 = args.config.startswith("hgp400")
+    ref400 = args.config.startswith("hgp400") or args.config.startswith("hgp625") or args.config.startswith("hgp900")
+    ref_seed = {"hgp400": ("mkmn_16_4_6.txt", "[[400,16,6]]", "192x400"), "hgp625": ("mkmn_20_5_8.txt", "[[625,25,8]]", "300x625"),
+                "hgp900": ("mkmn_24_6_10.txt", "[[900,36,10]]", "432x900")}.get(args.config[:6])
     cpu_one, cpu_per_proc = CPU_SAMPLE.get(args.config, CPU_SAMPLE_DEFAULT)
     if args.cpu_sample >= 0:
         cpu_one = args.cpu_sample
     # logical operators: the reference's generic route for H1922, the closed-form product basis for the large code
     if ref400:
-        seed = np.loadtxt(os.path.join(ROOT, "tests", "golden", "mkmn_16_4_6.txt"), dtype=int).astype(np.uint8)
+        seed = np.loadtxt(os.path.join(ROOT, "tests", "golden", ref_seed[0]), dtype=int).astype(np.uint8)
         code = hgp(seed, compute_logicals=(rank == 0))
     else:
         code = l29k(compute_logicals="closed_form" if rank == 0 else False) if large else h1922(compute_logicals=(rank == 0))
@@ -316,8 +324,10 @@ def main():
                          "against": other.bp_kernel_info()["kernel"] + " + " + (other.last_osd_kernel() or "osd_kernel")}
                 del o2
             del other
-        except Exception as e:  # the check must never take the bench line down
-            cross = {"identical": None, "error": str(e)[:200]}
+        except Exception as e:  # construction / memory failures of the SECOND decoder do not take the bench line down ...
+            cross = {"identical": None, "error": f"{type(e).__name__}: {e}"[:200]}
+        if cross is not None and cross.get("identical") is False:  # ... a disagreement of the two kernel paths does
+            print(f"[bench] CROSS-KERNEL CHECK FAILED: the two kernel paths disagree on {cross['outputs']}", file=sys.stderr, flush=True)
 
     # ---- host-to-host leg (rank 0, N = 1): the same batches through the host-pointer API from page-locked buffers
     host = None
@@ -338,6 +348,60 @@ def main():
         if (args.host_steps - 1) % nbatch == 0:
             host["same"] = bool((torch.from_numpy(h_out["osdw"]).to(dev) == d_osdw).all().item() and
                                 (torch.from_numpy(h_out["osd0"]).to(dev) == d_osd0).all().item())
+        # the same with bit-packed rows across PCIe (bposd_decode_batch_packed): syndromes in, osdw / osd0 / bp out
+        wm = (m + 63) // 64
+        p_syn = [dec.pinned_empty((B, wm), np.uint64) for _ in range(nbatch)]
+        for dst, b in zip(p_syn, batches):
+            for lo in range(0, B, 16384):
+                dst[lo:lo + 16384] = dec.pack_rows(b[1][lo:lo + 16384])
+        p_out = dict(osdw=dec.pinned_empty((B, wpr), np.uint64), osd0=dec.pinned_empty((B, wpr), np.uint64), bp=dec.pinned_empty((B, wpr), np.uint64))
+        for label, extra in (("packed_osdw", {}), ("packed_all", dict(osd0_words=p_out["osd0"], bp_words=p_out["bp"]))):
+            dec.decode_batch_packed_into(p_syn[0], p_out["osdw"], converged=h_out["conv"], iters=h_out["iters"], **extra)  # warm-up
+            th = time.perf_counter()
+            for k in range(args.host_steps):
+                dec.decode_batch_packed_into(p_syn[k % nbatch], p_out["osdw"], converged=h_out["conv"], iters=h_out["iters"], **extra)
+            host[label] = (time.perf_counter() - th) / args.host_steps
+        # a STREAM of batches through the asynchronous forms (bposd_decode_batch_async / _packed_async): three calls in flight
+        # on three lanes, each with buffers of its own -- what a decoding service does; a lone synchronous call always pays
+        # its own upload, its longest-running syndrome and its download
+        nsl, ncalls = 3, max(12, 4 * args.host_steps)
+        for label, is_packed in (("stream_packed_all", True), ("stream_all", False)):
+            if is_packed:
+                bufs = [dict(osdw=dec.pinned_empty((B, wpr), np.uint64), osd0=dec.pinned_empty((B, wpr), np.uint64), bp=dec.pinned_empty((B, wpr), np.uint64),
+                             conv=dec.pinned_empty((B,)), iters=dec.pinned_empty((B,), np.int32)) for _ in range(nsl)]
+                issue = lambda k, b: dec.decode_batch_packed_into(p_syn[k % nbatch], b["osdw"], b["osd0"], b["bp"], b["conv"], b["iters"], wait=False)
+            else:
+                bufs = [dict(osdw=dec.pinned_empty((B, n)), osd0=dec.pinned_empty((B, n)), bp=dec.pinned_empty((B, n)),
+                             conv=dec.pinned_empty((B,)), iters=dec.pinned_empty((B,), np.int32)) for _ in range(nsl)]
+                issue = lambda k, b: dec.decode_batch_into(h_syn[k % nbatch], b["osdw"], b["osd0"], b["bp"], b["conv"], b["iters"], wait=False)
+            lanes = [None] * nsl
+            for k in range(nsl):  # warm-up: buffers of every lane grow here
+                lanes[k] = issue(k, bufs[k])
+            dec.synchronize()
+            th = time.perf_counter()
+            for k in range(ncalls):
+                sl = k % nsl
+                if k >= nsl:
+                    dec.synchronize(lanes[sl])
+                lanes[sl] = issue(k, bufs[sl])
+            dec.synchronize()
+            host[label] = (time.perf_counter() - th) / ncalls
+            # the last call that decoded batch 0 must equal the synchronous result
+            k0 = max(k for k in range(ncalls) if k % nbatch == 0 and k >= ncalls - nsl) if any(k % nbatch == 0 for k in range(ncalls - nsl, ncalls)) else None
+            if k0 is not None:
+                b = bufs[k0 % nsl]
+                ref = p_out if is_packed else h_out
+                host[label + "_same"] = bool((b["osdw"] == ref["osdw"]).all() and (b["osd0"] == ref["osd0"]).all() and (b["bp"] == ref["bp"]).all())
+            del bufs
+        if (args.host_steps - 1) % nbatch == 0:
+            dpk = torch.empty((B, wpr), dtype=torch.int64, device=dev)
+            same_p = True
+            for words, rows in ((p_out["osdw"], d_osdw), (p_out["osd0"], d_osd0), (p_out["bp"], d_bp)):
+                dec.pack_rows_device(rows.data_ptr(), B, n, dpk.data_ptr())
+                dec.synchronize()
+                same_p = same_p and bool((torch.from_numpy(words.view(np.int64)).to(dev) == dpk).all().item())
+            host["same_packed"] = same_p
+            del dpk
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -393,12 +457,12 @@ def main():
         kinfo = dec.bp_kernel_info()
         local_edge = kinfo["kernel"] == "bp_local_kernel"
         code_label = ("[[29524,484]] HGP of a seeded (5,6)-regular 110x132 matrix, hz 14520x29524, " if large else
-                      "[[400,16,6]] HGP of mkmn_16_4_6 (the reference's example code), hz 192x400, " if ref400 else
+                      f"{ref_seed[1]} HGP of {ref_seed[0][:-4]} (the reference's example codes), hz {ref_seed[2]}, " if ref400 else
                       "[[1922,50]] HGP (31x31 circulant 1+x^2+x^5) hz 961x1922, ")
         num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         out = {
             "metric": "syndromes decoded/sec (whole node), large HGP 14520x29524 (BASELINE configs[4])" if large else
-                      "syndromes decoded/sec (whole node) + logical error rate, HGP [[400,16,6]] p=0.05 (reference example)" if ref400 else
+                      f"syndromes decoded/sec (whole node) + logical error rate, HGP {ref_seed[1]} p=0.05 (reference example)" if ref400 else
                       "syndromes decoded/sec (whole node) + logical error rate, HGP [[1922,50]] p=0.05",
             "value": value,
             "unit": "syndromes/s",
@@ -559,11 +623,22 @@ def main():
                 "unit": "syndromes/s",
                 "osdw_converged_iters": B / host["osdw"],
                 "all_outputs": B / host["all"],
-                "ms_per_step": {"osdw_converged_iters": 1e3 * host["osdw"], "all_outputs": 1e3 * host["all"]},
+                "packed_osdw_converged_iters": B / host["packed_osdw"],
+                "packed_all_outputs": B / host["packed_all"],
+                "stream_all_outputs": B / host["stream_all"],
+                "stream_packed_all_outputs": B / host["stream_packed_all"],
+                "stream_matches_synchronous_calls": bool(host.get("stream_all_same", True) and host.get("stream_packed_all_same", True)),
+                "stream_note": "the same batches as a stream of asynchronous calls (bposd_decode_batch_async / _packed_async), three in flight "
+                               "on three lanes with buffers of their own: consecutive calls overlap on the device like the device-resident steps of `value`",
+                "ms_per_step": {"osdw_converged_iters": 1e3 * host["osdw"], "all_outputs": 1e3 * host["all"],
+                                "packed_osdw_converged_iters": 1e3 * host["packed_osdw"], "packed_all_outputs": 1e3 * host["packed_all"],
+                                "stream_all_outputs": 1e3 * host["stream_all"], "stream_packed_all_outputs": 1e3 * host["stream_packed_all"]},
                 "steps": args.host_steps,
                 "matches_device_resident_run": host.get("same"),
-                "note": "bposd_decode_batch (numpy in / numpy out) from page-locked host buffers to page-locked host buffers, "
-                        "PCIe-inclusive, chunks overlapped on the handle's two lanes; never `value`",
+                "packed_matches_device_resident_run": host.get("same_packed"),
+                "note": "bposd_decode_batch (numpy in / numpy out; one byte per bit) and bposd_decode_batch_packed (64 bits per word both "
+                        "ways, SURVEY.md 8(d)(i) / 8(e)) from page-locked host buffers to page-locked host buffers, PCIe-inclusive, "
+                        "chunks overlapped on the handle's lanes; never `value`",
             }
         if cpu is not None:
             got = d_osdw[:cpu["n"]].cpu().numpy()
@@ -593,7 +668,12 @@ def main():
                               f"{cpu_all['busy']:.1f} s busy)",
                     "gpu_matches_cpu_bit_for_bit": same_all,
                 }
+        if cross is not None and cross.get("identical") is False:
+            out["value"] = None  # a number whose outputs two implementations do not agree on is not a measurement
         print(json.dumps(out))
+        if cross is not None and cross.get("identical") is False:
+            sys.stdout.flush()
+            os._exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -26,6 +26,8 @@ EXPORTED_SYMBOLS = (
     "bposd_update_channel_probs",
     "bposd_decode_batch",
     "bposd_decode_batch_packed",
+    "bposd_decode_batch_async",
+    "bposd_decode_batch_packed_async",
     "bposd_decode_batch_device",
     "bposd_decode_batch_select",
     "bposd_decode_batch_select_device",
@@ -99,6 +101,10 @@ def load():
     lib.bposd_decode_batch.restype = C.c_int
     lib.bposd_decode_batch_packed.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     lib.bposd_decode_batch_packed.restype = C.c_int
+    lib.bposd_decode_batch_async.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    lib.bposd_decode_batch_async.restype = C.c_int
+    lib.bposd_decode_batch_packed_async.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.bposd_decode_batch_packed_async.restype = C.c_int
     lib.bposd_decode_batch_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     lib.bposd_decode_batch_device.restype = C.c_int
     lib.bposd_decode_batch_select.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -62,6 +62,7 @@ struct BpClassParams {
     int* __restrict__ counters;
     unsigned long long* __restrict__ iter_total;
     int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
+    int packed_io;  // 1: packed syndromes in, packed result rows out (bp_kernel.hip.h: BpParams::packed_io)
     int queue_batch, queue_shift; // a workgroup takes  clamp((syndromes left) >> queue_shift, 1, queue_batch)  syndromes from the queue per
                                   // atomic -- big batches first, single syndromes at the end (2^queue_shift ~ 2 x the grid).  With codes
                                   // of a few hundred bits the chip retires a syndrome every ~25 ns, which is what one same-address
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = bpc_table_load(bpc_args()->pos_chk, (unsigned int)tid * 4u, (unsigned int)(j * NTMAX * 4));
-            sbit[j] = (c >= 0) ? ((bpc_args()->synd[(size_t)s * m + c] & 1) != 0) : false;
+            sbit[j] = (c >= 0) ? bp_synd_bit(bpc_args()->synd, bpc_args()->packed_io, s, m, c) : false;
             const unsigned long long bal = __ballot(sbit[j]);
             if (lane == 0 && ((wave << 6) + j * NT) < MP) {
                 const int w0 = ((wave << 6) + j * NT) >> 5;
@@ -406,19 +407,25 @@ __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassPara
             sh[0] = zero;
             sh[1] = zero;
         }
+        const int packed = __builtin_amdgcn_readfirstlane(bpc_args()->packed_io);
+        if (packed)  // result rows as 64-bit words through an LDS bitmap (the messages are dead)
+            bp_store_packed_rows<VPT>((unsigned int*)smem, tid, (int)blockDim.x, n, s, to_osd, (unsigned long long*)bpc_args()->out_bp,
+                                      (unsigned long long*)bpc_args()->out_osd0, (unsigned long long*)bpc_args()->out_osdw,
+                                      [&](int r) { return BPC_BIT(r); }, [&](int r) { return ((decmask >> r) & 1u) != 0u; });
 #pragma unroll
         for (int r = 0; r < VPT; ++r) {
             const int i = BPC_BIT(r);
             if (i >= 0) {
                 const size_t o = (size_t)s * n + i;
                 const uint8_t b = (uint8_t)((decmask >> r) & 1u);
-                if (bpc_args()->out_bp) bpc_args()->out_bp[o] = b;
-                if (!to_osd) {
-                    bpc_args()->out_osdw[o] = b;
-                    if (bpc_args()->out_osd0) bpc_args()->out_osd0[o] = b;
-                } else {
-                    bpc_args()->llr_ws[(size_t)slot * n + i] = BPC_LLRT[i];
+                if (!packed) {
+                    if (bpc_args()->out_bp) bpc_args()->out_bp[o] = b;
+                    if (!to_osd) {
+                        bpc_args()->out_osdw[o] = b;
+                        if (bpc_args()->out_osd0) bpc_args()->out_osd0[o] = b;
+                    }
                 }
+                if (to_osd) bpc_args()->llr_ws[(size_t)slot * n + i] = BPC_LLRT[i];
                 if (want_llr()) bpc_args()->out_llr[o] = BPC_LLRT[i];
             }
         }

@@ -75,7 +75,43 @@ struct BpParams {
     int* __restrict__ counters;         // [0] work queue, [1] osd count
     unsigned long long* __restrict__ iter_total;  // sum of iterations executed
     int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
+    int packed_io;  // 1: synd is [B][ceil(m/64)] and out_bp / out_osd0 / out_osdw are [B][ceil(n/64)] little-endian 64-bit words
+                    // (bposd_decode_batch_packed*: no unpack / pack kernels around the call)
 };
+
+// entry c of row s of the syndromes: a 0/1 byte, or bit (c & 63) of word (c >> 6) in the packed form
+__device__ __forceinline__ bool bp_synd_bit(const uint8_t* synd, int packed, long long s, int m, int c) {
+    if (packed) return (((const unsigned long long*)synd)[(size_t)s * (size_t)((m + 63) >> 6) + (c >> 6)] >> (c & 63)) & 1ull;
+    return (synd[(size_t)s * m + c] & 1) != 0;
+}
+
+// Packed result rows of one syndrome: the workgroup's hard decisions (thread-owned bits, any layout) meet in an LDS bitmap
+// (`bits`: 2 * ceil(n/64) dead words, e.g. the start of the message array once the iterations are over), then ceil(n/64)
+// threads store the 64-bit words.  bit_of(r) = index of the thread's r-th bit or -1, dec_of(r) = its decision.
+template <int NBITS, class BitOf, class DecOf>
+__device__ __forceinline__ void bp_store_packed_rows(unsigned int* bits, int tid, int nthreads, int n, long long s, bool to_osd,
+                                                     unsigned long long* out_bp, unsigned long long* out_osd0,
+                                                     unsigned long long* out_osdw, BitOf bit_of, DecOf dec_of) {
+    const int wpn = (n + 63) >> 6;
+    for (int w = tid; w < 2 * wpn; w += nthreads) bits[w] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NBITS; ++r) {
+        const int i = bit_of(r);
+        if (i >= 0 && dec_of(r)) atomicOr(&bits[i >> 5], 1u << (i & 31));
+    }
+    __syncthreads();
+    for (int w = tid; w < wpn; w += nthreads) {
+        const unsigned long long v = (unsigned long long)bits[2 * w] | ((unsigned long long)bits[2 * w + 1] << 32);
+        const size_t o = (size_t)s * wpn + w;
+        if (out_bp) out_bp[o] = v;
+        if (!to_osd) {
+            out_osdw[o] = v;
+            if (out_osd0) out_osd0[o] = v;
+        }
+    }
+    __syncthreads();  // the bitmap's words are message slots again
+}
 
 __host__ __device__ inline size_t bp_lds_bytes(int DC, int mp) {
     // messages (+1 dummy slot, padded to 16 B) + mismatch bitmap + 8 control words
@@ -183,7 +219,7 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
 #pragma unroll
         for (int r = 0; r < CPT; ++r) {
             const int c = tid + r * NT;
-            sbit[r] = (c < m) ? ((P.synd[(size_t)s * m + c] & 1) != 0) : false;
+            sbit[r] = (c < m) ? bp_synd_bit(P.synd, P.packed_io, s, m, c) : false;
             const unsigned long long bal = __ballot(sbit[r]);
             if (lane == 0) {
                 const int w0 = (c >> 5);  // c is a multiple of 64 for lane 0
@@ -375,19 +411,23 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
         }
         __syncthreads();  // publishes sh[3]; also fences this syndrome's reads of sh[0..1]
         const int slot = to_osd ? sh[3] : 0;
+        if (P.packed_io)
+            bp_store_packed_rows<VPT>((unsigned int*)smem, tid, NT, n, s, to_osd, (unsigned long long*)P.out_bp, (unsigned long long*)P.out_osd0,
+                                      (unsigned long long*)P.out_osdw, [&](int r) { return P.pos_bit[tid + r * NT]; }, [&](int r) { return dec[r] != 0; });
 #pragma unroll
         for (int r = 0; r < VPT; ++r) {
             const int i = P.pos_bit[tid + r * NT];  // reloaded here (not kept in registers across the BP loop)
             if (i >= 0) {
                 const size_t o = (size_t)s * n + i;
                 const uint8_t b = (uint8_t)dec[r];
-                if (P.out_bp) P.out_bp[o] = b;
-                if (!to_osd) {
-                    P.out_osdw[o] = b;
-                    if (P.out_osd0) P.out_osd0[o] = b;
-                } else {
-                    P.llr_ws[(size_t)slot * n + i] = llr[r];
+                if (!P.packed_io) {
+                    if (P.out_bp) P.out_bp[o] = b;
+                    if (!to_osd) {
+                        P.out_osdw[o] = b;
+                        if (P.out_osd0) P.out_osd0[o] = b;
+                    }
                 }
+                if (to_osd) P.llr_ws[(size_t)slot * n + i] = llr[r];
                 if (P.out_llr) P.out_llr[o] = llr[r];
             }
         }

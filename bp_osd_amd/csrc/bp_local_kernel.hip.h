@@ -61,6 +61,7 @@ struct BpLocalParams {
     int* __restrict__ counters;
     unsigned long long* __restrict__ iter_total;
     int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
+    int packed_io;  // 1: packed syndromes in, packed result rows out (bp_kernel.hip.h: BpParams::packed_io)
 };
 
 __host__ __device__ inline size_t bp_local_lds_bytes(int mp) {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = bpl_table_load(bpl_args()->pos_chk, (unsigned int)tid * 4u, (unsigned int)(j * NT * 4));
-            sbit[j] = (c >= 0) ? ((bpl_args()->synd[(size_t)s * m + c] & 1) != 0) : false;
+            sbit[j] = (c >= 0) ? bp_synd_bit(bpl_args()->synd, bpl_args()->packed_io, s, m, c) : false;
             const unsigned long long bal = __ballot(sbit[j]);
             if (lane == 0) {
                 const int w0 = ((wave << 6) + j * NT) >> 5;
@@ -419,19 +420,25 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
         }
         __syncthreads();
         const int slot = to_osd ? sh[3] : 0;
+        const int packed = __builtin_amdgcn_readfirstlane(bpl_args()->packed_io);
+        if (packed)  // result rows as 64-bit words through an LDS bitmap (the messages are dead)
+            bp_store_packed_rows<NB>((unsigned int*)smem, tid, NT, n, s, to_osd, (unsigned long long*)bpl_args()->out_bp,
+                                     (unsigned long long*)bpl_args()->out_osd0, (unsigned long long*)bpl_args()->out_osdw,
+                                     [&](int r) { return BPL_BIT(r); }, [&](int r) { return ((decmask >> r) & 1u) != 0u; });
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
             const int i = BPL_BIT(r);
             if (i >= 0) {
                 const size_t o = (size_t)s * n + i;
                 const uint8_t b = (uint8_t)((decmask >> r) & 1u);
-                if (bpl_args()->out_bp) bpl_args()->out_bp[o] = b;
-                if (!to_osd) {
-                    bpl_args()->out_osdw[o] = b;
-                    if (bpl_args()->out_osd0) bpl_args()->out_osd0[o] = b;
-                } else {
-                    bpl_args()->llr_ws[(size_t)slot * n + i] = BPL_LLRT[i];
+                if (!packed) {
+                    if (bpl_args()->out_bp) bpl_args()->out_bp[o] = b;
+                    if (!to_osd) {
+                        bpl_args()->out_osdw[o] = b;
+                        if (bpl_args()->out_osd0) bpl_args()->out_osd0[o] = b;
+                    }
                 }
+                if (to_osd) bpl_args()->llr_ws[(size_t)slot * n + i] = BPL_LLRT[i];
                 if (want_llr()) bpl_args()->out_llr[o] = BPL_LLRT[i];
             }
         }

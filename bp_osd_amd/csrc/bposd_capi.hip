@@ -633,7 +633,7 @@ int launch_pack(bposd_handle* h, hipStream_t st, const uint8_t* d_bytes, long lo
     if (B <= 0) return 0;
     const int wpr = (n + 63) / 64, threads = 256;
     const long long want = ((long long)B * wpr * 64 + threads - 1) / threads;
-    const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 16);
+    const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 2);  // few, fat workgroups: see launch_unpack
     hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(threads), 0, st, d_bytes, B, n, wpr, d_words);
     HIP_TRY(h, hipGetLastError());
     return 0;
@@ -643,7 +643,9 @@ int launch_unpack(bposd_handle* h, hipStream_t st, const unsigned long long* d_w
     if (B <= 0) return 0;
     const int wpr = (n + 63) / 64, threads = 256;
     const long long want = ((long long)B * n + threads - 1) / threads;
-    const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 16);
+    // few, fat workgroups: next to a persistent BP grid that takes every slot that frees up, a grid of thousands of short
+    // workgroups is starved after its first placements (traced: 6 ms per pack kernel instead of 0.4 ms)
+    const unsigned grid = (unsigned)std::min<long long>(want, (long long)h->num_cu * 2);
     hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid), dim3(threads), 0, st, d_words, B, n, wpr, d_bytes);
     HIP_TRY(h, hipGetLastError());
     return 0;
@@ -686,6 +688,7 @@ void bposd_destroy(bposd_handle* h) {
         if (l.ev_alt) (void)hipEventDestroy(l.ev_alt);
         if (l.ev_bp) (void)hipEventDestroy(l.ev_bp);
         if (l.ev_osd) (void)hipEventDestroy(l.ev_osd);
+        if (l.ev_done) (void)hipEventDestroy(l.ev_done);
         if (l.ev_up) (void)hipEventDestroy(l.ev_up);
         if (l.osd_stream) (void)hipStreamDestroy(l.osd_stream);
         if (l.stream) (void)hipStreamDestroy(l.stream);
@@ -786,6 +789,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
         CREATE_TRY(hipStreamCreateWithPriority(&l.osd_stream, hipStreamNonBlocking, prio_greatest));
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_bp, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_osd, hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_up, hipEventDisableTiming));
         CREATE_TRY(hipStreamCreateWithFlags(&l.copy_stream, hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&l.ev_copy, hipEventDisableTiming));
@@ -1079,7 +1083,19 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     P.counters = h->cur->d_counters;
     P.iter_total = (unsigned long long*)(h->cur->d_counters + 4);
     P.tail_flag = h->tail_gate ? h->cur->h_tail : nullptr;
+    P.packed_io = h->packed_now ? 1 : 0;
 
+    // At most TWO calls have kernels on the device: this call's BP kernel waits for the END of the call two back (its OSD
+    // kernel included).  (i) A third BP kernel that became ready meanwhile would share the slots the first one frees with the
+    // second from the first workgroup on -- both then take twice as long and finish together.  (ii) The OSD kernel needs a
+    // whole CU (131 KB of LDS for H1922); while ANY persistent BP grid is waiting, every slot a draining CU frees goes to a BP
+    // workgroup, which fits, and the eliminations of call k starve until the pipeline runs dry (traced with three and four
+    // asynchronous host calls in flight: completions came in bursts of three).  With this rule OSD(k) gets its CUs at the
+    // start of BP(k + 1)'s tail and BP(k + 2) follows ~1 ms later, whatever the number of calls queued.
+    if (!lean && h->nlanes >= 3) {
+        Lane& two_back = h->lanes[(lane + h->nlanes - 2) % h->nlanes];
+        if (two_back.done_recorded) HIP_TRY(h, hipStreamWaitEvent(h->cur->stream, two_back.ev_done, 0));
+    }
     if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[0], h->cur->stream));
     if (h->cfg.schedule == 1) {
         h->last_bp_kernel = BPOSD_BP_KERNEL_SERIAL;
@@ -1124,6 +1140,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.cmp_osd0 = d_osd0 ? h->cmp_osd0 : nullptr;
         Q.cmp_osdw = h->cmp_osdw;
         Q.dbg = nullptr;
+        Q.packed_io = h->packed_now ? 1 : 0;
         Q.cost = (h->fp_weights || (d_sel && h->cfg.weight_fn == 0)) ? h->d_cost : nullptr;
         Q.sel = d_sel;
         Q.cost_alt = h->lane_alt ? h->cur->d_alt + h->n : h->d_cost_alt;
@@ -1162,7 +1179,11 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         HIP_TRY(h, hipEventRecord(h->cur->ev_osd, h->cur->osd_stream));
         HIP_TRY(h, hipStreamWaitEvent(h->cur->stream, h->cur->ev_osd, 0));
     }
-    if (!lean) HIP_TRY(h, hipEventRecord(h->currec->ev[2], h->cur->stream));
+    if (!lean) {
+        HIP_TRY(h, hipEventRecord(h->currec->ev[2], h->cur->stream));
+        HIP_TRY(h, hipEventRecord(h->cur->ev_done, h->cur->stream));  // both kernels of this call have ended
+        h->cur->done_recorded = true;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->currec->h_counters, h->cur->d_counters, 32, hipMemcpyDeviceToHost, h->cur->stream));
     h->osd_now = nullptr;
     h->currec->recorded = true;
@@ -1359,6 +1380,7 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
     h->batch_hint = B;  // kernel variants are chosen for the call, not for a chunk
     const size_t n = (size_t)h->n, m = (size_t)h->m;
     const size_t rsn = packed ? (n + 63) / 64 * 8 : n, rsm = packed ? (m + 63) / 64 * 8 : m;  // host row strides in bytes
+    const bool native = packed && native_packed(h);  // the kernels read packed syndromes / write packed rows themselves
     int rc;
     static const bool gate_env = !(getenv("BPOSD_HOST_GATE") && getenv("BPOSD_HOST_GATE")[0] == '0');
     const bool gate = gate_env && nchunks > 1 && h->cfg.schedule == 0;  // (the serial-schedule kernel does not report its tail)
@@ -1378,7 +1400,7 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
             uint8_t* dst = which ? osd0 : osdw;
             if (!dst) continue;
             const void* src = which ? L.io_cmp0.p : L.io_cmpw.p;
-            if (packed) {  // the compact rows, packed on the (idle) lane's stream
+            if (packed && !native) {  // the compact rows, packed on the (idle) lane's stream
                 int rcp = launch_pack(h, L.stream, (const uint8_t*)src, count, (int)n, (unsigned long long*)L.io_pcmp.p);
                 if (rcp) return rcp;
                 HIP_TRY(h, hipMemcpyAsync(rows.data(), L.io_pcmp.p, rows.size(), hipMemcpyDeviceToHost, L.stream));
@@ -1431,7 +1453,7 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
             HIP_TRY_DRAIN(h, hipMemcpyAsync(L.io_sel.p, sel + (size_t)lo * n, bn, hipMemcpyHostToDevice, L.stream));
         }
         HIP_TRY_DRAIN(h, hipEventRecord(L.ev_up, L.stream));
-        if (packed && (rc = launch_unpack(h, L.stream, (const unsigned long long*)L.io_psynd.p, cnt, (int)m, (uint8_t*)L.io_synd.p))) {
+        if (packed && !native && (rc = launch_unpack(h, L.stream, (const unsigned long long*)L.io_psynd.p, cnt, (int)m, (uint8_t*)L.io_synd.p))) {
             (void)sync_all_lanes(h);
             return rc;
         }
@@ -1460,10 +1482,17 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         h->tail_gate = true;  // (also makes the call record ev_bp, which the downloads below wait for)
         h->cmp_osdw = osd_on ? (uint8_t*)L.io_cmpw.p : nullptr;
         h->cmp_osd0 = (osd_on && osd0) ? (uint8_t*)L.io_cmp0.p : nullptr;
-        rc = decode_device_impl(h, (const uint8_t*)L.io_synd.p, cnt, sel ? (const uint8_t*)L.io_sel.p : nullptr,
-                                (uint8_t*)L.io_osdw.p, osd0 ? (uint8_t*)L.io_osd0.p : nullptr,
-                                bp ? (uint8_t*)L.io_bp.p : nullptr, conv ? (uint8_t*)L.io_conv.p : nullptr,
-                                iters ? (int32_t*)L.io_iters.p : nullptr, llr ? (double*)L.io_llr.p : nullptr, lane, c);
+        h->packed_now = native;
+        if (native)
+            rc = decode_device_impl(h, (const uint8_t*)L.io_psynd.p, cnt, nullptr, (uint8_t*)L.io_posdw.p, osd0 ? (uint8_t*)L.io_posd0.p : nullptr,
+                                    bp ? (uint8_t*)L.io_pbp.p : nullptr, conv ? (uint8_t*)L.io_conv.p : nullptr,
+                                    iters ? (int32_t*)L.io_iters.p : nullptr, nullptr, lane, c);
+        else
+            rc = decode_device_impl(h, (const uint8_t*)L.io_synd.p, cnt, sel ? (const uint8_t*)L.io_sel.p : nullptr,
+                                    (uint8_t*)L.io_osdw.p, osd0 ? (uint8_t*)L.io_osd0.p : nullptr,
+                                    bp ? (uint8_t*)L.io_bp.p : nullptr, conv ? (uint8_t*)L.io_conv.p : nullptr,
+                                    iters ? (int32_t*)L.io_iters.p : nullptr, llr ? (double*)L.io_llr.p : nullptr, lane, c);
+        h->packed_now = false;
         h->tail_gate = false;
         h->cmp_osdw = h->cmp_osd0 = nullptr;
         if (rc) { (void)sync_all_lanes(h); return rc; }
@@ -1479,7 +1508,7 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
             struct { uint8_t* host; const DevBuf* bytes; const DevBuf* words; } outs[3] = {{osdw, &L.io_osdw, &L.io_posdw}, {osd0, &L.io_osd0, &L.io_posd0}, {bp, &L.io_bp, &L.io_pbp}};
             for (auto& o : outs) {
                 if (!o.host) continue;
-                if ((rc = launch_pack(h, cs, (const uint8_t*)o.bytes->p, cnt, (int)n, (unsigned long long*)o.words->p))) { (void)sync_all_lanes(h); return rc; }
+                if (!native && (rc = launch_pack(h, cs, (const uint8_t*)o.bytes->p, cnt, (int)n, (unsigned long long*)o.words->p))) { (void)sync_all_lanes(h); return rc; }
                 HIP_TRY_DRAIN(h, hipMemcpyAsync(o.host + (size_t)lo * rsn, o.words->p, (size_t)cnt * rsn, hipMemcpyDeviceToHost, cs));
             }
         } else {
@@ -1497,6 +1526,107 @@ static int decode_host_impl(bposd_handle* h, const uint8_t* synd, int64_t B, con
         if ((rc = patch_osd_rows(c))) { (void)sync_all_lanes(h); return rc; }
     h->nrec = nchunks;
     return sync_all_lanes(h);
+}
+
+// Asynchronous host-pointer decode: ONE lane, everything in stream order -- upload (packed rows: + unpack kernel), BP,
+// OSD, (pack kernels,) downloads -- and the call returns once that is enqueued.  Consecutive calls take consecutive lanes,
+// so call k + 1's BP workgroups fill the straggler tail of call k and call k's OSD kernel, packing and downloads run
+// under call k + 1's BP kernel: the host-to-host rate of a stream of batches approaches the device-resident one (a lone
+// synchronous call always pays its own upload, its 1922-iteration tail and its download).  The caller's buffers must be
+// page-locked (bposd_host_alloc) for the copies to be asynchronous, and stay untouched until bposd_synchronize_lane().
+static int decode_host_async_impl(bposd_handle* h, const uint8_t* synd, int64_t B, uint8_t* osdw, uint8_t* osd0, uint8_t* bp,
+                                  uint8_t* conv, int32_t* iters, double* llr, bool packed) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (B < 0 || B > 0x7fffffffLL) return fail(h, BPOSD_ERR_INVALID, "batch size %lld out of range", (long long)B);
+    if (B == 0) return BPOSD_OK;
+    if (!synd || !osdw) return fail(h, BPOSD_ERR_INVALID, "syndromes and osdw buffers are required");
+    if (packed && llr) return fail(h, BPOSD_ERR_INVALID, "the packed form has no LLR output");
+    DeviceGuard dev_guard(h->device);
+    HIP_TRY(h, dev_guard.err);
+    // a synchronous host-pointer call leaves no work behind, but its per-chunk records and staging are per lane too: nothing
+    // to drain here.  Buffers grow on every lane at once (no allocation inside a later call of the same size).
+    const size_t n = (size_t)h->n, m = (size_t)h->m, b8 = (size_t)B;
+    const size_t rsn = packed ? (n + 63) / 64 * 8 : n, rsm = packed ? (m + 63) / 64 * 8 : m;
+    int rc;
+    bool grew = false;
+    auto need = [&](DevBuf Lane::*member, size_t bytes) -> int {
+        bool have = true;
+        for (int l = 0; l < h->nlanes; ++l) have = have && (h->lanes[l].*member).p && (h->lanes[l].*member).bytes >= bytes;
+        if (have) return 0;
+        if (!grew && h->async_pending) { int rcs = sync_all_lanes(h); if (rcs) return rcs; }  // earlier calls may still use the old buffers
+        grew = true;
+        return ensure_lanes(h, member, bytes);
+    };
+    if ((rc = need(&Lane::io_synd, b8 * m))) return rc;
+    if ((rc = need(&Lane::io_osdw, b8 * n))) return rc;
+    if (osd0 && (rc = need(&Lane::io_osd0, b8 * n))) return rc;
+    if (bp && (rc = need(&Lane::io_bp, b8 * n))) return rc;
+    if ((rc = need(&Lane::io_conv, b8))) return rc;
+    if ((rc = need(&Lane::io_iters, sizeof(int) * b8))) return rc;
+    if (llr && (rc = need(&Lane::io_llr, sizeof(double) * b8 * n))) return rc;
+    if (packed) {
+        if ((rc = need(&Lane::io_psynd, b8 * rsm))) return rc;
+        if ((rc = need(&Lane::io_posdw, b8 * rsn))) return rc;
+        if (osd0 && (rc = need(&Lane::io_posd0, b8 * rsn))) return rc;
+        if (bp && (rc = need(&Lane::io_pbp, b8 * rsn))) return rc;
+    }
+    Lane& L = h->lanes[h->next_lane];  // the lane decode_device_impl is about to take
+    if (L.copy_pending) { HIP_TRY(h, hipStreamSynchronize(L.copy_stream)); L.copy_pending = false; }
+    // The copies and the pack / unpack kernels go to the lane's HIGH-PRIORITY stream (the one its OSD kernel runs on), ordered
+    // against the lane's main stream by events: when workgroup slots free up in the tail of another call's BP kernel these small
+    // kernels are dispatched first instead of competing with the next persistent BP grid for every slot.
+    hipStream_t hs = L.osd_stream;
+    HIP_TRY(h, hipEventRecord(L.ev_copy, L.stream));   // the lane's previous call (its downloads included) has finished
+    HIP_TRY(h, hipStreamWaitEvent(hs, L.ev_copy, 0));
+    const bool native = packed && native_packed(h);  // the kernels read packed syndromes / write packed rows themselves
+    if (packed) {
+        HIP_TRY(h, hipMemcpyAsync(L.io_psynd.p, synd, b8 * rsm, hipMemcpyHostToDevice, hs));
+        if (!native && (rc = launch_unpack(h, hs, (const unsigned long long*)L.io_psynd.p, B, (int)m, (uint8_t*)L.io_synd.p))) return rc;
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(L.io_synd.p, synd, b8 * m, hipMemcpyHostToDevice, hs));
+    }
+    HIP_TRY(h, hipEventRecord(L.ev_up, hs));
+    HIP_TRY(h, hipStreamWaitEvent(L.stream, L.ev_up, 0));
+    h->packed_now = native;
+    if (native)
+        rc = decode_device_impl(h, (const uint8_t*)L.io_psynd.p, B, nullptr, (uint8_t*)L.io_posdw.p, osd0 ? (uint8_t*)L.io_posd0.p : nullptr,
+                                bp ? (uint8_t*)L.io_pbp.p : nullptr, (uint8_t*)L.io_conv.p, (int32_t*)L.io_iters.p, nullptr);
+    else
+        rc = decode_device_impl(h, (const uint8_t*)L.io_synd.p, B, nullptr, (uint8_t*)L.io_osdw.p, osd0 ? (uint8_t*)L.io_osd0.p : nullptr,
+                                bp ? (uint8_t*)L.io_bp.p : nullptr, (uint8_t*)L.io_conv.p, (int32_t*)L.io_iters.p,
+                                llr ? (double*)L.io_llr.p : nullptr);
+    h->packed_now = false;
+    if (rc) { (void)sync_all_lanes(h); return rc; }
+    // (decode_device_impl has made L.stream wait for the OSD kernel: an event on it covers both kernels)
+    HIP_TRY_DRAIN(h, hipEventRecord(L.ev_copy, L.stream));
+    HIP_TRY_DRAIN(h, hipStreamWaitEvent(hs, L.ev_copy, 0));
+    struct { uint8_t* host; const DevBuf* bytes; const DevBuf* words; } outs[3] = {{osdw, &L.io_osdw, &L.io_posdw}, {osd0, &L.io_osd0, &L.io_posd0}, {bp, &L.io_bp, &L.io_pbp}};
+    if (conv) HIP_TRY_DRAIN(h, hipMemcpyAsync(conv, L.io_conv.p, b8, hipMemcpyDeviceToHost, hs));
+    if (iters) HIP_TRY_DRAIN(h, hipMemcpyAsync(iters, L.io_iters.p, sizeof(int) * b8, hipMemcpyDeviceToHost, hs));
+    for (auto& o : outs) {
+        if (!o.host) continue;
+        if (packed) {
+            if (!native && (rc = launch_pack(h, hs, (const uint8_t*)o.bytes->p, B, (int)n, (unsigned long long*)o.words->p))) { (void)sync_all_lanes(h); return rc; }
+            HIP_TRY_DRAIN(h, hipMemcpyAsync(o.host, o.words->p, b8 * rsn, hipMemcpyDeviceToHost, hs));
+        } else {
+            HIP_TRY_DRAIN(h, hipMemcpyAsync(o.host, o.bytes->p, b8 * n, hipMemcpyDeviceToHost, hs));
+        }
+    }
+    if (llr) HIP_TRY_DRAIN(h, hipMemcpyAsync(llr, L.io_llr.p, sizeof(double) * b8 * n, hipMemcpyDeviceToHost, hs));
+    HIP_TRY_DRAIN(h, hipEventRecord(L.ev_osd, hs));               // bposd_synchronize_lane waits on the main stream:
+    HIP_TRY_DRAIN(h, hipStreamWaitEvent(L.stream, L.ev_osd, 0));  // make it cover the downloads
+    return BPOSD_OK;
+}
+
+int bposd_decode_batch_async(bposd_handle* h, const uint8_t* synd, int64_t B, uint8_t* osdw, uint8_t* osd0, uint8_t* bp,
+                             uint8_t* conv, int32_t* iters, double* llr) {
+    return decode_host_async_impl(h, synd, B, osdw, osd0, bp, conv, iters, llr, /*packed=*/false);
+}
+
+int bposd_decode_batch_packed_async(bposd_handle* h, const uint64_t* synd_words, int64_t B, uint64_t* osdw_words, uint64_t* osd0_words,
+                                    uint64_t* bp_words, uint8_t* conv, int32_t* iters) {
+    return decode_host_async_impl(h, (const uint8_t*)synd_words, B, (uint8_t*)osdw_words, (uint8_t*)osd0_words, (uint8_t*)bp_words, conv,
+                                  iters, nullptr, /*packed=*/true);
 }
 
 static int record_timing(bposd_handle* h, CallRecord* recs, int count, double* bp_ms, double* osd_ms,

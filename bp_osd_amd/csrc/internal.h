@@ -34,6 +34,8 @@ struct Lane {
     // grid of the NEXT call's BP kernel for every CU that frees up and take many times their own run time.
     hipStream_t osd_stream = nullptr;
     hipEvent_t ev_bp = nullptr, ev_osd = nullptr;
+    hipEvent_t ev_done = nullptr;  // both kernels of the lane's last (non-lean) call have ended
+    bool done_recorded = false;
     void* h_stage = nullptr;     // page-locked, device-visible staging for small host-pointer calls (zero-copy path)
     size_t h_stage_bytes = 0;
     hipEvent_t ev_up = nullptr;  // host-pointer calls: this lane's chunk has been uploaded (uploads go one at a time, in
@@ -136,6 +138,7 @@ struct bposd_handle {
     uint8_t *cmp_osd0 = nullptr, *cmp_osdw = nullptr;  // compact OSD rows of the chunk being enqueued (host-pointer calls)
     bool bp_only = false;              // the call being enqueued wants BP's outputs only (bposd_posterior_llr): no OSD kernel
     bool lane_alt = false;             // the call being enqueued takes the alternative channel from its lane's buffers
+    bool packed_now = false;           // the call being enqueued hands the kernels packed syndromes and takes packed result rows
     bool tail_gate = false;            // the call being enqueued is a chunk of a host-pointer call: its BP kernel reports its tail
     std::string err;
 };
@@ -182,5 +185,7 @@ int launch_osd(bposd_handle* h, const bposd::OsdParams& P, long long B);  // lau
 int osd_words(int n);
 int launch_osd_large(bposd_handle* h, const bposd::OsdParams& P, long long B, int* d_rank_out);  // launch_osd_large.hip
 int osd_large_maxspan(bool cs);
+// do the kernels this handle runs read packed syndromes / write packed rows themselves (else unpack / pack kernels surround them)?
+inline bool native_packed(const bposd_handle* h) { return !h->large && !h->bp_any && h->cfg.schedule == 0 && h->bp_variant != 64; }
 
 }  // namespace bposd_host

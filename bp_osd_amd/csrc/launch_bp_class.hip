@@ -77,7 +77,7 @@ int launch_bp_class(bposd_handle* h, const BpParams& P) {
     C.synd = P.synd; C.llr0 = P.llr0; C.sel = P.sel; C.llr0_alt = P.llr0_alt;
     C.pos_chk = h->d_cpos_chk; C.pos_bit = h->d_cpos_bit; C.bit_slot = h->d_cbit_slot; C.grp_deg = h->d_cgrp_deg; C.grp_cdeg = h->d_cgrp_cdeg;
     C.out_bp = P.out_bp; C.out_osd0 = P.out_osd0; C.out_osdw = P.out_osdw; C.out_conv = P.out_conv; C.out_iters = P.out_iters;
-    C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total; C.tail_flag = P.tail_flag;
+    C.out_llr = P.out_llr; C.llr_ws = P.llr_ws; C.osd_list = P.osd_list; C.counters = P.counters; C.iter_total = P.iter_total; C.tail_flag = P.tail_flag; C.packed_io = P.packed_io;
     const bool uprior = h->probs_uniform && P.sel == nullptr && h->probs[0] > 0.0 && h->probs[0] < 0.5;
     if (h->class_dc == 7) return launch_bp_class_shape<7, 7, 3, 4, BPOSD_CLASS7_MINW, BPOSD_CLASS7_MINW_PS>(h, C, uprior);
     if (h->class_dc == 6) return launch_bp_class_shape<6, 6, 3, 3, 8, BPOSD_CLASS6_MINW_PS>(h, C, uprior);

@@ -37,7 +37,7 @@ int launch_bp_local(bposd_handle* h, const BpParams& P) {
     L.pos_chk = h->d_lpos_chk; L.pos_bit = h->d_lpos_bit; L.pos_alo = h->d_lpos_alo; L.pos_ahi = h->d_lpos_ahi;
     L.grp_dl = h->d_lgrp_dl; L.pos_dl = h->d_lpos_dl;
     L.out_bp = P.out_bp; L.out_osd0 = P.out_osd0; L.out_osdw = P.out_osdw; L.out_conv = P.out_conv; L.out_iters = P.out_iters;
-    L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list; L.counters = P.counters; L.iter_total = P.iter_total; L.tail_flag = P.tail_flag;
+    L.out_llr = P.out_llr; L.llr_ws = P.llr_ws; L.osd_list = P.osd_list; L.counters = P.counters; L.iter_total = P.iter_total; L.tail_flag = P.tail_flag; L.packed_io = P.packed_io;
     if (h->local_mp == 2048) return launch_bp_local_t<2, 2048, 4, false>(h, L);  // 1024 threads, one workgroup per CU
     if (h->bp_variant == 17) return launch_bp_local_t<2, 1024, 8, false>(h, L);   // 512 threads, <= 64 VGPRs: 4 workgroups per CU
     if (h->bp_variant == 18) return launch_bp_local_t<1, 1024, 8, false>(h, L);   // 1024 threads, <= 64 VGPRs: 2 workgroups per CU

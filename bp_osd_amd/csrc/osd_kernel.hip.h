@@ -83,7 +83,28 @@ struct OsdParams {
     const double* __restrict__ cost_alt;
     unsigned long long* __restrict__ rows_ws;  // [gridDim.x][W][blockDim.x * RPT] finished row words
     long long* __restrict__ dbg;       // nullable: 8 phase timestamps (s_memtime) of list slot 0
+    int packed_io;  // 1: synd is [B][ceil(m/64)] and out_osd0 / out_osdw / cmp_* are rows of ceil(n/64) little-endian 64-bit words
 };
+
+__device__ __forceinline__ bool osd_synd_bit(const uint8_t* synd, int packed, long long s, int m, int r) {
+    if (packed) return (((const unsigned long long*)synd)[(size_t)s * (size_t)((m + 63) >> 6) + (r >> 6)] >> (r & 63)) & 1ull;
+    return (synd[(size_t)s * m + r] & 1) != 0;
+}
+
+// one result row from its 0/1 bytes in LDS: n bytes, or ceil(n/64) words in the packed form
+__device__ __forceinline__ void osd_store_row(uint8_t* out, int packed, size_t row, int n, const uint8_t* x, int tid, int nthreads) {
+    if (!out) return;
+    if (packed) {
+        const int wpn = (n + 63) >> 6;
+        for (int w = tid; w < wpn; w += nthreads) {
+            unsigned long long v = 0ull;
+            for (int b = 0; b < 64 && 64 * w + b < n; ++b) v |= (unsigned long long)(x[64 * w + b] & 1) << b;
+            ((unsigned long long*)out)[row * wpn + w] = v;
+        }
+    } else {
+        for (int i = tid; i < n; i += nthreads) out[row * n + i] = x[i];
+    }
+}
 
 // Diagnostics (phase timestamps + a dump of the sweep tables for list slot 0) are compiled in only with
 // -DBPOSD_OSD_DIAG: their address arithmetic otherwise costs registers in the hot loops.
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
 #pragma unroll
                     for (int w = 0; w < W; ++w) row[k][w] |= (jw == w) ? bit : 0ull;
                 }
-                if (P.synd[(size_t)s * m + r] & 1) row[k][W - 1] |= 1ull << 63;
+                if (osd_synd_bit(P.synd, P.packed_io, s, m, r)) row[k][W - 1] |= 1ull << 63;
             }
         }
 
@@ -585,10 +606,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             if (lane == 0) L.npmask[w] = np;
         }
         __syncthreads();
-        if (P.out_osd0)
-            for (int i = tid; i < n; i += NT) P.out_osd0[(size_t)s * n + i] = L.xout[i];
-        if (P.cmp_osd0)
-            for (int i = tid; i < n; i += NT) P.cmp_osd0[(size_t)slot_id * n + i] = L.xout[i];
+        osd_store_row(P.out_osd0, P.packed_io, (size_t)s, n, L.xout, tid, NT);
+        osd_store_row(P.cmp_osd0, P.packed_io, (size_t)slot_id, n, L.xout, tid, NT);
 
         int w0 = 0;
         for (int q = 0; q < ncv; ++q) w0 += __popcll(L.yvec[q]);
@@ -872,10 +891,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         // ------------------------------------------------- write the OSD-W solution
         if (sel_a == -1) {
             // OSD-0 stays the best
-            for (int i = tid; i < n; i += NT) {
-                P.out_osdw[(size_t)s * n + i] = L.xout[i];
-                if (P.cmp_osdw) P.cmp_osdw[(size_t)slot_id * n + i] = L.xout[i];
-            }
+            osd_store_row(P.out_osdw, P.packed_io, (size_t)s, n, L.xout, tid, NT);
+            osd_store_row(P.cmp_osdw, P.packed_io, (size_t)slot_id, n, L.xout, tid, NT);
         } else {
             __syncthreads();
             for (int i = tid; i < n; i += NT) L.xout[i] = 0;
@@ -911,10 +928,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             for (int k = 0; k < RPT; ++k)
                 if (used[k] && xs[k]) L.xout[L.kidx[mypos[k]]] = 1;
             __syncthreads();
-            for (int i = tid; i < n; i += NT) {
-                P.out_osdw[(size_t)s * n + i] = L.xout[i];
-                if (P.cmp_osdw) P.cmp_osdw[(size_t)slot_id * n + i] = L.xout[i];
-            }
+            osd_store_row(P.out_osdw, P.packed_io, (size_t)s, n, L.xout, tid, NT);
+            osd_store_row(P.cmp_osdw, P.packed_io, (size_t)slot_id, n, L.xout, tid, NT);
         }
         OSD_STAMP(6);
         __syncthreads();

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
 #pragma unroll
                     for (int w = 0; w < W; ++w) row[q][w] |= (w == (j >> 6)) ? bit : 0ull;
                 }
-                if (P.synd[(size_t)s * m + r] & 1) row[q][W - 1] |= 1ull << 63;
+                if (osd_synd_bit(P.synd, P.packed_io, s, m, r)) row[q][W - 1] |= 1ull << 63;
             }
         }
 
@@ -201,14 +201,24 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
             for (int q = 0; q < RPL; ++q)
                 if (lane == q) yv[q] = yy[q];
             osdw_sync();
+            const int wpn = (n + 63) >> 6;
+            unsigned int* bits = (unsigned int*)keys;  // packed form: the row meets in an LDS bitmap (the sort keys are dead)
+            if (P.packed_io) {
+                for (int w = lane; w < 2 * wpn; w += 64) bits[w] = 0u;
+                osdw_sync();
+            }
             for (int j = lane; j < n; j += 64) {
                 const int pr = pivrow[j];
                 uint8_t bit;
                 if (pr >= 0) bit = (uint8_t)((yv[pr >> 6] >> (pr & 63)) & 1ull);
                 else bit = (uint8_t)((j == fpos_a || j == fpos_b) ? 1 : 0);
                 const int i = kidx[j];
-                if (out) out[(size_t)s * n + i] = bit;
-                if (cmp) cmp[(size_t)slot_id * n + i] = bit;
+                if (P.packed_io) {
+                    if (bit) atomicOr(&bits[i >> 5], 1u << (i & 31));
+                } else {
+                    if (out) out[(size_t)s * n + i] = bit;
+                    if (cmp) cmp[(size_t)slot_id * n + i] = bit;
+                }
             }
             if (fa) {  // osd_e pattern: a few more ones
                 unsigned long long pp = fa;
@@ -217,9 +227,21 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
                     pp &= pp - 1;
                     if (lane == 0) {
                         const int i = kidx[tpos[a]];
-                        if (out) out[(size_t)s * n + i] = 1;
-                        if (cmp) cmp[(size_t)slot_id * n + i] = 1;
+                        if (P.packed_io) {
+                            atomicOr(&bits[i >> 5], 1u << (i & 31));
+                        } else {
+                            if (out) out[(size_t)s * n + i] = 1;
+                            if (cmp) cmp[(size_t)slot_id * n + i] = 1;
+                        }
                     }
+                }
+            }
+            if (P.packed_io) {
+                osdw_sync();
+                for (int w = lane; w < wpn; w += 64) {
+                    const unsigned long long v = (unsigned long long)bits[2 * w] | ((unsigned long long)bits[2 * w + 1] << 32);
+                    if (out) ((unsigned long long*)out)[(size_t)s * wpn + w] = v;
+                    if (cmp) ((unsigned long long*)cmp)[(size_t)slot_id * wpn + w] = v;
                 }
             }
             osdw_sync();

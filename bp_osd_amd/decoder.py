@@ -218,9 +218,11 @@ class BpOsdDecoder:
         self.batch_osd0, self.batch_bp, self.batch_osdw = osd0, bp, osdw
         return osdw
 
-    def decode_batch_packed_into(self, syndrome_words, osdw_words, osd0_words=None, bp_words=None, converged=None, iters=None):
+    def decode_batch_packed_into(self, syndrome_words, osdw_words, osd0_words=None, bp_words=None, converged=None, iters=None, wait=True):
         """Host-pointer decode of bit-packed rows into caller-owned C-contiguous arrays: ``uint64 [B, ceil(m/64)]`` in,
-        ``uint64 [B, ceil(n/64)]`` out (page-locked arrays from :meth:`pinned_empty` make the copies asynchronous)."""
+        ``uint64 [B, ceil(n/64)]`` out (page-locked arrays from :meth:`pinned_empty` make the copies asynchronous).
+        ``wait=False``: the call is only enqueued (``bposd_decode_batch_packed_async``) and the lane to
+        :meth:`synchronize` on is returned; the arrays must stay untouched until then."""
         self._timing_override = None
         wm, wn = (self.m + 63) // 64, (self.n + 63) // 64
         s = syndrome_words
@@ -237,10 +239,10 @@ class BpOsdDecoder:
             if a.dtype != dt or a.shape != shp or not a.flags.c_contiguous:
                 raise ValueError(f"{name} must be a C-contiguous {np.dtype(dt).name} array of shape {shp}")
         ptr = lambda a: a.ctypes.data if a is not None else None
-        rc = self._lib.bposd_decode_batch_packed(self._h, s.ctypes.data, B, ptr(osdw_words), ptr(osd0_words), ptr(bp_words),
-                                                 ptr(converged), ptr(iters)) if B else 0
+        fn = self._lib.bposd_decode_batch_packed if wait else self._lib.bposd_decode_batch_packed_async
+        rc = fn(self._h, s.ctypes.data, B, ptr(osdw_words), ptr(osd0_words), ptr(bp_words), ptr(converged), ptr(iters)) if B else 0
         _lib.check(self._lib, self._h, rc)
-        return osdw_words
+        return osdw_words if wait else self.last_lane
 
     def decode_batch(self, syndromes, want_osd0=True, want_bp=True, want_llr=False, prior_select=None,
                      alt_channel_probs=None, packed=False):
@@ -514,10 +516,11 @@ class BpOsdDecoder:
         weakref.finalize(buf, self._lib.bposd_host_free, ptr)  # freed when the last view of the buffer is gone
         return arr
 
-    def decode_batch_into(self, syndromes, osdw, osd0=None, bp=None, converged=None, iters=None, llr=None):
+    def decode_batch_into(self, syndromes, osdw, osd0=None, bp=None, converged=None, iters=None, llr=None, wait=True):
         """Host-pointer decode into caller-owned C-contiguous arrays (``uint8 [B, m]`` in; ``uint8 [B, n]``, ``uint8 [B]``,
         ``int32 [B]``, ``float64 [B, n]`` out; any output but ``osdw`` may be None) -- ``bposd_decode_batch`` with no
-        allocation or conversion on the way."""
+        allocation or conversion on the way.  ``wait=False``: ``bposd_decode_batch_async`` -- the call is only enqueued and
+        the lane to :meth:`synchronize` on is returned; the arrays must stay untouched until then."""
         self._timing_override = None
         s = syndromes
         if s.dtype != np.uint8 or s.ndim != 2 or s.shape[1] != self.m or not s.flags.c_contiguous:
@@ -533,10 +536,10 @@ class BpOsdDecoder:
             if a.dtype != dt or a.shape != shp or not a.flags.c_contiguous:
                 raise ValueError(f"{name} must be a C-contiguous {np.dtype(dt).name} array of shape {shp}")
         ptr = lambda a: a.ctypes.data if a is not None else None
-        rc = self._lib.bposd_decode_batch(self._h, s.ctypes.data, B, ptr(osdw), ptr(osd0), ptr(bp), ptr(converged),
-                                          ptr(iters), ptr(llr)) if B else 0
+        fn = self._lib.bposd_decode_batch if wait else self._lib.bposd_decode_batch_async
+        rc = fn(self._h, s.ctypes.data, B, ptr(osdw), ptr(osd0), ptr(bp), ptr(converged), ptr(iters), ptr(llr)) if B else 0
         _lib.check(self._lib, self._h, rc)
-        return osdw
+        return osdw if wait else self.last_lane
 
     def last_timing(self):
         """dict(bp_ms, osd_ms, bp_iterations, osd_invocations) of the last decode call (HIP events).  Small host-pointer

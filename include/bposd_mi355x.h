@@ -121,6 +121,20 @@ int bposd_decode_batch_packed(bposd_handle *h, const uint64_t *syndrome_words, i
                               uint64_t *osd0_words, uint64_t *bp_words, uint8_t *converged, int32_t *iters);
 
 /*
+ * Asynchronous forms of bposd_decode_batch / bposd_decode_batch_packed for a STREAM of batches: the whole call -- upload,
+ * kernels, download -- is enqueued on the handle's next lane (see "Lanes" below) and the function returns; consecutive
+ * calls overlap on the device, which a synchronous call cannot (it pays its own upload, its longest-running syndrome and
+ * its download).  The buffers should come from bposd_host_alloc (with pageable memory the copies block) and must stay
+ * untouched until bposd_synchronize_lane(h, lane) with lane = bposd_last_lane(h) read right after the call, or
+ * bposd_synchronize(h).  At most bposd_num_lanes(h) calls are in flight; a further call queues behind the oldest.
+ * (No counterpart in the reference: its decode is synchronous.)
+ */
+int bposd_decode_batch_async(bposd_handle *h, const uint8_t *syndromes, int64_t B, uint8_t *osdw, uint8_t *osd0,
+                             uint8_t *bp, uint8_t *converged, int32_t *iters, double *llr);
+int bposd_decode_batch_packed_async(bposd_handle *h, const uint64_t *syndrome_words, int64_t B, uint64_t *osdw_words,
+                                    uint64_t *osd0_words, uint64_t *bp_words, uint8_t *converged, int32_t *iters);
+
+/*
  * Same, but every pointer is a DEVICE pointer on the handle's device (inputs already
  * resident in HBM).  Asynchronous on the handle's stream: call bposd_synchronize()
  * before reading the outputs.

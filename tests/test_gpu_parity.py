@@ -1854,3 +1854,51 @@ def test_packed_host_api_equals_byte_api(gpu_ready, h1922, hgp400, hgp4050):
         d.decode_batch(syn, packed=True, want_llr=True)
     with pytest.raises(ValueError):
         d.decode_batch(words[:, :-1], packed=True)
+
+
+def test_async_host_api_stream_of_batches(gpu_ready, h1922, hgp4050):
+    """bposd_decode_batch_async / bposd_decode_batch_packed_async: several calls in flight on consecutive lanes with buffers
+    of their own equal the synchronous calls on the same batches -- byte rows with every output (LLRs included) and packed
+    rows; a lane's buffers are reused by the call after next; the HBM-resident path (two lanes)."""
+    from bp_osd_amd import BpOsdDecoder
+
+    for H, B, q, kw in ((h1922.hz, 20000, 0.06, dict(max_iter=40, osd_method="osd_cs", osd_order=7)),
+                        (hgp4050.hz, 200, 0.06, dict(max_iter=6, osd_method="osd_e", osd_order=5))):
+        m, n = H.shape
+        d = BpOsdDecoder(H, error_rate=q, bp_method="ms", ms_scaling_factor=0.625, **kw)
+        batches = [_syndromes(H, q, B, 500 + k)[1] for k in range(3)]
+        want = []
+        for syn in batches:
+            osdw = d.decode_batch(syn, want_osd0=True, want_bp=True, want_llr=True).copy()
+            want.append(dict(osdw=osdw, osd0=d.batch_osd0.copy(), bp=d.batch_bp.copy(), conv=d.batch_converge.copy(), iters=d.batch_iter.copy(),
+                             llr=d.batch_llr.copy()))
+            assert (~d.batch_converge).sum() > 3
+        ncalls = 7
+        pin = [d.pinned_empty((B, m)) for _ in range(3)]
+        for dst, syn in zip(pin, batches):
+            dst[:] = syn
+        outs = [dict(osdw=d.pinned_empty((B, n)), osd0=d.pinned_empty((B, n)), bp=d.pinned_empty((B, n)), conv=d.pinned_empty((B,)),
+                     iters=d.pinned_empty((B,), np.int32), llr=d.pinned_empty((B, n), np.float64)) for _ in range(ncalls)]
+        lanes = [d.decode_batch_into(pin[k % 3], o["osdw"], o["osd0"], o["bp"], o["conv"], o["iters"], o["llr"], wait=False) for k, o in enumerate(outs)]
+        assert lanes[:d.num_lanes] == list(range(d.num_lanes))
+        d.synchronize()
+        for k, o in enumerate(outs):
+            w = want[k % 3]
+            assert (o["osdw"] == w["osdw"]).all() and (o["osd0"] == w["osd0"]).all() and (o["bp"] == w["bp"]).all(), k
+            assert (o["conv"].astype(bool) == w["conv"]).all() and (o["iters"] == w["iters"]).all(), k
+            assert (o["llr"].view(np.uint64) == w["llr"].view(np.uint64)).all(), k
+        wn = (n + 63) // 64
+        pw = [d.pack_rows(syn) for syn in batches]
+        pouts = [dict(osdw=np.zeros((B, wn), np.uint64), osd0=np.zeros((B, wn), np.uint64), bp=np.zeros((B, wn), np.uint64), conv=np.zeros(B, np.uint8),
+                      iters=np.zeros(B, np.int32)) for _ in range(ncalls)]  # (pageable memory: the copies block, the results must not differ)
+        for k, o in enumerate(pouts):
+            lane = d.decode_batch_packed_into(pw[k % 3], o["osdw"], o["osd0"], o["bp"], o["conv"], o["iters"], wait=False)
+            if k == 3:
+                d.synchronize(lane)  # waiting on one lane only
+        d.synchronize()
+        for k, o in enumerate(pouts):
+            w = want[k % 3]
+            assert (d.unpack_rows(o["osdw"], n) == w["osdw"]).all() and (d.unpack_rows(o["osd0"], n) == w["osd0"]).all(), k
+            assert (d.unpack_rows(o["bp"], n) == w["bp"]).all() and (o["iters"] == w["iters"]).all(), k
+        # a synchronous call after asynchronous ones drains them first and still agrees
+        assert (d.decode_batch(batches[1]) == want[1]["osdw"]).all()
