@@ -631,12 +631,16 @@ def test_large_code_rank_deficient_osd(gpu_ready):
                        {k: (v[nonan] if k == "llr" else v) for k, v in ref.items()})
 
 
-@pytest.mark.parametrize("name", ["e10", "cs3", "e15"])
+@pytest.mark.parametrize("name", ["e10", "cs3", "e15", "e15b", "cs42", "cs16sel"])
 def test_l29k_golden(gpu_ready, name):
     """BASELINE configs[4]'s code (14520 x 29524, 16 rows per thread in the OSD kernel) against oracle vectors
-    frozen in tests/golden/l29k_golden_*.npz (tests/golden/make_golden_l29k.py; the oracle needs minutes there).
-    "e15" is configs[4] at its stated settings: min-sum, max_iter = 100, osd_e order 15 (32767 candidates), q = 0.05;
-    two shots through OSD, one converged."""
+    frozen in tests/golden/l29k_golden_*.npz (tests/golden/make_golden_l29k.py; the oracle needs minutes per shot there).
+    "e15" / "e15b" are configs[4] at its stated settings: min-sum, max_iter = 100, osd_e order 15 (32767 candidates),
+    q = 0.05 -- 2 + 12 shots through OSD, 1 + 1 converged; "cs42" is the reference example's OSD setting (osd_cs order 42,
+    examples/qldpc_decode_example.py:15-16) with a uniform channel, 8 + 1 shots; "cs16sel" is osd_cs 16 with the per-shot
+    two-valued channel of the harness's channel_update (css_decode_sim.py:207-248: fp64 weights), 6 + 1 shots.  Every
+    fixture is decoded three times: which ROW becomes the pivot of a column depends on the order of LDS atomics in the
+    kernel's compact panel phase, the reduced system -- hence every output -- must not."""
     import ast
     import hashlib
     import os
@@ -654,12 +658,16 @@ def test_l29k_golden(gpu_ready, name):
     syn = np.unpackbits(g["syn"], axis=1)[:, :m]
     dec = BpOsdDecoder(H, **ast.literal_eval(str(g["cfg"])))
     assert dec.rank == 14520
-    out = dec.decode_batch(syn, want_osd0=True, want_bp=True)
-    assert (dec.batch_converge == g["converged"].astype(bool)).all()
-    assert (dec.batch_iter == g["iters"]).all()
-    assert (dec.batch_bp == np.unpackbits(g["bp"], axis=1)[:, :n]).all()
-    assert (dec.batch_osd0 == np.unpackbits(g["osd0"], axis=1)[:, :n]).all()
-    assert (out == np.unpackbits(g["osdw"], axis=1)[:, :n]).all()
+    extra = {}
+    if "prior_select" in g.files:
+        extra = dict(prior_select=np.unpackbits(g["prior_select"], axis=1)[:, :n], alt_channel_probs=np.full(n, float(g["alt_prob"])))
+    for rep in range(3 if name != "e10" else 1):
+        out = dec.decode_batch(syn, want_osd0=True, want_bp=True, **extra)
+        assert (dec.batch_converge == g["converged"].astype(bool)).all(), rep
+        assert (dec.batch_iter == g["iters"]).all(), rep
+        assert (dec.batch_bp == np.unpackbits(g["bp"], axis=1)[:, :n]).all(), rep
+        assert (dec.batch_osd0 == np.unpackbits(g["osd0"], axis=1)[:, :n]).all(), rep
+        assert (out == np.unpackbits(g["osdw"], axis=1)[:, :n]).all(), rep
 
 
 def test_large_code_limits_and_nonuniform_channel(gpu_ready, hgp4050):
