@@ -54,9 +54,12 @@ CONFIGS = {
 }
 # syndromes timed on ONE CPU thread / per worker of the all-cores leg (the oracle needs ~1 ms per H1922 syndrome,
 # ~4.5 s per L29k elimination plus ~7 ms per OSD-E candidate)
-# (large code: 3 syndromes on one thread, 2 per worker of the all-cores leg -- a quarter of them go through a ~4.5-minute OSD-E sweep)
-CPU_SAMPLE = {"l29k_ms_e15": (3, 2), "h1922_ps_cs60": (512, 128), "h1922_ps_cs60_clip20": (1024, 256),
+# (large code: a quarter of the syndromes go through a ~4.5-minute OSD-E sweep on one core.  One thread decodes syndromes 0..3
+# of batch 0 -- one of them needs OSD --, the all-cores leg one syndrome per worker from syndrome 20 on: with 16 workers six of
+# those need OSD, at most one per worker; ~12 minutes of CPU in all, which is why this is not the default bench line)
+CPU_SAMPLE = {"l29k_ms_e15": (4, 1), "h1922_ps_cs60": (512, 128), "h1922_ps_cs60_clip20": (1024, 256),
               "hgp625_ms_cs42": (4096, 1024), "hgp900_ms_cs42": (2048, 512)}
+CPU_ALL_CORES_OFFSET = {"l29k_ms_e15": 20}  # first syndrome of the all-cores leg (default: right behind the one-thread sample)
 CPU_SAMPLE_DEFAULT = (8192, 2048)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 CLOCK_HZ = 2.4e9        # peak shader clock (MI355X_MICROARCH.md, chip-level parameters)
@@ -189,16 +192,17 @@ def main():
         # all host cores: one process per core over disjoint shards of the same batch (the reference's execution model
         # is one decode at a time per process, css_decode_sim.py:519-520)
         procs = args.cpu_procs if args.cpu_procs >= 0 else min(usable_cores(), 64)
-        per = min(cpu_per_proc, max(0, (B - ns)) // max(procs, 1))
+        lo_all = max(ns, CPU_ALL_CORES_OFFSET.get(args.config, ns))
+        per = min(cpu_per_proc, max(0, (B - lo_all)) // max(procs, 1))
         if procs > 1 and per > 0:
             import multiprocessing as mp
 
-            shards = [np.ascontiguousarray(batches[0][1][ns + i * per: ns + (i + 1) * per]) for i in range(procs)]
+            shards = [np.ascontiguousarray(batches[0][1][lo_all + i * per: lo_all + (i + 1) * per]) for i in range(procs)]
             with mp.get_context("fork").Pool(procs) as pool:
                 t0 = time.perf_counter()
                 res = pool.map(cpu_baseline_worker, [(H.indptr, H.indices, H.shape, kw, s) for s in shards])
                 wall = time.perf_counter() - t0
-            cpu_all = dict(procs=procs, per=per, wall=wall, lo=ns, osdw=np.concatenate([r[1] for r in res]),
+            cpu_all = dict(procs=procs, per=per, wall=wall, lo=lo_all, osdw=np.concatenate([r[1] for r in res]),
                            iters=np.concatenate([r[3] for r in res]), busy=max(r[0] for r in res))
         stop.set()
 

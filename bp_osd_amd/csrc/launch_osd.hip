@@ -3,6 +3,7 @@
 #include "internal.h"
 
 #include "osd_wave_kernel.hip.h"
+#include "osd_mw_kernel.hip.h"
 
 using namespace bposd;
 using namespace bposd_host;
@@ -73,7 +74,51 @@ static int osd_wave_shape(const bposd_handle* h, const OsdParams& P, long long B
     return 0;
 }
 
+// a few waves per elimination, rows in registers (osd_mw_kernel.hip.h): mid-size codes, integer weights
+template <int NWV, int RPL, int W, int MINW>
+static int launch_osd_mw_t(bposd_handle* h, const OsdParams& P, long long B) {
+    auto k = osd_mw_kernel<NWV, RPL, W, MINW>;
+    const size_t lds = osdm_lds_bytes(osdw_nsort(h->n), NWV, RPL, W);
+    { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
+    int wg_per_cu = 1;
+    { int rc_occ = cached_occupancy(h, (const void*)k, 64 * NWV, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
+    wg_per_cu = std::max(1, std::min(wg_per_cu, 16));
+    if (getenv("BPOSD_DEBUG_OCC")) fprintf(stderr, "[bposd] osd_mw_kernel<%d,%d,%d>: %zu B LDS, %d workgroups per CU\n", NWV, RPL, W, lds, wg_per_cu);
+    long long grid = std::min<long long>(B, (long long)h->num_cu * wg_per_cu);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * NWV), lds, h->osd_now ? h->osd_now : h->cur->osd_stream, P);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+// 0 = not this kernel.  Shapes: 1 = 2 waves x 4 rows x 15 words (m <= 512, n <= 959: [[900,36,10]], surface codes d = 19 ... 21),
+// 2 = 4 waves x 3 rows x 20 words (m <= 768, n <= 1279: surface d = 23 ... 25), 3 = 8 waves x 2 rows x 31 words (m <= 1024,
+// n <= 1983: H1922 -- only when asked for with variant 2), 11 = shape 1 as 4 waves x 2 rows (A/B: BPOSD_OSD_MW_4X2=1)
+static int osd_mw_shape(const bposd_handle* h, const OsdParams& P, long long B) {
+    static const bool on = !(getenv("BPOSD_OSD_MW") && getenv("BPOSD_OSD_MW")[0] == '0');
+    static const bool alt = getenv("BPOSD_OSD_MW_4X2") && getenv("BPOSD_OSD_MW_4X2")[0] == '1';
+    static const long long min_batch = getenv("BPOSD_OSD_MW_MIN_BATCH") ? atoll(getenv("BPOSD_OSD_MW_MIN_BATCH")) : 2048;
+    if (!on || h->osd_variant == 1 || P.cost != nullptr || P.dbg != nullptr) return 0;  // switched off; fp64 weights; diagnostics
+    if (h->osd_variant == 0 && std::max<long long>(B, h->batch_hint) < min_batch) return 0;
+    if (P.osd_method == BPOSD_OSD_E && P.osd_order > OSDW_MAX_E) return 0;
+    const int m = h->m, n1 = h->n + 1;
+    if (m <= 320 && n1 <= 640) return 0;  // the one-wave kernel's
+    if (m <= 512 && n1 <= 960) return alt ? 11 : 1;
+    if (m <= 768 && n1 <= 1280) return 2;
+    if (m <= 1024 && n1 <= 1984) return h->osd_variant == 2 ? 3 : 0;
+    return 0;
+}
+
 int launch_osd(bposd_handle* h, const OsdParams& P, long long B) {
+    if (const int shp = osd_mw_shape(h, P, B)) {
+        h->last_osd_kernel = 4;
+        switch (shp) {
+            case 1: return launch_osd_mw_t<2, 4, 15, 3>(h, P, B);
+            case 11: return launch_osd_mw_t<4, 2, 15, 4>(h, P, B);
+            case 2: return launch_osd_mw_t<4, 3, 20, 2>(h, P, B);
+            case 3: return launch_osd_mw_t<8, 2, 31, 2>(h, P, B);
+        }
+    }
     h->last_osd_kernel = osd_wave_shape(h, P, B) ? 2 : 1;
     switch (osd_wave_shape(h, P, B)) {
         case 1: return launch_osd_wave_t<1, 2>(h, P, B);

@@ -570,7 +570,7 @@ class BpOsdDecoder:
         return {"kernel": self.BP_KERNEL_NAMES.get(k.value, "none"), "read_cycles": int(mdl[0]), "read_floor": int(mdl[1]),
                 "write_cycles": int(mdl[2]), "write_floor": int(mdl[3])}
 
-    OSD_KERNEL_NAMES = {1: "osd_kernel", 2: "osd_wave_kernel", 3: "osd_large_kernel"}
+    OSD_KERNEL_NAMES = {1: "osd_kernel", 2: "osd_wave_kernel", 3: "osd_large_kernel", 4: "osd_mw_kernel"}
 
     def set_osd_variant(self, variant: int):
         """Tuning / test knob: 0 auto; 1 one workgroup per elimination; 2 one wave per elimination where it applies."""

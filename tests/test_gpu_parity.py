@@ -911,7 +911,7 @@ def test_osd_wave_kernel_equals_workgroup_kernel_and_oracle(gpu_ready, surface13
         a = BpOsdDecoder(H, **kw)
         a.set_osd_variant(2)  # (auto takes the wave kernel for calls of >= 4096 syndromes: a lone elimination is faster on a workgroup)
         ra = _gpu_decode(a, syn)
-        assert a.last_osd_kernel() == ("osd_wave_kernel" if m <= 320 else "osd_kernel"), (method, order)
+        assert a.last_osd_kernel() == ("osd_wave_kernel" if m <= 320 else "osd_mw_kernel"), (method, order)
         b = BpOsdDecoder(H, **kw)
         b.set_osd_variant(1)
         rb = _gpu_decode(b, syn)
