@@ -9,13 +9,13 @@ using namespace bposd;
 using namespace bposd_host;
 
 namespace bposd_host {
-template <int W>
-static int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
+template <int W, bool PACKED>
+static int launch_osd_tp(bposd_handle* h, const OsdParams& P, long long B) {
     // OSD_RPT rows per thread: 4 waves cover 1024 rows
     const int rows_per_thread = OSD_RPT;
     const int NT = std::min(64 * OSD_MAXW, std::max(64, ((h->m + rows_per_thread - 1) / rows_per_thread + 63) / 64 * 64));
     const size_t lds = osd_lds_bytes(W, NT * OSD_RPT);
-    auto k = osd_kernel<W>;
+    auto k = osd_kernel<W, PACKED>;
     { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
     // persistent workgroups: as many per CU as registers and LDS admit (H1922: one 8-wave workgroup; the reference's
     // [[400,16,6]] code: four 2-wave workgroups -- with one per CU its 32 k eliminations per batch took longer than BP)
@@ -33,9 +33,14 @@ static int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
     return 0;
 }
 
+template <int W>
+static int launch_osd_t(bposd_handle* h, const OsdParams& P, long long B) {
+    return P.packed_io ? launch_osd_tp<W, true>(h, P, B) : launch_osd_tp<W, false>(h, P, B);
+}
+
 int osd_words(int n) {
     const int need = (n + 1 + 63) / 64;
-    for (int w : {1, 2, 4, 8, 16, 31, 32})
+    for (int w : {1, 2, 4, 8, 16, 24, 31, 32})
         if (w >= need) return w;
     return 0;
 }
@@ -104,7 +109,7 @@ static int osd_mw_shape(const bposd_handle* h, const OsdParams& P, long long B) 
     const int m = h->m, n1 = h->n + 1;
     if (m <= 320 && n1 <= 640) return 0;  // the one-wave kernel's
     if (m <= 512 && n1 <= 960) return alt ? 11 : 1;
-    if (m <= 768 && n1 <= 1280) return 2;
+    if (m <= 768 && n1 <= 1280) return h->osd_variant == 2 ? 2 : 0;  // (measured slower than osd_kernel<24>: surface code d = 25)
     if (m <= 1024 && n1 <= 1984) return h->osd_variant == 2 ? 3 : 0;
     return 0;
 }
@@ -132,6 +137,7 @@ int launch_osd(bposd_handle* h, const OsdParams& P, long long B) {
         case 4: return launch_osd_t<4>(h, P, B);
         case 8: return launch_osd_t<8>(h, P, B);
         case 16: return launch_osd_t<16>(h, P, B);
+        case 24: return launch_osd_t<24>(h, P, B);
         case 31: return launch_osd_t<31>(h, P, B);
         case 32: return launch_osd_t<32>(h, P, B);
     }

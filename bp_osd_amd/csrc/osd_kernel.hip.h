@@ -294,7 +294,9 @@ __device__ __forceinline__ void osd_apply_tables(unsigned long long (&row)[OSD_R
     }
 }
 
-template <int W>
+// PACKED: the packed-I/O form (OsdParams::packed_io) as a compile-time switch -- the byte form's register allocation (256 VGPRs
+// at W = 31) does not pay for it
+template <int W, bool PACKED = false>
 __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RPT = OSD_RPT;
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
 #pragma unroll
                     for (int w = 0; w < W; ++w) row[k][w] |= (jw == w) ? bit : 0ull;
                 }
-                if (osd_synd_bit(P.synd, P.packed_io, s, m, r)) row[k][W - 1] |= 1ull << 63;
+                if (osd_synd_bit(P.synd, PACKED ? 1 : 0, s, m, r)) row[k][W - 1] |= 1ull << 63;
             }
         }
 
@@ -606,8 +608,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             if (lane == 0) L.npmask[w] = np;
         }
         __syncthreads();
-        osd_store_row(P.out_osd0, P.packed_io, (size_t)s, n, L.xout, tid, NT);
-        osd_store_row(P.cmp_osd0, P.packed_io, (size_t)slot_id, n, L.xout, tid, NT);
+        osd_store_row(P.out_osd0, PACKED ? 1 : 0, (size_t)s, n, L.xout, tid, NT);
+        osd_store_row(P.cmp_osd0, PACKED ? 1 : 0, (size_t)slot_id, n, L.xout, tid, NT);
 
         int w0 = 0;
         for (int q = 0; q < ncv; ++q) w0 += __popcll(L.yvec[q]);
@@ -891,8 +893,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         // ------------------------------------------------- write the OSD-W solution
         if (sel_a == -1) {
             // OSD-0 stays the best
-            osd_store_row(P.out_osdw, P.packed_io, (size_t)s, n, L.xout, tid, NT);
-            osd_store_row(P.cmp_osdw, P.packed_io, (size_t)slot_id, n, L.xout, tid, NT);
+            osd_store_row(P.out_osdw, PACKED ? 1 : 0, (size_t)s, n, L.xout, tid, NT);
+            osd_store_row(P.cmp_osdw, PACKED ? 1 : 0, (size_t)slot_id, n, L.xout, tid, NT);
         } else {
             __syncthreads();
             for (int i = tid; i < n; i += NT) L.xout[i] = 0;
@@ -928,8 +930,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             for (int k = 0; k < RPT; ++k)
                 if (used[k] && xs[k]) L.xout[L.kidx[mypos[k]]] = 1;
             __syncthreads();
-            osd_store_row(P.out_osdw, P.packed_io, (size_t)s, n, L.xout, tid, NT);
-            osd_store_row(P.cmp_osdw, P.packed_io, (size_t)slot_id, n, L.xout, tid, NT);
+            osd_store_row(P.out_osdw, PACKED ? 1 : 0, (size_t)s, n, L.xout, tid, NT);
+            osd_store_row(P.cmp_osdw, PACKED ? 1 : 0, (size_t)slot_id, n, L.xout, tid, NT);
         }
         OSD_STAMP(6);
         __syncthreads();
