@@ -35,10 +35,8 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     // every sub-array is [grid][count], laid out back to back in one allocation
     const size_t g = (size_t)grid;
     const bool wide_cs = Q.osd_method == BPOSD_OSD_CS && Q.osd_order > OSDL_MAXSPAN;
-    if (wide_cs && fpw)
-        return fail(h, BPOSD_ERR_UNSUPPORTED, "osd_cs order %d > %d with a non-uniform or per-shot channel is not supported by the HBM-resident "
-                    "OSD kernel (m=%d n=%d)", Q.osd_order, OSDL_MAXSPAN, h->m, h->n);
-    const size_t sizes[15] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
+    const bool wide_fp = wide_cs && fpw;  // fp64 weights over a pair span beyond 16: 64-bit column words per row / per bit in HBM
+    const size_t sizes[17] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
                              g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
                              g * sizeof(int) * (size_t)Q.nsort,                    // kidx
                              g * sizeof(int) * (size_t)h->n,                       // inv
@@ -52,18 +50,22 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
                              fpw ? g * sizeof(double) * (size_t)Q.wdn : 0,                   // wd_ws
                              fpw ? g * sizeof(unsigned short) * (size_t)Q.mrl : 0,           // am_ws
                              g * sizeof(int) * (size_t)Q.mrl,                                // alist
-                             wide_cs ? g * sizeof(unsigned long long) * (size_t)OSDL_MAXSPAN_CS * RPT * OSDL_NW : 0};  // colvec_ws
+                             wide_cs ? g * sizeof(unsigned long long) * (size_t)OSDL_MAXSPAN_CS * RPT * OSDL_NW : 0,  // colvec_ws
+                             wide_fp ? g * sizeof(unsigned long long) * (size_t)Q.mrl : 0,                   // am64_ws
+                             wide_fp ? g * sizeof(unsigned long long) * (size_t)h->n : 0};                   // cm64_ws
     size_t total = 0;
     for (size_t b : sizes) total += a256(b);
     int rc = ensure_lanes(h, &Lane::osdl_ws, total);
     if (rc) return rc;
-    unsigned char* ptrs[15];
+    unsigned char* ptrs[17];
     {
         unsigned char* base = (unsigned char*)h->cur->osdl_ws.p;
-        for (int i = 0; i < 15; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
+        for (int i = 0; i < 17; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
     }
     Q.alist = (int*)ptrs[13];
     Q.colvec_ws = wide_cs ? (unsigned long long*)ptrs[14] : nullptr;
+    Q.am64_ws = wide_fp ? (unsigned long long*)ptrs[15] : nullptr;
+    Q.cm64_ws = wide_fp ? (unsigned long long*)ptrs[16] : nullptr;
     Q.costs_ws = (double*)ptrs[10];
     Q.wd_ws = (double*)ptrs[11];
     Q.am_ws = (unsigned short*)ptrs[12];

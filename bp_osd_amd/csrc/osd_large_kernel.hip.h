@@ -103,6 +103,10 @@ struct OsdLargeParams {
     unsigned long long* __restrict__ colvec_ws;  // [grid][OSDL_MAXSPAN_CS][RPT * OSDL_NW] reduced columns when osd_cs order > 16
     double* __restrict__ wd_ws;             // [grid][wdn] weights of the single candidates / of the osd_e patterns
     unsigned short* __restrict__ am_ws;     // [grid][mrl] per row: its entries in the first <= 16 non-pivot columns
+    // osd_cs with fp64 weights and a pair span beyond 16 (the reference harness's defaults on a large code: osd_cs with
+    // channel_update = "x->z", css_decode_sim.py:73-80,207-248): the same per row / per bit in 64-bit words, in HBM
+    unsigned long long* __restrict__ am64_ws;  // [grid][mrl] nullable
+    unsigned long long* __restrict__ cm64_ws;  // [grid][n]   nullable: per original bit, its entries in the first <= 64 non-pivot columns
     int wdn;                                // max(64 * W, 2^16)
 };
 
@@ -493,6 +497,9 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         unsigned short* am = P.cost ? P.am_ws + (size_t)blockIdx.x * MRL : nullptr;
         if (am)
             for (int i = tid; i < MRL; i += NT) am[i] = 0;
+        unsigned long long* am64 = (P.cost && P.am64_ws) ? P.am64_ws + (size_t)blockIdx.x * MRL : nullptr;
+        if (am64)
+            for (int i = tid; i < MRL; i += NT) am64[i] = 0ull;
         __syncthreads();
         for (int k = 2; k <= NS; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -1172,7 +1179,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         if (P.osd_method >= 2 && P.osd_order > 0) {
             // pair span of osd_cs with integer weights: up to 64 columns (/root/reference/examples/qldpc_decode_example.py:16
             // passes 42); beyond 16 the reduced columns go to a global workspace instead of LDS
-            const int span_cap = (P.osd_method == 3 && !P.cost && P.colvec_ws) ? OSDL_MAXSPAN_CS : OSDL_MAXSPAN;
+            const int span_cap = (P.osd_method == 3 && P.colvec_ws && (!P.cost || am64)) ? OSDL_MAXSPAN_CS : OSDL_MAXSPAN;
             const int wspan = P.osd_order < span_cap ? P.osd_order : span_cap;
             unsigned long long* colv = wspan > OSDL_MAXSPAN ? P.colvec_ws + (size_t)blockIdx.x * OSDL_MAXSPAN_CS * NCV : colvec;
             int tcount = gauss ? ntc_g : 0;  // gauss mode: colvec / tpos / am come from the back-substitution
@@ -1202,7 +1209,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         if (tcount < wspan) {
                             const unsigned long long cb = __ballot(usedk && bitv);
                             if (lane == 0) colv[tcount * NCV + k * OSDL_NW + wave] = cb;
-                            if (am && usedk && bitv) am[tid + k * NT] |= (unsigned short)(1u << tcount);  // only the row's owner
+                            if (am64 && usedk && bitv) am64[tid + k * NT] |= 1ull << tcount;  // only the row's owner
+                            else if (am && usedk && bitv && tcount < 16) am[tid + k * NT] |= (unsigned short)(1u << tcount);
                         }
                     }
                     if (lane == b) acc += cnt;
@@ -1223,6 +1231,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 double* pairw = (double*)(info + ((n + 1) & ~1));
                 double* costs = P.costs_ws + (size_t)blockIdx.x * n;
                 double* wd = P.wd_ws + (size_t)blockIdx.x * P.wdn;
+                unsigned long long* cm64 = am64 ? P.cm64_ws + (size_t)blockIdx.x * n : nullptr;
+                if (cm64) pairw = wd + 32768;  // up to 2016 pair weights: behind the singles' (64 W <= 32768 entries of wd's 65536)
                 OSDL_FRESH_TID();
                 for (int i = tid; i < n; i += NT) {
                     double ci = P.cost[i];
@@ -1234,7 +1244,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     const int pos = inv[i];
                     const int pr = pivrow[pos];
                     unsigned int e = (unsigned int)xout[i] << 31;
-                    if (pr >= 0) e |= (1u << 30) | ((unsigned int)pr << 16) | am[pr];
+                    if (cm64) {  // wide pair span: the column entries live in a 64-bit word per bit in HBM
+                        unsigned long long cmv = 0ull;
+                        if (pr >= 0) { e |= (1u << 30) | ((unsigned int)pr << 16); cmv = am64[pr]; }
+                        else
+                            for (int a = 0; a < ntc; ++a)
+                                if (tpos[a] == pos) cmv |= 1ull << a;
+                        cm64[i] = cmv;
+                    } else if (pr >= 0) e |= (1u << 30) | ((unsigned int)pr << 16) | am[pr];
                     else
                         for (int a = 0; a < ntc; ++a)
                             if (tpos[a] == pos) e |= 1u << a;
@@ -1273,11 +1290,17 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     for (int pidx = tid; pidx < npairs; pidx += NT) {
                         int a = 0, rem = pidx;
                         while (rem >= ntc - 1 - a) { rem -= ntc - 1 - a; ++a; }
-                        const unsigned int pat = (1u << a) | (1u << (a + 1 + rem));
                         double acc = 0.0;
-                        for (int i = 0; i < n; ++i) {
-                            const unsigned int e = info[i];
-                            if (((e >> 31) ^ (unsigned int)__popc(e & pat)) & 1u) acc += costs[i];
+                        if (cm64) {
+                            const unsigned long long pat = (1ull << a) | (1ull << (a + 1 + rem));
+                            for (int i = 0; i < n; ++i)
+                                if (((info[i] >> 31) ^ (unsigned int)__popcll(cm64[i] & pat)) & 1u) acc += costs[i];
+                        } else {
+                            const unsigned int pat = (1u << a) | (1u << (a + 1 + rem));
+                            for (int i = 0; i < n; ++i) {
+                                const unsigned int e = info[i];
+                                if (((e >> 31) ^ (unsigned int)__popc(e & pat)) & 1u) acc += costs[i];
+                            }
                         }
                         pairw[pidx] = acc;
                         atomicMin(&best64[1], (unsigned long long)__double_as_longlong(acc));

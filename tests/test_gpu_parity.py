@@ -691,10 +691,20 @@ def test_large_code_limits_and_nonuniform_channel(gpu_ready, hgp4050):
     for order in (42, 64, 17):
         kw = dict(error_rate=0.07, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=order)
         _compare_exact(_gpu_decode(BpOsdDecoder(H, **kw), syn), OracleDecoder(H, **kw).decode_batch(syn))
-    # ... which a non-uniform channel (fp64 weights) does not have beyond order 16: refused when the decode is asked for
-    g = BpOsdDecoder(H, channel_probs=probs, max_iter=6, bp_method="ms", osd_method="osd_cs", osd_order=42)
-    with pytest.raises(ValueError):
-        g.decode_batch(syn)
+    # ... and with a non-uniform channel (fp64 weights: 64-bit column words per row and per bit in a global workspace) -- the
+    # reference harness's DEFAULTS on a large code are osd_cs with channel_update="x->z" (css_decode_sim.py:73-80,207-248)
+    for order in (42, 64, 17):
+        kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=order)
+        _compare_exact(_gpu_decode(BpOsdDecoder(H, **kw), syn), OracleDecoder(H, **kw).decode_batch(syn))
+    sel42 = (rng.random((len(syn), n)) < 0.15).astype(np.uint8)
+    kw = dict(channel_probs=np.full(n, 0.04), max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_cs", osd_order=42)
+    g = BpOsdDecoder(H, **kw)
+    got = g.decode_batch(syn, prior_select=sel42, alt_channel_probs=np.full(n, 0.3))
+    o = OracleDecoder(H, **kw)
+    for b in range(len(syn)):
+        o.update_channel_probs(np.where(sel42[b] != 0, 0.3, 0.04))
+        r = o.decode(syn[b])
+        assert (got[b] == r["osdw"]).all() and (g.batch_osd0[b] == r["osd0"]).all(), b
     for method, order in (("osd_0", 0), ("osd_e", 4), ("osd_e", 9), ("osd_cs", 2), ("osd_cs", 7), ("osd_cs", 16)):
         for weight_fn in (0, 1):
             kw = dict(channel_probs=probs, max_iter=6, bp_method="ms", ms_scaling_factor=0.625, osd_method=method,
