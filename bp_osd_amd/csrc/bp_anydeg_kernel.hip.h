@@ -128,7 +128,7 @@ __global__ __launch_bounds__(BPA_NT) void bp_anydeg_kernel(const BpAnyParams P) 
                             dpar ^= dec[P.ci[e]];
                             if (last) continue;
                             pre[e] = t;
-                            const double th = pm_tanh(msg[e] / 2);
+                            const double th = pm_tanh_half(msg[e]);
                             thv[e] = th;
                             t *= th;
                         }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(BPA_NT) void bp_anydeg_kernel(const BpAnyParams P) 
                             const double sg = sbit ? -1.0 : 1.0;
                             for (int e = e1 - 1; e >= e0; --e) {
                                 const double x = pre[e] * t;
-                                double o = sg * pm_log((1 + x) / (1 - x));
+                                double o = sg * pm_log_quot(1 + x, 1 - x);
                                 if (P.ps_clip > 0.0) {  // the comparisons are false for NaN, as on the CPU
                                     if (o > P.ps_clip) o = P.ps_clip;
                                     if (o < -P.ps_clip) o = -P.ps_clip;

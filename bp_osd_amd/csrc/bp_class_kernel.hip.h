@@ -179,7 +179,7 @@ __device__ __forceinline__ void check_pass_deg(msg_ptr mc, bool sbit, int alpha_
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             pre[k] = t;
-            th[k] = pm_tanh(v[k] / 2);
+            th[k] = pm_tanh_half(v[k]);
             t *= th[k];
         }
         t = 1.0;
@@ -187,7 +187,7 @@ __device__ __forceinline__ void check_pass_deg(msg_ptr mc, bool sbit, int alpha_
 #pragma unroll
         for (int k = D - 1; k >= 0; --k) {
             const double x = pre[k] * t;
-            double o = sg * pm_log((1 + x) / (1 - x));
+            double o = sg * pm_log_quot(1 + x, 1 - x);
             if (ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
                 if (o > ps_clip) o = ps_clip;
                 if (o < -ps_clip) o = -ps_clip;

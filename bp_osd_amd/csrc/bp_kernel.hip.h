@@ -323,7 +323,7 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                                 pre[k] = t;
                                 th[k] = 1.0;
                                 if (REG || k < deg) {
-                                    th[k] = pm_tanh(v[k] / 2);
+                                    th[k] = pm_tanh_half(v[k]);
                                     t *= th[k];
                                 }
                             }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                             for (int k = DC - 1; k >= 0; --k) {
                                 if (REG || k < deg) {
                                     const double x = pre[k] * t;
-                                    double o = sg * pm_log((1 + x) / (1 - x));
+                                    double o = sg * pm_log_quot(1 + x, 1 - x);
                                     if (P.ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
                                         if (o > P.ps_clip) o = P.ps_clip;
                                         if (o < -P.ps_clip) o = -P.ps_clip;

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                             pre[k] = t;
                             th[k] = 1.0;
                             if (k < deg) {
-                                th[k] = pm_tanh(v[k] / 2);
+                                th[k] = pm_tanh_half(v[k]);
                                 t *= th[k];
                             }
                         }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                         for (int k = DC - 1; k >= 0; --k) {
                             if (k < deg) {
                                 const double x = pre[k] * t;
-                                double o = sg * pm_log((1 + x) / (1 - x));
+                                double o = sg * pm_log_quot(1 + x, 1 - x);
                                 if (P.ps_clip > 0.0) {
                                     if (o > P.ps_clip) o = P.ps_clip;
                                     if (o < -P.ps_clip) o = -P.ps_clip;

@@ -109,8 +109,8 @@ __global__ __launch_bounds__(BPS_NT) void bp_serial_kernel(const BpSerialParams 
                             if (P.bp_method == 0) {
                                 double prod = 1.0;
                                 for (int g = g0; g < g1; ++g)
-                                    if (g != e) prod *= pm_tanh(b2c[g] / 2);
-                                msg = ((syn[c] & 1) ? -1.0 : 1.0) * pm_log((1 + prod) / (1 - prod));
+                                    if (g != e) prod *= pm_tanh_half(b2c[g]);
+                                msg = ((syn[c] & 1) ? -1.0 : 1.0) * pm_log_quot(1 + prod, 1 - prod);
                                 if (P.ps_clip > 0.0) {
                                     if (msg > P.ps_clip) msg = P.ps_clip;
                                     if (msg < -P.ps_clip) msg = -P.ps_clip;

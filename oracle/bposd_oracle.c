@@ -174,20 +174,21 @@ static void bp_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *converged,
                 double temp = 1.0;
                 for (int e = d->rp[c]; e < d->rp[c + 1]; e++) {
                     d->c2b[e] = temp;
-                    temp *= pm ? pm_tanh(d->b2c[e] / 2) : tanh(d->b2c[e] / 2);
+                    temp *= pm ? pm_tanh_half(d->b2c[e]) : tanh(d->b2c[e] / 2);
                 }
                 temp = 1;
                 for (int e = d->rp[c + 1] - 1; e >= d->rp[c]; e--) {
                     d->c2b[e] *= temp;
                     int message_sign = syn[c] ? -1 : 1;
-                    const double ratio = (1 + d->c2b[e]) / (1 - d->c2b[e]);
-                    d->c2b[e] = message_sign * (pm ? pm_log(ratio) : log(ratio));
+                    /* ps_math = 1: the kernels' routines (portable_math.h, "round 4": same operation order, the quotient folded
+                     * into the logarithm) */
+                    d->c2b[e] = message_sign * (pm ? pm_log_quot(1 + d->c2b[e], 1 - d->c2b[e]) : log((1 + d->c2b[e]) / (1 - d->c2b[e])));
                     if (d->cfg.ps_clip > 0) { /* build-owned switch; upstream does not clip (Appendix A.3 [M]) */
                         if (d->c2b[e] > d->cfg.ps_clip) d->c2b[e] = d->cfg.ps_clip;
                         if (d->c2b[e] < -d->cfg.ps_clip) d->c2b[e] = -d->cfg.ps_clip;
                     }
                     if (!d->diag_first_nonfinite && !isfinite(d->c2b[e])) d->diag_first_nonfinite = it;
-                    temp *= pm ? pm_tanh(d->b2c[e] / 2) : tanh(d->b2c[e] / 2);
+                    temp *= pm ? pm_tanh_half(d->b2c[e]) : tanh(d->b2c[e] / 2);
                 }
             }
         } else {
@@ -293,9 +294,8 @@ static void bp_decode_serial(oracle_decoder *d, const uint8_t *syn, uint8_t *con
                 if (d->cfg.bp_method == 0) {
                     double prod = 1.0;
                     for (int g = d->rp[c]; g < d->rp[c + 1]; g++)
-                        if (g != e) prod *= pm ? pm_tanh(d->b2c[g] / 2) : tanh(d->b2c[g] / 2);
-                    const double ratio = (1 + prod) / (1 - prod);
-                    msg = (syn[c] ? -1 : 1) * (pm ? pm_log(ratio) : log(ratio));
+                        if (g != e) prod *= pm ? pm_tanh_half(d->b2c[g]) : tanh(d->b2c[g] / 2);
+                    msg = (syn[c] ? -1 : 1) * (pm ? pm_log_quot(1 + prod, 1 - prod) : log((1 + prod) / (1 - prod)));
                     if (d->cfg.ps_clip > 0) {
                         if (msg > d->cfg.ps_clip) msg = d->cfg.ps_clip;
                         if (msg < -d->cfg.ps_clip) msg = -d->cfg.ps_clip;
@@ -567,6 +567,14 @@ int oracle_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *osdw, uint8_t 
 /* vectorised access to bp_osd_amd/csrc/portable_math.h for tests/test_portable_math.py: which = 0 tanh, 1 log, 2 expm1 */
 void oracle_portable_math(int32_t which, const double *x, double *y, int64_t count) {
     for (int64_t i = 0; i < count; i++) y[i] = which == 0 ? pm_tanh(x[i]) : (which == 1 ? pm_log(x[i]) : pm_expm1(x[i]));
+}
+
+/* round 4: tanh(x / 2) with one division, log(A / B) with one division */
+void oracle_portable_tanh_half(const double *x, double *y, int64_t count) {
+    for (int64_t i = 0; i < count; i++) y[i] = pm_tanh_half(x[i]);
+}
+void oracle_portable_log_quot(const double *a, const double *b, double *y, int64_t count) {
+    for (int64_t i = 0; i < count; i++) y[i] = pm_log_quot(a[i], b[i]);
 }
 
 int oracle_decode_batch_diag(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,

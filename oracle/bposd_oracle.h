@@ -71,6 +71,8 @@ int oracle_decode_batch(oracle_decoder *d, const uint8_t *syndromes, int64_t B, 
 
 /* y[i] = f(x[i]) with f from bp_osd_amd/csrc/portable_math.h (which: 0 tanh, 1 log, 2 expm1); for the accuracy test. */
 void oracle_portable_math(int32_t which, const double *x, double *y, int64_t count);
+void oracle_portable_tanh_half(const double *x, double *y, int64_t count);
+void oracle_portable_log_quot(const double *a, const double *b, double *y, int64_t count);
 
 /* oracle_decode_batch plus per-shot BP diagnostics (see oracle_last_bp_diag); the three arrays are nullable. */
 int oracle_decode_batch_diag(oracle_decoder *d, const uint8_t *syndromes, int64_t B, uint8_t *osdw,

@@ -85,6 +85,29 @@ def portable_math(which, x):
     return y
 
 
+def portable_tanh_half(x):
+    """tanh(x / 2) as the product-sum kernels evaluate it (portable_math.h: pm_tanh_half, one division)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    lib = _load()
+    lib.oracle_portable_tanh_half.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.oracle_portable_tanh_half.restype = None
+    lib.oracle_portable_tanh_half(x.ctypes.data, y.ctypes.data, x.size)
+    return y
+
+
+def portable_log_quot(a, b):
+    """log(a / b) as the product-sum kernels evaluate it (portable_math.h: pm_log_quot, one division)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    y = np.empty_like(a)
+    lib = _load()
+    lib.oracle_portable_log_quot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.oracle_portable_log_quot.restype = None
+    lib.oracle_portable_log_quot(a.ctypes.data, b.ctypes.data, y.ctypes.data, a.size)
+    return y
+
+
 class OracleDecoder:
     def __init__(self, pcm, error_rate=None, channel_probs=None, max_iter=0, bp_method="ms",
                  ms_scaling_factor=1.0, osd_method="osd0", osd_order=0, sort_tie_policy=0, weight_fn=0,

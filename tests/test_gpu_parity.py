@@ -296,7 +296,7 @@ def test_product_sum_vs_oracle(gpu_ready, h1922):
     glibc's in the last bit on ~1 % of arguments -> tolerance parity, stated here (the bit-exact comparison against the
     oracle's portable-math mode is test_product_sum_clip_vs_oracle_live / test_config2_...): on shots that
     converge in the same iteration on both sides (>= 98% of shots) the integer outputs are identical
-    and LLRs agree to 1e-9 relative after clipping to +-30 on all but 1e-4 of entries; every output,
+    and LLRs agree to 1e-9 relative after clipping to +-30 on all but 3e-4 of entries; every output,
     converged or not, reproduces its syndrome; OSD outputs of non-converged shots are compared
     statistically (mean correction weight within 3%), see the comment at the end."""
     from bp_osd_amd import BpOsdDecoder
@@ -312,7 +312,9 @@ def test_product_sum_vs_oracle(gpu_ready, h1922):
     conv = same & r["converged"]
     assert (r["osdw"][conv] == ref["osdw"][conv]).all()
     bad, nanfrac = _ps_llr_mismatch_fraction(r["llr"][conv], ref["llr"][conv])
-    assert bad <= 1e-4, (bad, nanfrac)
+    # (round 4: the kernels fold the quotient (1 + x) / (1 - x) into the logarithm -- one division instead of two -- so 8 % of
+    # their log evaluations differ from glibc's in the last bits instead of 2 %; measured here 1.5e-4, four-division form 0.6e-4)
+    assert bad <= 3e-4, (bad, nanfrac)
     assert (_syndrome_of(h1922.hz, r["osdw"]) == syn).all()
     # Non-converged shots: the LLRs handed to OSD contain +-inf and NaN on both sides (saturated
     # messages), for which the reliability order is not even well defined in the reference (its
@@ -1244,7 +1246,9 @@ def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
     if name == "clip20":
         # with clipping nothing saturates, but in this highly symmetric code most shots hold LLR pairs that are equal in
         # exact arithmetic and differ in the last bits, so few shots are "clean"; last-bit libm differences move the
-        # iteration of convergence (or a near-tie of the final order) on ~10 % of the others (measured: 188 of 2048)
+        # iteration of convergence (or a near-tie of the final order) on ~10 % of the others (measured: 188 of 2048 with the
+        # four-division evaluation of rounds 1-3, 207 with round 4's two-division one; a ONE-division form that keeps tanh as a
+        # fraction moved the roundings of 1 - x and changed 374 -- measured, not kept: portable_math.h)
         assert (~same).mean() <= 0.15, (~same).mean()
     else:
         assert (clean | allnan).mean() >= 0.55, (clean | allnan).mean()
