@@ -247,15 +247,36 @@ def main():
     x_packed = [torch.empty((B, wpr), dtype=torch.int64) for _ in range(2)] if (do_gather and args.rehearse_on_one_gpu) else d_packed
     stats = {"bp_ms": [], "osd_ms": [], "iters": 0, "osd": 0}
     lane_of_slot = {}
+    # N > 1 with the gather: where the kernels write bit-packed rows themselves (every small-path code) the decode fills the
+    # gather's buffer directly -- packed syndromes in, osdw / osd0 / bp out as 64-bit words -- and no pack kernel runs between
+    # the decode and the gather; on the HBM-resident path the byte rows are packed by bposd_pack_rows_device as before
+    native_gather = False
+    if do_gather:
+        try:
+            d_psyn = [torch.from_numpy(np.concatenate([dec.pack_rows(b[1][lo:lo + 16384]) for lo in range(0, B, 16384)]).view(np.int64)).to(dev)
+                      for b in batches]
+            pouts = [dict(osd0=torch.empty((B, wpr), dtype=torch.int64, device=dev), bp=torch.empty((B, wpr), dtype=torch.int64, device=dev))
+                     for _ in range(nslots)]
+            dec.decode_batch_device_packed(d_psyn[0].data_ptr(), B, d_packed[0].data_ptr(), pouts[0]["osd0"].data_ptr(), pouts[0]["bp"].data_ptr(),
+                                           outs[0]["conv"].data_ptr(), outs[0]["iters"].data_ptr())
+            dec.synchronize()
+            native_gather = True
+        except ValueError:
+            native_gather = False
 
     def launch(k, slot):
         o = outs[slot]
-        dec.decode_batch_device(d_syn[k % nbatch].data_ptr(), B, o["osdw"].data_ptr(), o["osd0"].data_ptr(), o["bp"].data_ptr(),
-                                o["conv"].data_ptr(), o["iters"].data_ptr(), None)
+        if native_gather:
+            dec.decode_batch_device_packed(d_psyn[k % nbatch].data_ptr(), B, d_packed[k & 1].data_ptr(), pouts[slot]["osd0"].data_ptr(),
+                                           pouts[slot]["bp"].data_ptr(), o["conv"].data_ptr(), o["iters"].data_ptr())
+        else:
+            dec.decode_batch_device(d_syn[k % nbatch].data_ptr(), B, o["osdw"].data_ptr(), o["osd0"].data_ptr(), o["bp"].data_ptr(),
+                                    o["conv"].data_ptr(), o["iters"].data_ptr(), None)
         lane_of_slot[slot] = dec.last_lane
 
     def pack(slot, buf):  # queued on the lane of the decode just launched
-        dec.pack_rows_device(outs[slot]["osdw"].data_ptr(), B, n, d_packed[buf].data_ptr())
+        if not native_gather:
+            dec.pack_rows_device(outs[slot]["osdw"].data_ptr(), B, n, d_packed[buf].data_ptr())
 
     def wait(slot):
         dec.synchronize(lane_of_slot[slot])
@@ -488,7 +509,8 @@ def main():
                 "per_gpu_batch": B,
                 "global_batch": B * world,
                 "sharding": f"independent syndromes, contiguous shards x{world}" +
-                            ("" if world == 1 or args.no_gather else ", RCCL gather of bit-packed corrections to rank 0"),
+                            ("" if world == 1 or args.no_gather else ", RCCL gather of bit-packed corrections to rank 0" +
+                             (" (rows packed by the decode kernels themselves)" if native_gather else " (bposd_pack_rows_device)")),
                 "bp_variant": args.variant,
                 "pipelined_steps": nslots,
                 "timed_outputs": ["osdw", "osd0", "bp", "converged", "iters"],

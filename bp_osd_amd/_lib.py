@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "bposd_decode_batch_async",
     "bposd_decode_batch_packed_async",
     "bposd_decode_batch_device",
+    "bposd_decode_batch_device_packed",
     "bposd_decode_batch_select",
     "bposd_decode_batch_select_device",
     "bposd_pack_rows_device",
@@ -107,6 +108,8 @@ def load():
     lib.bposd_decode_batch_packed_async.restype = C.c_int
     lib.bposd_decode_batch_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     lib.bposd_decode_batch_device.restype = C.c_int
+    lib.bposd_decode_batch_device_packed.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.bposd_decode_batch_device_packed.restype = C.c_int
     lib.bposd_decode_batch_select.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.bposd_decode_batch_select.restype = C.c_int
     lib.bposd_decode_batch_select_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]

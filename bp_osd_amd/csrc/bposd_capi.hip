@@ -1198,6 +1198,19 @@ int bposd_decode_batch_device(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     return decode_device_impl(h, d_synd, B, nullptr, d_osdw, d_osd0, d_bp, d_conv, d_iters, d_llr);
 }
 
+int bposd_decode_batch_device_packed(bposd_handle* h, const uint64_t* d_synd_words, int64_t B, uint64_t* d_osdw_words,
+                                     uint64_t* d_osd0_words, uint64_t* d_bp_words, uint8_t* d_conv, int32_t* d_iters) {
+    if (!h) return BPOSD_ERR_INVALID;
+    if (!native_packed(h))
+        return fail(h, BPOSD_ERR_UNSUPPORTED, "this code's kernels take byte rows (HBM-resident path, any-degree or serial-schedule kernel): "
+                    "use bposd_decode_batch_device and bposd_pack_rows_device");
+    h->packed_now = true;
+    const int rc = decode_device_impl(h, (const uint8_t*)d_synd_words, B, nullptr, (uint8_t*)d_osdw_words, (uint8_t*)d_osd0_words,
+                                      (uint8_t*)d_bp_words, d_conv, d_iters, nullptr);
+    h->packed_now = false;
+    return rc;
+}
+
 static int alt_channel_tables(bposd_handle* h, const double* alt, double* l0, double* cost) {
     if (!alt) return fail(h, BPOSD_ERR_INVALID, "channel_probs_alt is required");
     for (int i = 0; i < h->n; ++i) {

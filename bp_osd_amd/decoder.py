@@ -466,6 +466,15 @@ class BpOsdDecoder:
                                                      d_converged, d_iters, d_llr)
         _lib.check(self._lib, self._h, rc)
 
+    def decode_batch_device_packed(self, d_syndrome_words, B, d_osdw_words, d_osd0_words=None, d_bp_words=None, d_converged=None, d_iters=None):
+        """Asynchronous decode of ``B`` bit-packed syndromes (device uint64 [B, ceil(m/64)]) into bit-packed rows (device uint64
+        [B, ceil(n/64)]) -- ``bposd_decode_batch_device_packed``; raises ValueError where the kernels take byte rows only (then
+        :meth:`decode_batch_device` + :meth:`pack_rows_device`)."""
+        self._timing_override = None
+        rc = self._lib.bposd_decode_batch_device_packed(self._h, d_syndrome_words, int(B), d_osdw_words, d_osd0_words, d_bp_words,
+                                                        d_converged, d_iters)
+        _lib.check(self._lib, self._h, rc)
+
     def pack_rows_device(self, d_bytes, B, n, d_words, lane=None):
         """Bit-pack B device rows of n 0/1 bytes into ceil(n/64) uint64 words each (asynchronous).  Queued on the lane of
         the most recent device-pointer decode -- call it right after the decode whose rows it packs -- or on ``lane``

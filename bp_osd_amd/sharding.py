@@ -163,13 +163,16 @@ class StepPipeline:
         slot = k % self.nslots
         while len(self.pending) >= self.nslots:  # slot (and its output buffers) of step k - nslots must be free
             self._finalise(*self.pending.pop(0))
-        self.launch(k, slot)
         if self.do_gather:
+            # the packed buffer of this step must be free BEFORE the decode is enqueued: where the kernels write packed rows
+            # themselves (bposd_decode_batch_device_packed) the launch, not the pack step, fills it
             buf = k & 1
             if self.gather_done[buf] is not None:
                 self.gather_done[buf].synchronize()
                 self.gather_done[buf] = None
-            self.pack(slot, buf)
+        self.launch(k, slot)
+        if self.do_gather:
+            self.pack(slot, k & 1)
         self.pending.append((k, timed))
 
     def gather_ms(self):

@@ -143,6 +143,14 @@ int bposd_decode_batch_device(bposd_handle *h, const uint8_t *d_syndromes, int64
                               uint8_t *d_osdw, uint8_t *d_osd0, uint8_t *d_bp,
                               uint8_t *d_converged, int32_t *d_iters, double *d_llr);
 
+/* The device-pointer call with bit-packed rows (the layout of bposd_decode_batch_packed; every pointer a device pointer):
+ * the kernels read packed syndromes and write packed result rows themselves -- no pack kernel between the decode and the
+ * multi-GPU gather.  Codes on the HBM-resident path (m > 1024 or n > 2047), on the any-degree BP kernel or with the serial
+ * schedule return BPOSD_ERR_UNSUPPORTED: there bposd_decode_batch_device + bposd_pack_rows_device do the same.
+ * Asynchronous like bposd_decode_batch_device. */
+int bposd_decode_batch_device_packed(bposd_handle *h, const uint64_t *d_syndrome_words, int64_t B, uint64_t *d_osdw_words,
+                                     uint64_t *d_osd0_words, uint64_t *d_bp_words, uint8_t *d_converged, int32_t *d_iters);
+
 /*
  * Per-syndrome channel, two values per bit: bit i of syndrome b is decoded with probability
  * channel_probs_alt[i] where select[b*n + i] != 0 and with the handle's channel_probs[i] elsewhere

@@ -1924,3 +1924,43 @@ def test_async_host_api_stream_of_batches(gpu_ready, h1922, hgp4050):
             assert (d.unpack_rows(o["bp"], n) == w["bp"]).all() and (o["iters"] == w["iters"]).all(), k
         # a synchronous call after asynchronous ones drains them first and still agrees
         assert (d.decode_batch(batches[1]) == want[1]["osdw"]).all()
+
+
+def test_device_pointer_packed_api_with_torch(gpu_ready, h1922, hgp400, hgp4050):
+    """bposd_decode_batch_device_packed: packed syndromes and packed result rows in device memory, written by the kernels
+    themselves (local-edge, class and generic BP kernels; workgroup, wave and multi-wave OSD kernels) -- equal to the byte API;
+    the HBM-resident path refuses it (there the byte rows are packed by bposd_pack_rows_device)."""
+    import torch
+
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import hgp, rep_code
+
+    dev = torch.device("cuda", 0)
+    cases = [(h1922.hz, 20000, 0.06, dict(max_iter=30, osd_method="osd_cs", osd_order=7), 0),
+             (hgp400.hz, 9000, 0.07, dict(max_iter=10, osd_method="osd_cs", osd_order=42), 0),
+             (hgp400.hx, 5000, 0.07, dict(max_iter=10, osd_method="osd_e", osd_order=6), 1),     # generic LDS BP kernel, workgroup OSD kernel
+             (hgp(rep_code(21), compute_logicals=False).hz, 6000, 0.06, dict(max_iter=8, osd_method="osd_cs", osd_order=9), 0)]  # osd_mw_kernel
+    for H, B, q, kw, variant in cases:
+        m, n = H.shape
+        _, syn = _syndromes(H, q, B, 321)
+        d = BpOsdDecoder(H, error_rate=q, bp_method="ms", ms_scaling_factor=0.625, **kw)
+        if variant:
+            d.set_bp_variant(variant)
+            d.set_osd_variant(1)
+        want = dict(osdw=d.decode_batch(syn, want_osd0=True, want_bp=True).copy(), osd0=d.batch_osd0.copy(), bp=d.batch_bp.copy(),
+                    conv=d.batch_converge.copy(), iters=d.batch_iter.copy())
+        assert (~want["conv"]).sum() > 10
+        wn = (n + 63) // 64
+        d_syn = torch.from_numpy(d.pack_rows(syn).view(np.int64)).to(dev)
+        o = {k: torch.empty((B, wn), dtype=torch.int64, device=dev) for k in ("osdw", "osd0", "bp")}
+        conv = torch.empty(B, dtype=torch.uint8, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        for rep in range(2):
+            d.decode_batch_device_packed(d_syn.data_ptr(), B, o["osdw"].data_ptr(), o["osd0"].data_ptr(), o["bp"].data_ptr(), conv.data_ptr(), iters.data_ptr())
+        d.synchronize()
+        for k in ("osdw", "osd0", "bp"):
+            assert (d.unpack_rows(o[k].cpu().numpy().view(np.uint64), n) == want[k]).all(), (H.shape, k)
+        assert (conv.cpu().numpy().astype(bool) == want["conv"]).all() and (iters.cpu().numpy() == want["iters"]).all()
+    big = BpOsdDecoder(hgp4050.hz, error_rate=0.05, max_iter=4, bp_method="ms", osd_method="osd0")
+    with pytest.raises(ValueError):
+        big.decode_batch_device_packed(d_syn.data_ptr(), 1, o["osdw"].data_ptr())
