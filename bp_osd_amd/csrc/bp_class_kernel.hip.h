@@ -74,6 +74,10 @@ __host__ __device__ inline size_t bp_class_lds_bytes(int DC, int mp, int ntmax) 
     return ((size_t)DC * mp + ntmax + 2) * 8 + (size_t)(mp / 32 + 2) * 4 + 8 * 4;
 }
 
+// CONTRACT: bp_class_kernel takes exactly ONE explicit argument, the BpClassParams struct BY VALUE -- it then sits at offset 0 of the
+// kernarg segment and bpc_args() may read it there.  A second kernel parameter, or the struct passed by pointer, would make these
+// reads return garbage without a diagnostic; a -DBPOSD_DEBUG build traps on the first workgroup if the two views disagree.
+static_assert(__is_trivially_copyable(BpClassParams) && alignof(BpClassParams) <= 8, "BpClassParams is copied into the kernarg segment as it is");
 typedef const __attribute__((address_space(4))) BpClassParams* bpc_args_ptr;
 __device__ __forceinline__ bpc_args_ptr bpc_args() {  // cold arguments: read from the kernarg segment at the point of use
     bpc_args_ptr a = (bpc_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -215,6 +219,9 @@ template <int DCLO, int DC, int DVLO, int DVHI, int CPT, int VPT, int MPT, int N
 __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n;
+#ifdef BPOSD_DEBUG
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (bpc_args()->m != P.m || bpc_args()->counters != P.counters)) __builtin_trap();
+#endif
     constexpr int MP = MPT;
     constexpr int NW = NTMAX / 64;
     const int tid = threadIdx.x;

@@ -125,6 +125,10 @@ __device__ __forceinline__ int bpl_table_load(const int* base, unsigned int lane
 // Kernel arguments that are read once per syndrome or less often (tables, output pointers, the queue) are fetched from the
 // kernarg segment where they are used -- s_load from the scalar cache -- instead of being held in ~50 SGPRs for the
 // lifetime of the kernel: the 64-VGPR build had run out of SGPRs and of lanes in its SGPR-spill register.
+// CONTRACT: bp_local_kernel takes exactly ONE explicit argument, the BpLocalParams struct BY VALUE -- it then sits at offset 0 of the
+// kernarg segment and bpl_args() may read it there.  A second kernel parameter, or the struct passed by pointer, would make these
+// reads return garbage without a diagnostic; a -DBPOSD_DEBUG build traps on the first workgroup if the two views disagree.
+static_assert(__is_trivially_copyable(BpLocalParams) && alignof(BpLocalParams) <= 8, "BpLocalParams is copied into the kernarg segment as it is");
 typedef const __attribute__((address_space(4))) BpLocalParams* bpl_args_ptr;
 __device__ __forceinline__ bpl_args_ptr bpl_args() {
     bpl_args_ptr a = (bpl_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -140,6 +144,9 @@ template <int CPT, int MPT, int MINW, bool EARLY, bool UPRIOR>
 __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocalParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n;
+#ifdef BPOSD_DEBUG
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (bpl_args()->m != P.m || bpl_args()->counters != P.counters)) __builtin_trap();
+#endif
     constexpr int NT = MPT / CPT;
     constexpr int MP = MPT;
     const int tid = threadIdx.x;
