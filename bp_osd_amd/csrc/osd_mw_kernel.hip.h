@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * NWV, MINW) void osd_mw_kernel(const OsdParams 
                         if (q == pslot) {  // wave-uniform
                             if (lane == psrc) {
 #pragma unroll
-                                for (int x = 0; x < W; ++x) xb[x] = row[q][x];
+                                for (int x = w; x < W; ++x) xb[x] = row[q][x];  // (words left of the panel: see below)
                             }
                         }
                     }
@@ -176,9 +176,12 @@ __global__ __launch_bounds__(64 * NWV, MINW) void osd_mw_kernel(const OsdParams 
                 par ^= 1;
                 if (win < 0) continue;  // no unused row has this column set: a non-pivot column
                 ++nrank;
+                // only the words from the panel on: an unused row is zero in every column already passed (a column is declared
+                // non-pivot when NO unused row has it set, and unused rows only ever absorb rows that were unused then), so the
+                // pivot row leaves every earlier word as it is -- those words are final
                 unsigned long long piv[W];
 #pragma unroll
-                for (int x = 0; x < W; ++x) piv[x] = pw[x];  // broadcast reads
+                for (int x = w; x < W; ++x) piv[x] = pw[x];  // broadcast reads
                 const bool mine = (win == wave);
                 if (mine) {
                     if (lane == psrc) usedm |= 1u << pslot;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(64 * NWV, MINW) void osd_mw_kernel(const OsdParams 
                     const bool hit = (row[q][w] & mask) != 0ull && !(mine && q == pslot && lane == psrc);
                     if (hit) {
 #pragma unroll
-                        for (int x = 0; x < W; ++x) row[q][x] ^= piv[x];
+                        for (int x = w; x < W; ++x) row[q][x] ^= piv[x];
                     }
                 }
             }

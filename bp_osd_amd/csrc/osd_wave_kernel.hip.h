@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
                             psrc = __ffsll((long long)bal) - 1;
                             pslot = q;
 #pragma unroll
-                            for (int x = 0; x < W; ++x) piv[x] = osdw_readlane64(row[q][x], psrc);
+                            for (int x = w; x < W; ++x) piv[x] = osdw_readlane64(row[q][x], psrc);  // (words left of the current one: see the update)
                             if (lane == psrc) usedm |= 1u << q;
                         }
                     }
@@ -163,13 +163,16 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
                 if (lane == 0) pivrow[64 * w + b] = (short)(64 * pslot + psrc);
                 ++nrank;
                 // under the execution mask of the rows that have the column set: one v_xor with the (scalar) pivot word per
-                // register, against a select + xor per register in the branch-free form (half the vector instructions)
+                // register, against a select + xor per register in the branch-free form (half the vector instructions).  Only the
+                // words from the current one on (round 4): an unused row is zero in every column already passed -- a column is
+                // declared non-pivot when NO unused row has it set, and unused rows only ever absorb rows that were unused then --
+                // so the pivot row leaves every earlier word as it is
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
                     const bool hit = (row[q][w] & mask) != 0ull && !(q == pslot && lane == psrc);
                     if (hit) {
 #pragma unroll
-                        for (int x = 0; x < W; ++x) row[q][x] ^= piv[x];
+                        for (int x = w; x < W; ++x) row[q][x] ^= piv[x];
                     }
                 }
             }
