@@ -102,7 +102,10 @@ def cpu_baseline_worker(args):
     from oracle import OracleDecoder
 
     H = sp.csr_matrix((np.ones(len(hz_indices), dtype=np.uint8), hz_indices, hz_indptr), shape=shape)
-    dec = OracleDecoder(H, **kw)
+    # product-sum: the oracle evaluates tanh / log with the kernels' routines (ps_math = 1, bp_osd_amd/csrc/portable_math.h), the
+    # mode in which the GPU is bit-exact; against the platform libm (what the reference calls) parity is the tolerance of
+    # tests/test_gpu_parity.py::test_config2_product_sum_cs60_vs_golden.  The two modes cost the CPU the same within a few per cent.
+    dec = OracleDecoder(H, ps_math=1 if kw.get("bp_method") == "ps" else 0, **kw)
     t0 = time.perf_counter()
     r = dec.decode_batch(syn, want_llr=False)
     dt = time.perf_counter() - t0
@@ -675,7 +678,8 @@ def main():
                 "cores": 1,
                 "kind": "port",
                 "sample": f"first {cpu['n']} syndromes of batch 0, decoded one at a time by oracle/bposd_oracle.c "
-                          f"(single thread, {cpu['dt']:.1f} s); the reference's ldpc/Cython path is not installable here",
+                          f"(single thread, {cpu['dt']:.1f} s); the reference's ldpc/Cython path is not installable here" +
+                          ("; product-sum: the oracle's ps_math = 1 mode (the kernels' tanh / log routines)" if bp_method == "ps" else ""),
                 "host_cores_available": len(os.sched_getaffinity(0)),
                 "host_cores_usable": usable_cores(),
                 "gpu_matches_cpu_bit_for_bit": same,

@@ -140,7 +140,9 @@ __device__ __forceinline__ bpl_args_ptr bpl_args() {
 // EARLY: the check pass requests the LDS messages of all its checks before it computes the first one (the LDS accesses
 // are volatile, i.e. issued in program order: without this the read latency is exposed once per check)
 // UPRIOR: every bit has the same prior (uniform channel, no per-shot channel): it lives in a scalar register pair
-template <int CPT, int MPT, int MINW, bool EARLY, bool UPRIOR>
+// PACKED: the packed-I/O form (BpLocalParams::packed_io) as a compile-time switch: the byte form is then instruction for
+// instruction what it was before the packed form existed (as a run-time switch it cost the headline launch 1.2 %, same-box A/B)
+template <int CPT, int MPT, int MINW, bool EARLY, bool UPRIOR, bool PACKED = false>
 __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocalParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = bpl_table_load(bpl_args()->pos_chk, (unsigned int)tid * 4u, (unsigned int)(j * NT * 4));
-            sbit[j] = (c >= 0) ? bp_synd_bit(bpl_args()->synd, bpl_args()->packed_io, s, m, c) : false;
+            sbit[j] = (c >= 0) ? (PACKED ? bp_synd_bit(bpl_args()->synd, 1, s, m, c) : ((bpl_args()->synd[(size_t)s * m + c] & 1) != 0)) : false;
             const unsigned long long bal = __ballot(sbit[j]);
             if (lane == 0) {
                 const int w0 = ((wave << 6) + j * NT) >> 5;
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(MPT / CPT, MINW) void bp_local_kernel(const BpLocal
         }
         __syncthreads();
         const int slot = to_osd ? sh[3] : 0;
-        const int packed = __builtin_amdgcn_readfirstlane(bpl_args()->packed_io);
+        constexpr bool packed = PACKED;
         if (packed)  // result rows as 64-bit words through an LDS bitmap (the messages are dead)
             bp_store_packed_rows<NB>((unsigned int*)smem, tid, NT, n, s, to_osd, (unsigned long long*)bpl_args()->out_bp,
                                      (unsigned long long*)bpl_args()->out_osd0, (unsigned long long*)bpl_args()->out_osdw,

@@ -1092,7 +1092,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     // workgroup, which fits, and the eliminations of call k starve until the pipeline runs dry (traced with three and four
     // asynchronous host calls in flight: completions came in bursts of three).  With this rule OSD(k) gets its CUs at the
     // start of BP(k + 1)'s tail and BP(k + 2) follows ~1 ms later, whatever the number of calls queued.
-    if (!lean && h->nlanes >= 3) {
+    if (!lean && !h->tail_gate && h->nlanes >= 3) {  // (the chunks of a synchronous host call are released one by one by the host: tail_gate)
         Lane& two_back = h->lanes[(lane + h->nlanes - 2) % h->nlanes];
         if (two_back.done_recorded) HIP_TRY(h, hipStreamWaitEvent(h->cur->stream, two_back.ev_done, 0));
     }

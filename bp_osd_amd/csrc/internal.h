@@ -186,6 +186,9 @@ int osd_words(int n);
 int launch_osd_large(bposd_handle* h, const bposd::OsdParams& P, long long B, int* d_rank_out);  // launch_osd_large.hip
 int osd_large_maxspan(bool cs);
 // do the kernels this handle runs read packed syndromes / write packed rows themselves (else unpack / pack kernels surround them)?
-inline bool native_packed(const bposd_handle* h) { return !h->large && !h->bp_any && h->cfg.schedule == 0 && h->bp_variant != 64; }
+inline bool native_packed(const bposd_handle* h) {
+    // (forced local-edge variants 16 .. 26 have no packed instantiation; the LDS and class kernels switch at run time)
+    return !h->large && !h->bp_any && h->cfg.schedule == 0 && h->bp_variant != 64 && !(h->bp_variant >= 16 && h->bp_variant <= 26);
+}
 
 }  // namespace bposd_host

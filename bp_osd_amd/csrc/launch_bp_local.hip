@@ -8,9 +8,24 @@ using namespace bposd;
 using namespace bposd_host;
 
 namespace bposd_host {
+template <int CPT, int MP, int MINW, bool EARLY, bool UPRIOR, bool PACKED>
+static int launch_bp_local_tp(bposd_handle* h, const BpLocalParams& L);
+
+// the packed-I/O form exists for the instances auto-selection takes (internal.h: native_packed() asks for bp_variant == 0)
 template <int CPT, int MP, int MINW, bool EARLY, bool UPRIOR = false>
 static int launch_bp_local_t(bposd_handle* h, const BpLocalParams& L) {
-    auto k = bp_local_kernel<CPT, MP, MINW, EARLY, UPRIOR>;
+    constexpr bool has_packed = !EARLY && ((CPT == 1 && MP == 1024 && MINW == 8) || (CPT == 2 && MP == 1024 && (MINW == 8 || MINW == 6)) || MP == 2048);
+    if constexpr (has_packed) {
+        if (L.packed_io) return launch_bp_local_tp<CPT, MP, MINW, EARLY, UPRIOR, true>(h, L);
+    } else {
+        if (L.packed_io) return fail(h, BPOSD_ERR_UNSUPPORTED, "this BP kernel variant has no packed-I/O form");
+    }
+    return launch_bp_local_tp<CPT, MP, MINW, EARLY, UPRIOR, false>(h, L);
+}
+
+template <int CPT, int MP, int MINW, bool EARLY, bool UPRIOR, bool PACKED>
+static int launch_bp_local_tp(bposd_handle* h, const BpLocalParams& L) {
+    auto k = bp_local_kernel<CPT, MP, MINW, EARLY, UPRIOR, PACKED>;
     const int nt = MP / CPT;
     const size_t lds = bp_local_lds_bytes(L.mp);
     { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }

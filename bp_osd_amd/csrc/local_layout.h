@@ -461,7 +461,9 @@ inline bool local_layout_host(const std::vector<int>& rp, const std::vector<int>
         }
         std::sort(rank.begin(), rank.end());
         const size_t nfinish = std::min(rank.size(), getenv("BPOSD_LAYOUT_ALL") ? rank.size() : (size_t)3);
-        const int iters = getenv("BPOSD_LAYOUT_ITERS") ? atoi(getenv("BPOSD_LAYOUT_ITERS")) : 1000000;  // (0.4 M: 218 + 408 modelled cycles in 1.1 s, 1 M: 210 + 401 in 1.3 s, 2 M: 208 + 402 in 2.6 s)
+        // (0.4 M steps: 218 + 408 modelled cycles in 1.1 s; 1 M: 210 + 401 in 1.3 s; 2 M: 208 + 402 in 2.6 s -- and no measurable difference
+        // in launch time between the three, same-box A/B of round 4: 26.1 +- 0.15 ms each)
+        const int iters = getenv("BPOSD_LAYOUT_ITERS") ? atoi(getenv("BPOSD_LAYOUT_ITERS")) : 400000;
         std::vector<Layout> fin(nfinish);
         std::vector<std::thread> th;
         for (size_t q = 0; q < nfinish; ++q) {  // the searches are independent: one host thread each
