@@ -46,9 +46,15 @@ int osd_words(int n) {
 }
 
 // one wave per elimination (osd_wave_kernel.hip.h): small codes, integer weights
+template <int RPL, int W, bool PACKED>
+static int launch_osd_wave_tp(bposd_handle* h, const OsdParams& P, long long B);
 template <int RPL, int W>
 static int launch_osd_wave_t(bposd_handle* h, const OsdParams& P, long long B) {
-    auto k = osd_wave_kernel<RPL, W>;
+    return P.packed_io ? launch_osd_wave_tp<RPL, W, true>(h, P, B) : launch_osd_wave_tp<RPL, W, false>(h, P, B);
+}
+template <int RPL, int W, bool PACKED>
+static int launch_osd_wave_tp(bposd_handle* h, const OsdParams& P, long long B) {
+    auto k = osd_wave_kernel<RPL, W, PACKED>;
     const size_t lds = OSDW_WAVES * osdw_lds_per_wave(osdw_nsort(h->n), RPL, W);
     { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
     int wg_per_cu = 1;
@@ -80,9 +86,15 @@ static int osd_wave_shape(const bposd_handle* h, const OsdParams& P, long long B
 }
 
 // a few waves per elimination, rows in registers (osd_mw_kernel.hip.h): mid-size codes, integer weights
+template <int NWV, int RPL, int W, int MINW, bool PACKED>
+static int launch_osd_mw_tp(bposd_handle* h, const OsdParams& P, long long B);
 template <int NWV, int RPL, int W, int MINW>
 static int launch_osd_mw_t(bposd_handle* h, const OsdParams& P, long long B) {
-    auto k = osd_mw_kernel<NWV, RPL, W, MINW>;
+    return P.packed_io ? launch_osd_mw_tp<NWV, RPL, W, MINW, true>(h, P, B) : launch_osd_mw_tp<NWV, RPL, W, MINW, false>(h, P, B);
+}
+template <int NWV, int RPL, int W, int MINW, bool PACKED>
+static int launch_osd_mw_tp(bposd_handle* h, const OsdParams& P, long long B) {
+    auto k = osd_mw_kernel<NWV, RPL, W, MINW, PACKED>;
     const size_t lds = osdm_lds_bytes(osdw_nsort(h->n), NWV, RPL, W);
     { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
     int wg_per_cu = 1;

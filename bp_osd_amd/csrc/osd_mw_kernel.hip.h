@@ -38,7 +38,8 @@ __host__ __device__ constexpr size_t osdm_lds_bytes(int ns, int nwv, int rpl, in
 
 // NWV: waves per elimination (= per workgroup);  RPL: rows per lane (m <= 64 NWV RPL);  W: 64-bit words per row (n + 1 <= 64 W)
 // MINW: waves per SIMD the register allocation must admit
-template <int NWV, int RPL, int W, int MINW>
+// PACKED: the packed-I/O form (OsdParams::packed_io) as a compile-time switch
+template <int NWV, int RPL, int W, int MINW, bool PACKED = false>
 __global__ __launch_bounds__(64 * NWV, MINW) void osd_mw_kernel(const OsdParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NWV;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64 * NWV, MINW) void osd_mw_kernel(const OsdParams 
 #pragma unroll
                     for (int w = 0; w < W; ++w) row[q][w] |= (w == (j >> 6)) ? bit : 0ull;
                 }
-                if (osd_synd_bit(P.synd, P.packed_io, s, m, r)) row[q][W - 1] |= 1ull << 63;
+                if (osd_synd_bit(P.synd, PACKED ? 1 : 0, s, m, r)) row[q][W - 1] |= 1ull << 63;
             }
         }
 
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(64 * NWV, MINW) void osd_mw_kernel(const OsdParams 
                 if (lane == q) yv[wave * RPL + q] = yy[q];
             const int wpn = (n + 63) >> 6;
             unsigned int* bits = (unsigned int*)keys;  // packed form: the row meets in an LDS bitmap (the sort keys are dead)
-            if (P.packed_io)
+            if (PACKED)
                 for (int w = tid; w < 2 * wpn; w += NT) bits[w] = 0u;
             __syncthreads();
             for (int j = tid; j < n; j += NT) {
@@ -251,14 +252,14 @@ __global__ __launch_bounds__(64 * NWV, MINW) void osd_mw_kernel(const OsdParams 
                         if ((int)tpos[__ffsll((long long)pp) - 1] == j) bit = 1;
                 }
                 const int i = kidx[j];
-                if (P.packed_io) {
+                if (PACKED) {
                     if (bit) atomicOr(&bits[i >> 5], 1u << (i & 31));
                 } else {
                     if (out) out[(size_t)s * n + i] = bit;
                     if (cmp) cmp[(size_t)slot_id * n + i] = bit;
                 }
             }
-            if (P.packed_io) {
+            if (PACKED) {
                 __syncthreads();
                 for (int w = tid; w < wpn; w += NT) {
                     const unsigned long long v = (unsigned long long)bits[2 * w] | ((unsigned long long)bits[2 * w + 1] << 32);

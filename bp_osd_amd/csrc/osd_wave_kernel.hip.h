@@ -50,7 +50,8 @@ __device__ __forceinline__ unsigned long long osdw_readlane64(unsigned long long
 }
 
 // RPL: rows per lane (m <= 64 * RPL);  W: 64-bit words per row (n + 1 <= 64 * W)
-template <int RPL, int W>
+// PACKED: the packed-I/O form (OsdParams::packed_io) as a compile-time switch (as a run-time switch it cost the byte form 4 %)
+template <int RPL, int W, bool PACKED = false>
 __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
 #pragma unroll
                     for (int w = 0; w < W; ++w) row[q][w] |= (w == (j >> 6)) ? bit : 0ull;
                 }
-                if (osd_synd_bit(P.synd, P.packed_io, s, m, r)) row[q][W - 1] |= 1ull << 63;
+                if (osd_synd_bit(P.synd, PACKED ? 1 : 0, s, m, r)) row[q][W - 1] |= 1ull << 63;
             }
         }
 
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
             osdw_sync();
             const int wpn = (n + 63) >> 6;
             unsigned int* bits = (unsigned int*)keys;  // packed form: the row meets in an LDS bitmap (the sort keys are dead)
-            if (P.packed_io) {
+            if (PACKED) {
                 for (int w = lane; w < 2 * wpn; w += 64) bits[w] = 0u;
                 osdw_sync();
             }
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
                 if (pr >= 0) bit = (uint8_t)((yv[pr >> 6] >> (pr & 63)) & 1ull);
                 else bit = (uint8_t)((j == fpos_a || j == fpos_b) ? 1 : 0);
                 const int i = kidx[j];
-                if (P.packed_io) {
+                if (PACKED) {
                     if (bit) atomicOr(&bits[i >> 5], 1u << (i & 31));
                 } else {
                     if (out) out[(size_t)s * n + i] = bit;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
                     pp &= pp - 1;
                     if (lane == 0) {
                         const int i = kidx[tpos[a]];
-                        if (P.packed_io) {
+                        if (PACKED) {
                             atomicOr(&bits[i >> 5], 1u << (i & 31));
                         } else {
                             if (out) out[(size_t)s * n + i] = 1;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(64 * OSDW_WAVES) void osd_wave_kernel(const OsdPara
                     }
                 }
             }
-            if (P.packed_io) {
+            if (PACKED) {
                 osdw_sync();
                 for (int w = lane; w < wpn; w += 64) {
                     const unsigned long long v = (unsigned long long)bits[2 * w] | ((unsigned long long)bits[2 * w + 1] << 32);
