@@ -655,19 +655,21 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 }
                 __syncthreads();
                 OSDL_TICK(12);
-                // Software-pipelined over the thread's rows: the words and masks of row k + 1 are requested before
-                // the look-ups of row k start (one wave keeps 2 x 4.5 KB in flight), otherwise the pass is bound by
-                // the latency of its own global loads rather than by the LDS.
-                unsigned long long vn[OSDL_CW], mkn[OSDL_K];
+                // Round 4: a row's words are touched only where they CHANGE.  The look-ups first form the change (delta) of the
+                // row's eight words from the open groups' tables -- that needs the combination masks only --, then exactly the
+                // words with a non-zero delta are loaded, XORed and stored (per lane and word).  While the matrix is sparse most
+                // (row, word) visits are no-ops -- a listed row selects one or two pivot rows, each non-zero in a few of its
+                // 462 words --; before, every listed row's eight words were read and written in every chunk, and with 252
+                // eliminations in flight next to the following step's BP kernel the STEP is bound by the memory system's
+                // 3.6-4.2 TB/s (BP 255 GB + OSD 486 GB per 178 ms), i.e. by these bytes.  The masks of row k + 1 are still
+                // requested before the look-ups of row k start.
+                unsigned long long mkn[OSDL_K];
                 // list entry of round k: position tid + k * NT; lanes beyond the list's end work on its first row and
                 // do not store
                 int rown = alist[tid < nact ? tid : 0];
                 int rown2 = alist[tid + NT < nact ? tid + NT : 0];
                 {
                     const unsigned int ro = osdl_opaque((unsigned int)rown * 8u);
-#pragma unroll
-                    for (int xx = 0; xx < OSDL_CW; ++xx)
-                        vn[xx] = (xx < cw) ? OSDL_ROW_LD(M + (size_t)(x0 + xx) * MRL, ro) : 0ull;
 #pragma unroll
                     for (int g = 0; g < OSDL_K; ++g)
                         mkn[g] = (g < ng) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro) : 0ull;
@@ -676,9 +678,9 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 for (int k = 0; k < nk; ++k) {
                     const bool live = tid + k * NT < nact;
                     const unsigned int ro = osdl_opaque((unsigned int)rown * 8u);
-                    unsigned long long v[OSDL_CW], mks[OSDL_K];
+                    unsigned long long v[OSDL_CW], mks[OSDL_K];  // v: the delta of the row's words
 #pragma unroll
-                    for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] = vn[xx];
+                    for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] = 0ull;
 #pragma unroll
                     for (int g = 0; g < OSDL_K; ++g) mks[g] = mkn[g];
                     if (k + 1 < nk) {
@@ -686,9 +688,6 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         const int p2 = tid + (k + 2) * NT;
                         rown2 = alist[p2 < nact ? p2 : 0];
                         const unsigned int rn = osdl_opaque((unsigned int)rown * 8u);
-#pragma unroll
-                        for (int xx = 0; xx < OSDL_CW; ++xx)
-                            vn[xx] = (xx < cw) ? OSDL_ROW_LD(M + (size_t)(x0 + xx) * MRL, rn) : 0ull;
 #pragma unroll
                         for (int g = 0; g < OSDL_K; ++g)
                             mkn[g] = (g < ng) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, rn) : 0ull;
@@ -708,12 +707,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         // into ds_read2_b64, which issues at half rate on gfx950 -- same finding as bp_kernel.hip.h;
                         // measured here: 855 -> 677 ms per 254 L29k eliminations)
                         osdl_lds_ptr tb = (osdl_lds_ptr)(U + (size_t)g * OSDL_G5 * TS);
-                        // Zero fields need no look-up.  A row of the 14520 x 29524 code starts with 6 ones in 462 words, so
-                        // while the matrix is sparse nearly every 5-bit field of nearly every listed row is zero, and later
-                        // a group of few pivots still leaves most of its fields empty: a whole group, or a block of 4-5
-                        // fields, that is zero in all 64 lanes is skipped by a wave-uniform test (~8 instructions per
-                        // block against ~100 for its look-ups; measured faster over the whole elimination, also in
-                        // its dense second half: 226 -> 206 ms per 254 eliminations against probing only while it pays).
+                        // Zero fields need no look-up: a whole group, or a block of 4-5 fields, that is zero in all 64 lanes is
+                        // skipped by a wave-uniform test (~8 instructions per block against ~100 for its look-ups).
                         if (__ballot(mk != 0ull) == 0ull) continue;
 #pragma unroll
                         for (int qb = 0; qb < 3; ++qb) {
@@ -738,9 +733,16 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             }
                         }
                     }
+                    // the words that change: loads in flight together, then XOR and store
+                    unsigned long long cur[OSDL_CW];
+#pragma unroll
+                    for (int xx = 0; xx < OSDL_CW; ++xx) {
+                        cur[xx] = 0ull;
+                        if (xx < cw && live && v[xx] != 0ull) cur[xx] = OSDL_ROW_LD(M + (size_t)(x0 + xx) * MRL, ro);
+                    }
 #pragma unroll
                     for (int xx = 0; xx < OSDL_CW; ++xx)
-                        if (xx < cw && live) OSDL_ROW_ST(M + (size_t)(x0 + xx) * MRL, ro, v[xx]);
+                        if (xx < cw && live && v[xx] != 0ull) OSDL_ROW_ST(M + (size_t)(x0 + xx) * MRL, ro, cur[xx] ^ v[xx]);
                 }
             }
             __syncthreads();
