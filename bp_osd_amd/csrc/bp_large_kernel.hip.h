@@ -14,6 +14,13 @@
 //   * graph tables (degrees, edge slots) are re-read from global memory every iteration (+E * 4 B);
 //   * hard decisions (bytes) and the mismatch bitmap stay in LDS; the final LLRs are written to the
 //     workspace only in the last iteration (or every iteration when the caller wants LLRs).
+//   * min-sum (METHOD 1; round 4): a check's deg check->bit messages take two magnitudes only -- the smallest |bit->check|
+//     for every edge but the one that attains it, the second smallest for that one -- so the check pass writes ONE 32-byte
+//     record per check {alpha * min1, alpha * min2, index of the minimum, sign flips} instead of deg 8-byte messages, and
+//     the bit pass rebuilds each incoming message from its check's record (flip_sign(k == kmin ? a2 : a1, flip_k): the same
+//     fp64 product the per-edge form computes -- min over a set is exact and order-free, the product is formed once).
+//     HBM per iteration: (2E + 2n) * 8 + 2 * 32 m instead of (4E + 2n) * 8 -- 3.95 instead of 5.58 MB on 14520 x 29524.
+//     Product-sum (METHOD 0) keeps per-edge messages both ways -- the form min-sum had in rounds 1-3 too.
 // Visibility: messages written by one wave and read by another of the SAME workgroup go through
 // global memory between two __syncthreads() (workgroup-scope release/acquire; the waves share the
 // CU's L1).  No inter-workgroup communication exists.
@@ -42,6 +49,7 @@ struct BpLargeParams {
     const int* __restrict__ chk_deg;     // [m]
     const int* __restrict__ var_deg;     // [n]
     const int* __restrict__ var_pos;     // [DV * n], entry d*n+i = k*mp + c
+    const int* __restrict__ var_ck;      // [DV * n], entry d*n+i = c*16 + k   (min-sum)
     double* __restrict__ msg_ws;         // [gridDim.x][DC * mp]
     double* __restrict__ llr_tmp;        // [gridDim.x][n]  LLRs of the current syndrome
     uint8_t* __restrict__ out_bp;
@@ -72,7 +80,10 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
     unsigned char* dec = smem;                                                        // [n] hard decisions
     unsigned int* diffw = reinterpret_cast<unsigned int*>(smem + ((n + 15) & ~15));  // [m/32] mismatch bitmap
     int* sh = reinterpret_cast<int*>(diffw + ((m + 31) / 32 + 2));                    // flags / ids
-    double* msg = P.msg_ws + (size_t)blockIdx.x * DC * MP;
+    constexpr bool REC = (METHOD == 1);                  // min-sum: one record per check (product-sum: per-edge messages both ways)
+    constexpr int SLOTS = REC ? DC + 4 : DC;             // message planes + 4 doubles of record per check
+    double* msg = P.msg_ws + (size_t)blockIdx.x * SLOTS * MP;
+    double* rec = msg + (size_t)DC * MP;                 // [MP][4]: a1, a2, (kmin | flips << 8), unused   (32-byte aligned: MP % 64 == 0)
     double* llrt = P.llr_tmp + (size_t)blockIdx.x * n;
 
 #ifdef BPOSD_BPLARGE_DIAG  // phase clocks of the first workgroups, printed at exit (tools/bp_large_probe.py with a -D build)
@@ -109,7 +120,14 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
             double l0 = P.llr0[i];
             if (P.sel && P.sel[(size_t)s * n + i]) l0 = P.llr0_alt[i];
             const int deg = P.var_deg[i];
-            for (int d = 0; d < deg; ++d) msg[P.var_pos[(size_t)d * n + i]] = l0;
+            if (REC) {
+                for (int d = 0; d < deg; ++d) {
+                    const int ck = P.var_ck[(size_t)d * n + i];
+                    msg[(size_t)(ck & 15) * MP + (ck >> 4)] = l0;
+                }
+            } else {
+                for (int d = 0; d < deg; ++d) msg[P.var_pos[(size_t)d * n + i]] = l0;
+            }
             dec[i] = 0;
             llrt[i] = l0;
         }
@@ -151,28 +169,30 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                         v[k] = __DBL_MAX__;
                         if (k < deg) v[k] = mc[(size_t)k * MP];
                     }
-                    if (METHOD == 1) {
-                        bool neg[DC];
+                    if (REC) {
+                        // two smallest magnitudes, where the smallest sits, the signs: one record per check
+                        unsigned int negm = 0u;
                         bool par = sbit;
+                        double m1 = __DBL_MAX__, m2 = __DBL_MAX__;
+                        int kmin = 0;
 #pragma unroll
                         for (int k = 0; k < DC; ++k) {
-                            neg[k] = (v[k] <= 0.0);
-                            par ^= neg[k];
+                            const bool ng = (v[k] <= 0.0);  // (absent edges: +DBL_MAX, never negative, never below a present value)
+                            negm |= ng ? (1u << k) : 0u;
+                            par ^= ng;
+                            const double a = min_abs(__DBL_MAX__, v[k]);  // |v[k]|
+                            const bool lt = a < m1;
+                            m2 = lt ? m1 : min_pos(m2, a);
+                            kmin = lt ? k : kmin;
+                            m1 = lt ? a : m1;
                         }
-                        double pre[DC], suf[DC];
-                        pre[0] = __DBL_MAX__;
-#pragma unroll
-                        for (int k = 1; k < DC; ++k) pre[k] = min_abs(pre[k - 1], v[k - 1]);
-                        suf[DC - 1] = __DBL_MAX__;
-#pragma unroll
-                        for (int k = DC - 2; k >= 0; --k) suf[k] = min_abs(suf[k + 1], v[k + 1]);
-#pragma unroll
-                        for (int k = 0; k < DC; ++k) {
-                            if (k < deg) {
-                                const double mag = min_pos(pre[k], suf[k]);
-                                mc[(size_t)k * MP] = flip_sign(mag * alpha, par ^ neg[k]);
-                            }
-                        }
+                        const unsigned int flips = (par ? ~negm : negm) & 0xffffu;
+                        double2 r01;
+                        r01.x = m1 * alpha;
+                        r01.y = m2 * alpha;
+                        double2* rp = reinterpret_cast<double2*>(rec + (size_t)c * 4);
+                        rp[0] = r01;
+                        reinterpret_cast<unsigned int*>(rp + 1)[0] = (unsigned int)kmin | (flips << 8);
                     } else {
                         double pre[DC], th[DC];
                         double t = 1.0;
@@ -223,15 +243,42 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                     if (P.sel && P.sel[(size_t)s * n + i]) l0 = P.llr0_alt[i];
                     int pos[DV];
                     double cm[DV], pre[DV];
+                    if (REC) {
+                        int ck[DV];
 #pragma unroll
-                    for (int d = 0; d < DV; ++d) {
-                        pos[d] = 0;
-                        cm[d] = 0.0;
-                        if (d < deg) pos[d] = P.var_pos[(size_t)d * n + i];
+                        for (int d = 0; d < DV; ++d) {
+                            ck[d] = 0;
+                            if (d < deg) ck[d] = P.var_ck[(size_t)d * n + i];
+                        }
+                        double2 r01[DV];
+                        unsigned int meta[DV];
+#pragma unroll
+                        for (int d = 0; d < DV; ++d) {
+                            r01[d].x = 0.0; r01[d].y = 0.0; meta[d] = 0u;
+                            if (d < deg) {
+                                const double2* rp = reinterpret_cast<const double2*>(rec + (size_t)(ck[d] >> 4) * 4);
+                                r01[d] = rp[0];
+                                meta[d] = reinterpret_cast<const unsigned int*>(rp + 1)[0];
+                            }
+                        }
+#pragma unroll
+                        for (int d = 0; d < DV; ++d) {
+                            const int k = ck[d] & 15;
+                            pos[d] = k * MP + (ck[d] >> 4);
+                            const double mag = ((int)(meta[d] & 15u) == k) ? r01[d].y : r01[d].x;
+                            cm[d] = (d < deg) ? flip_sign(mag, ((meta[d] >> (8 + k)) & 1u) != 0u) : 0.0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < DV; ++d) {
+                            pos[d] = 0;
+                            cm[d] = 0.0;
+                            if (d < deg) pos[d] = P.var_pos[(size_t)d * n + i];
+                        }
+#pragma unroll
+                        for (int d = 0; d < DV; ++d)
+                            if (d < deg) cm[d] = msg[pos[d]];
                     }
-#pragma unroll
-                    for (int d = 0; d < DV; ++d)
-                        if (d < deg) cm[d] = msg[pos[d]];
                     double t = l0;
 #pragma unroll
                     for (int d = 0; d < DV; ++d) {

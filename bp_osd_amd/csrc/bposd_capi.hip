@@ -27,6 +27,9 @@
 #include <vector>
 
 #include "internal.h"
+#include <array>
+#include <vector>
+#include <algorithm>
 #include "local_layout.h"
 #include "class_layout.h"
 
@@ -495,13 +498,14 @@ int build_tables_class(bposd_handle* h) {
 int build_tables_large(bposd_handle* h, int DV, int MP) {
     const int m = h->m, n = h->n;
     std::vector<int> chk_deg(m), var_deg(n, 0);
-    std::vector<int> var_pos((size_t)DV * n, 0);
+    std::vector<int> var_pos((size_t)DV * n, 0), var_ck((size_t)DV * n, 0);
     for (int c = 0; c < m; ++c) {
         chk_deg[c] = h->rp[c + 1] - h->rp[c];
         for (int e = h->rp[c]; e < h->rp[c + 1]; ++e) {
             const int i = h->ci[e];
             const int d = var_deg[i]++;
             var_pos[(size_t)d * n + i] = (e - h->rp[c]) * MP + c;
+            var_ck[(size_t)d * n + i] = c * 16 + (e - h->rp[c]);  // (slot < 16: the large-code kernels are built for check degree <= 16)
         }
     }
     auto up = [&](int** dst, const std::vector<int>& v) -> int {
@@ -514,6 +518,7 @@ int build_tables_large(bposd_handle* h, int DV, int MP) {
     if ((rc = up(&h->d_chk_deg, chk_deg))) return rc;
     if ((rc = up(&h->d_var_deg, var_deg))) return rc;
     if ((rc = up(&h->d_var_pos, var_pos))) return rc;
+    if ((rc = up(&h->d_var_ck, var_ck))) return rc;
     h->tab_mp = MP;
     return 0;
 }
@@ -694,7 +699,7 @@ void bposd_destroy(bposd_handle* h) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (void* p : {(void*)h->d_rp, (void*)h->d_ci, (void*)h->d_chk_deg, (void*)h->d_var_deg,
-                    (void*)h->d_var_pos, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt,
+                    (void*)h->d_var_pos, (void*)h->d_var_ck, (void*)h->d_pos_bit, (void*)h->d_llr0, (void*)h->d_cost, (void*)h->d_llr0_alt, (void*)h->d_cost_alt,
                     (void*)h->d_lpos_chk, (void*)h->d_lpos_bit,
                     (void*)h->d_lpos_alo, (void*)h->d_lpos_ahi, (void*)h->d_lgrp_dl, (void*)h->d_lpos_dl,
                     (void*)h->d_cpos_chk, (void*)h->d_cpos_bit, (void*)h->d_cbit_slot, (void*)h->d_cgrp_deg, (void*)h->d_cgrp_cdeg,
@@ -1146,19 +1151,39 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
         Q.cost_alt = h->lane_alt ? h->cur->d_alt + h->n : h->d_cost_alt;
         const char* dbg_env = getenv("BPOSD_OSD_DEBUG");
         if (dbg_env && dbg_env[0] == '1') {
-            if (!h->cur->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->cur->d_osd_dbg, 2048 * sizeof(long long)));
-            HIP_TRY(h, hipMemsetAsync(h->cur->d_osd_dbg, 0, 2048 * sizeof(long long), h->osd_now));
+            if (!h->cur->d_osd_dbg) HIP_TRY(h, hipMalloc((void**)&h->cur->d_osd_dbg, 8192 * sizeof(long long)));
+            HIP_TRY(h, hipMemsetAsync(h->cur->d_osd_dbg, 0, 8192 * sizeof(long long), h->osd_now));
             Q.dbg = h->cur->d_osd_dbg;
         }
         if (h->large) {
             h->last_osd_kernel = 3;
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
             if (Q.dbg) {
-                long long st[17];
+                long long st[24];
                 HIP_TRY(h, hipStreamSynchronize(h->osd_now));
                 HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[bposd large osd, s_memtime ticks, list slot 0] sort %lld  build %lld  E1 %lld  E2 %lld  E3 %lld  apply %lld  "
-                        "sweep %lld (back-substitution %lld, column vectors %lld, candidates %lld, write-out %lld) | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld apply table builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[13], st[14], st[15], st[16], st[7], st[8], st[9], st[10], st[11], st[12]);
+                        "sweep %lld (back-substitution %lld, column vectors %lld, candidates %lld, write-out %lld) | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld | apply pass: row walks %lld, wait for the slowest walker %lld, own table build %lld, wait for the builders %lld, list builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5] + st[17] + st[18] + st[19] + st[20], st[6], st[13], st[14], st[15], st[16], st[7], st[8], st[9], st[10], st[11], st[5], st[19], st[17], st[18], st[20]);
+                {   // every elimination of the launch (osd_large_kernel writes 16 numbers per list slot behind the first 32)
+                    static long long all[8192];
+                    HIP_TRY(h, hipMemcpy(all, h->cur->d_osd_dbg, sizeof(all), hipMemcpyDeviceToHost));
+                    std::vector<std::array<long long, 16>> v;
+                    for (int i = 0; i < 500; ++i)
+                        if (all[32 + i * 16] > 0) {
+                            std::array<long long, 16> a;
+                            for (int k = 0; k < 16; ++k) a[k] = all[32 + i * 16 + k];
+                            v.push_back(a);
+                        }
+                    if (v.size() > 1) {
+                        std::sort(v.begin(), v.end());
+                        fprintf(stderr, "[bposd large osd, all %zu eliminations of the launch, sorted by ticks] M ticks: total | sort build E2 E3 row-walks sweep | words groups applies | own-table-build wait-builders wait-walkers of-the-build:loads\n", v.size());
+                        for (size_t i = 0; i < v.size(); i += (i + 8 < v.size() ? v.size() / 8 : 1)) {
+                            const auto& a = v[i];
+                            fprintf(stderr, "  [%3zu] %.0f | %.1f %.1f %.1f %.1f %.1f %.1f | %lld %lld %lld | %.1f %.1f %.1f %.1f\n", i, a[0] * 1e-6, a[1] * 1e-6, a[2] * 1e-6, a[4] * 1e-6, a[5] * 1e-6,
+                                    a[6] * 1e-6, a[7] * 1e-6, a[8], a[9], a[10], a[12] * 1e-6, a[13] * 1e-6, a[14] * 1e-6, a[15] * 1e-6);
+                        }
+                    }
+                }
                 Q.dbg = nullptr;
             }
         } else if ((rc = launch_osd(h, Q, B))) return rc;

@@ -120,7 +120,7 @@ struct bposd_handle {
     std::vector<double> probs;
     // device tables
     int *d_rp = nullptr, *d_ci = nullptr;
-    int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr, *d_pos_bit = nullptr;
+    int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr, *d_pos_bit = nullptr, *d_var_ck = nullptr;
     int tab_np = 0;
     long layout_cost = 0, layout_cost_natural = 0, layout_cost_ideal = 0;  // simulated LDS cycles of the bit pass
     double* d_llr0 = nullptr;

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         const double* llr = P.llr_ws + (size_t)slot_id * n;
 
 #ifdef BPOSD_OSD_DIAG
-        long long tk[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 13..16: back-substitution, column vectors, candidate sweep, write-out  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
+        long long tk[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 17..20 (apply pass): own table build, wait for the builders, wait for the row walkers, list build  // 13..16: back-substitution, column vectors, candidate sweep, write-out  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
                                                                // apply look-ups per thread, apply row-words per thread
         long long t0 = (long long)__builtin_amdgcn_s_memtime();
 #define OSDL_TICK(i)                                                     \
@@ -610,11 +610,13 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             const int nact = cnt[RPT * OSDL_NW];
             const int nk = (nact + NT - 1) / NT;  // list entries per thread (the last round may be partial)
             __syncthreads();
+            OSDL_TICK(20);
             for (int x0 = xlo; x0 < W && nact > 0; x0 += OSDL_CW) {
                 OSDL_FRESH_TID();
                 const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
-                __syncthreads();  // the previous tables are no longer read
                 OSDL_TICK(5);
+                __syncthreads();  // the previous tables are no longer read
+                OSDL_TICK(19);
 #ifdef BPOSD_OSD_DIAG
                 for (int g = 0; g < ng; ++g) OSDL_ADD(10, (long long)nk * cw * ((gnp[g] + 4) / 5 > 8 ? 13 : ((gnp[g] + 4) / 5 > 4 ? 8 : 4)));
                 OSDL_ADD(11, (long long)nk * cw);
@@ -631,13 +633,24 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     const int np = gnp[g] - 5 * grp;
                     unsigned long long pr[5];
                     // unconditional (clamped) loads so that the five requests are in flight together
+                    // unconditional (clamped) loads so that the five requests are in flight together
                     const unsigned long long* src = PRO + ((size_t)g * W + (xx < cw ? x0 + xx : W - 1)) * 64;
+                    unsigned long long val[5];
 #pragma unroll
                     for (int kk = 0; kk < 5; ++kk) {
                         const int q = 5 * grp + kk;
-                        const unsigned long long val = src[q < 63 ? q : 63];
-                        pr[kk] = (xx < cw && kk < np) ? val : 0ull;
+                        val[kk] = src[q < 63 ? q : 63];
                     }
+                    // (all five values are "used" here: without this the compiler moves each load under the branch of its select and
+                    // waits for it there -- five round trips in a row.  With 254 eliminations in flight one round trip costs ~6.6 k
+                    // cycles, 17 M of an elimination's ~220 M; bringing the words into LDS a chunk ahead by LDS-direct loads
+                    // removed that wait and made the row walks slower by as much or more -- measured twice, not kept.)
+                    asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]));
+#ifdef BPOSD_OSD_DIAG
+                    if (tt == tid) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); OSDL_TICK(21); }
+#endif
+#pragma unroll
+                    for (int kk = 0; kk < 5; ++kk) pr[kk] = (xx < cw && kk < np) ? val[kk] : 0ull;
                     unsigned int idx = osdl_opaque((unsigned int)lane & 31u);  // (laundered: else all 32 indices are hoisted + spilled)
                     unsigned long long v = 0ull;
 #pragma unroll
@@ -653,8 +666,9 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         tabp[idx] = v;
                     }
                 }
+                OSDL_TICK(17);
                 __syncthreads();
-                OSDL_TICK(12);
+                OSDL_TICK(18);
                 // Round 4: a row's words are touched only where they CHANGE.  The look-ups first form the change (delta) of the
                 // row's eight words from the open groups' tables -- that needs the combination masks only --, then exactly the
                 // words with a non-zero delta are loaded, XORed and stored (per lane and word).  While the matrix is sparse most
@@ -1490,7 +1504,16 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #ifdef BPOSD_OSD_DIAG
         tk[6] = tk[13] + tk[14] + tk[15] + tk[16];
         if (P.dbg && slot_id == 0 && tid == 0)
-            for (int i = 0; i < 17; ++i) P.dbg[i] = tk[i];
+            for (int i = 0; i < 24; ++i) P.dbg[i] = tk[i];
+        if (P.dbg && slot_id < 500 && tid == 0) {  // every elimination of the launch: total ticks, then the stamps 0..12 + 17..20
+            long long tot = 0;
+            for (int i = 0; i < 7; ++i) tot += tk[i];
+            tot += tk[17] + tk[18] + tk[19] + tk[20] + tk[21];
+            long long* d = P.dbg + 32 + slot_id * 16;
+            d[0] = tot;
+            for (int i = 0; i < 11; ++i) d[1 + i] = tk[i];
+            d[12] = tk[17] + tk[21]; d[13] = tk[18]; d[14] = tk[19]; d[15] = tk[21];
+        }
 #endif
 #undef OSDL_TICK
 #undef OSDL_COUNT
