@@ -574,15 +574,23 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             unsigned int touched = 0u;  // bit k: my k-th row takes part in this pass
             {
                 const unsigned int ro = osdl_opaque((unsigned int)threadIdx.x * 8u);
+                // four rows' masks in flight together, frozen rows included (their masks are read and ignored): under a per-row
+                // `if (!frozen)` the compiler waits for each row's loads inside the branch, two round trips per row
+                constexpr int LB = RPT < 4 ? RPT : 4;
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    unsigned long long any = 0ull;
-                    if (((frozenmask >> k) & 1u) == 0u) {
+                for (int k0 = 0; k0 < RPT; k0 += LB) {
+                    unsigned long long any[LB];
+#pragma unroll
+                    for (int i = 0; i < LB; ++i) {
+                        any[i] = 0ull;
 #pragma unroll
                         for (int g = 0; g < OSDL_K; ++g)
-                            if (g < ng) any |= OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + k * NT * 8);
+                            if (g < ng) any[i] |= OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8);
                     }
-                    if (any) touched |= 1u << k;
+                    if (LB == 4) asm volatile("" : "+v"(any[0]), "+v"(any[1]), "+v"(any[LB > 2 ? 2 : 0]), "+v"(any[LB > 3 ? 3 : 0]));
+#pragma unroll
+                    for (int i = 0; i < LB; ++i)
+                        if (any[i] != 0ull && ((frozenmask >> (k0 + i)) & 1u) == 0u) touched |= 1u << (k0 + i);
                 }
             }
 #pragma unroll
@@ -779,10 +787,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     unsigned long long v = 0ull;
                     const int np = gnp[g] - 4 * grp;
                     if (np > 0) {
-                        const unsigned long long* pr = PRO + ((size_t)g * W + w) * 64 + 4 * grp;
+                        const unsigned long long* pr = PRO + ((size_t)g * W + w) * 64 + 4 * grp;  // (grp <= 15: all four words exist)
+                        unsigned long long val[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) val[kk] = pr[kk];
+                        asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));  // four loads in flight, not four round trips
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk)
-                            if (((idx >> kk) & 1) && kk < np) v ^= pr[kk];
+                            if (((idx >> kk) & 1) && kk < np) v ^= val[kk];
                     }
                     U[e] = v;
                 }

@@ -21,7 +21,7 @@ python bench.py --steps 10 --warmup 2 --config hgp400_ms_cs42 > $OUT/bench_hgp40
 python bench.py --steps 5 --warmup 2 --config hgp625_ms_cs42 --host-steps 0 > $OUT/bench_hgp625_ms_cs42.json 2>> $OUT/bench.err && echo "hgp625 done" &&
 python bench.py --steps 5 --warmup 2 --config hgp900_ms_cs42 --host-steps 0 > $OUT/bench_hgp900_ms_cs42.json 2>> $OUT/bench.err && echo "hgp900 done"
 elif [ "$PART" = "B" ]; then
-python bench.py --steps 4 --warmup 1 --config l29k_ms_e15 --host-steps 0 > $OUT/bench_l29k_ms_e15.json 2> $OUT/bench_l29k.err && echo "l29k done"
+python bench.py --steps 12 --warmup 2 --config l29k_ms_e15 --host-steps 0 > $OUT/bench_l29k_ms_e15.json 2> $OUT/bench_l29k.err && echo "l29k done"
 else
 python tools/bp_iteration_cost.py 1 0 > $OUT/bp_iteration_cost.txt 2>&1 &&
 BP_METHOD=ps python tools/bp_iteration_cost.py 1 0 > $OUT/bp_iteration_cost_ps.txt 2>&1 &&
