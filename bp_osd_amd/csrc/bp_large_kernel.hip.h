@@ -20,6 +20,9 @@
 //     the bit pass rebuilds each incoming message from its check's record (flip_sign(k == kmin ? a2 : a1, flip_k): the same
 //     fp64 product the per-edge form computes -- min over a set is exact and order-free, the product is formed once).
 //     HBM per iteration: (2E + 2n) * 8 + 2 * 32 m instead of (4E + 2n) * 8 -- 3.95 instead of 5.58 MB on 14520 x 29524.
+//     METHOD 2 (where 8 bytes per check still fit the CU's LDS next to the decisions: 14520 x 29524 needs 148 KB) keeps a1 of
+//     every check in LDS and writes only a2 and the 32-bit flags to the workspace; the bit pass reads a1 from LDS, gathers the
+//     4-byte flags and fetches a2 for the one edge in deg that holds the minimum.
 //     Product-sum (METHOD 0) keeps per-edge messages both ways -- the form min-sum had in rounds 1-3 too.
 // Visibility: messages written by one wave and read by another of the SAME workgroup go through
 // global memory between two __syncthreads() (workgroup-scope release/acquire; the waves share the
@@ -65,8 +68,9 @@ struct BpLargeParams {
     int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
 };
 
-__host__ __device__ inline size_t bp_large_lds_bytes(int m, int n) {
-    return (size_t)((n + 15) & ~15) + (size_t)((m + 31) / 32 + 2) * 4 + 8 * 4;
+// a1_in_lds: the min-sum form that keeps every check's first scaled minimum in LDS (METHOD 2) adds 8 bytes per check
+__host__ __device__ inline size_t bp_large_lds_bytes(int m, int n, bool a1_in_lds = false) {
+    return (size_t)((n + 15) & ~15) + (size_t)((m + 31) / 32 + 2) * 4 + 8 * 4 + (a1_in_lds ? (size_t)((m + 1) & ~1) * 8 : 0);
 }
 
 template <int DC, int DV, int METHOD>
@@ -77,13 +81,17 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
-    unsigned char* dec = smem;                                                        // [n] hard decisions
-    unsigned int* diffw = reinterpret_cast<unsigned int*>(smem + ((n + 15) & ~15));  // [m/32] mismatch bitmap
+    constexpr bool REC = (METHOD == 1);                  // min-sum: one 32-byte record per check in the workspace
+    constexpr bool RLDS = (METHOD == 2);                 // min-sum: a1 of every check in LDS, a2 and the flags in the workspace
+    constexpr int SLOTS = REC ? DC + 4 : (RLDS ? DC + 2 : DC);  // message planes + the per-check data
+    double* a1lds = reinterpret_cast<double*>(smem);     // [m] (RLDS)
+    unsigned char* dec = smem + (RLDS ? (size_t)((m + 1) & ~1) * 8 : 0);              // [n] hard decisions
+    unsigned int* diffw = reinterpret_cast<unsigned int*>(dec + ((n + 15) & ~15));    // [m/32] mismatch bitmap
     int* sh = reinterpret_cast<int*>(diffw + ((m + 31) / 32 + 2));                    // flags / ids
-    constexpr bool REC = (METHOD == 1);                  // min-sum: one record per check (product-sum: per-edge messages both ways)
-    constexpr int SLOTS = REC ? DC + 4 : DC;             // message planes + 4 doubles of record per check
     double* msg = P.msg_ws + (size_t)blockIdx.x * SLOTS * MP;
-    double* rec = msg + (size_t)DC * MP;                 // [MP][4]: a1, a2, (kmin | flips << 8), unused   (32-byte aligned: MP % 64 == 0)
+    double* rec = msg + (size_t)DC * MP;                 // REC: [MP][4]: a1, a2, (kmin | flips << 8), unused   (32-byte aligned: MP % 64 == 0)
+    double* a2g = rec;                                   // RLDS: [MP] a2, then [MP] 32-bit (kmin | flips << 8)
+    unsigned int* metag = reinterpret_cast<unsigned int*>(rec + MP);
     double* llrt = P.llr_tmp + (size_t)blockIdx.x * n;
 
 #ifdef BPOSD_BPLARGE_DIAG  // phase clocks of the first workgroups, printed at exit (tools/bp_large_probe.py with a -D build)
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
             double l0 = P.llr0[i];
             if (P.sel && P.sel[(size_t)s * n + i]) l0 = P.llr0_alt[i];
             const int deg = P.var_deg[i];
-            if (REC) {
+            if (REC || RLDS) {
                 for (int d = 0; d < deg; ++d) {
                     const int ck = P.var_ck[(size_t)d * n + i];
                     msg[(size_t)(ck & 15) * MP + (ck >> 4)] = l0;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                         v[k] = __DBL_MAX__;
                         if (k < deg) v[k] = mc[(size_t)k * MP];
                     }
-                    if (REC) {
+                    if (REC || RLDS) {
                         // two smallest magnitudes, where the smallest sits, the signs: one record per check
                         unsigned int negm = 0u;
                         bool par = sbit;
@@ -187,12 +195,18 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                             m1 = lt ? a : m1;
                         }
                         const unsigned int flips = (par ? ~negm : negm) & 0xffffu;
-                        double2 r01;
-                        r01.x = m1 * alpha;
-                        r01.y = m2 * alpha;
-                        double2* rp = reinterpret_cast<double2*>(rec + (size_t)c * 4);
-                        rp[0] = r01;
-                        reinterpret_cast<unsigned int*>(rp + 1)[0] = (unsigned int)kmin | (flips << 8);
+                        if (RLDS) {
+                            a1lds[c] = m1 * alpha;
+                            a2g[c] = m2 * alpha;
+                            metag[c] = (unsigned int)kmin | (flips << 8);
+                        } else {
+                            double2 r01;
+                            r01.x = m1 * alpha;
+                            r01.y = m2 * alpha;
+                            double2* rp = reinterpret_cast<double2*>(rec + (size_t)c * 4);
+                            rp[0] = r01;
+                            reinterpret_cast<unsigned int*>(rp + 1)[0] = (unsigned int)kmin | (flips << 8);
+                        }
                     } else {
                         double pre[DC], th[DC];
                         double t = 1.0;
@@ -243,7 +257,31 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                     if (P.sel && P.sel[(size_t)s * n + i]) l0 = P.llr0_alt[i];
                     int pos[DV];
                     double cm[DV], pre[DV];
-                    if (REC) {
+                    if (RLDS) {
+                        int ck[DV];
+#pragma unroll
+                        for (int d = 0; d < DV; ++d) {
+                            ck[d] = 0;
+                            if (d < deg) ck[d] = P.var_ck[(size_t)d * n + i];
+                        }
+                        unsigned int meta[DV];
+#pragma unroll
+                        for (int d = 0; d < DV; ++d) {
+                            meta[d] = 0u;
+                            if (d < deg) meta[d] = metag[ck[d] >> 4];
+                        }
+#pragma unroll
+                        for (int d = 0; d < DV; ++d) {
+                            const int k = ck[d] & 15, c = ck[d] >> 4;
+                            pos[d] = k * MP + c;
+                            double mag = 0.0;
+                            if (d < deg) {
+                                mag = a1lds[c];
+                                if ((int)(meta[d] & 15u) == k) mag = a2g[c];  // the edge that holds the check's minimum: 1 in deg
+                            }
+                            cm[d] = (d < deg) ? flip_sign(mag, ((meta[d] >> (8 + k)) & 1u) != 0u) : 0.0;
+                        }
+                    } else if (REC) {
                         int ck[DV];
 #pragma unroll
                         for (int d = 0; d < DV; ++d) {

@@ -938,8 +938,8 @@ int bposd_update_channel_probs(bposd_handle* h, const double* channel_probs) {
 
 int bposd_set_bp_variant(bposd_handle* h, int32_t variant) {
     if (!h) return BPOSD_ERR_INVALID;
-    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32 && variant != 64)
-        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel), 32 (class kernel) or 64 (any-degree kernel)");
+    if (variant != 0 && variant != 1 && variant != 2 && variant != 4 && !(variant >= 16 && variant <= 26) && variant != 32 && variant != 63 && variant != 64)
+        return fail(h, BPOSD_ERR_INVALID, "bp variant must be 0 (auto), 1, 2, 4 (LDS kernel shapes), 16 .. 26 (local-edge kernel), 32 (class kernel), 63 (HBM-resident min-sum with whole check records in the workspace) or 64 (any-degree kernel)");
     if (variant == 64 && !h->d_cp) {  // the any-degree kernel as a second implementation for cross-checks: its CSC edge map
         DeviceGuard dev_guard(h->device);
         HIP_TRY(h, dev_guard.err);

@@ -576,6 +576,11 @@ def test_large_code_bp_vs_oracle(gpu_ready, hgp4050):
         r = _gpu_decode(g, syn)
         ref = OracleDecoder(H, **kw).decode_batch(syn)
         _compare_exact(r, ref)
+        # the other form of the min-sum check records (whole 32-byte records in the workspace instead of a1 in LDS: what a code
+        # beyond the CU's LDS gets) -- same answers, LLR bits included
+        g.set_bp_variant(63)
+        _compare_exact(_gpu_decode(g, syn), ref)
+        g.set_bp_variant(0)
     # zero syndromes and the per-syndrome channel also go through the large kernel
     out = g.decode_batch(np.zeros((3, 2025), dtype=np.uint8))
     assert not out.any() and g.batch_converge.all()
