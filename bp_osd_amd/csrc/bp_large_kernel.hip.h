@@ -20,9 +20,10 @@
 //     the bit pass rebuilds each incoming message from its check's record (flip_sign(k == kmin ? a2 : a1, flip_k): the same
 //     fp64 product the per-edge form computes -- min over a set is exact and order-free, the product is formed once).
 //     HBM per iteration: (2E + 2n) * 8 + 2 * 32 m instead of (4E + 2n) * 8 -- 3.95 instead of 5.58 MB on 14520 x 29524.
-//     METHOD 2 (where 8 bytes per check still fit the CU's LDS next to the decisions: 14520 x 29524 needs 148 KB) keeps a1 of
-//     every check in LDS and writes only a2 and the 32-bit flags to the workspace; the bit pass reads a1 from LDS, gathers the
-//     4-byte flags and fetches a2 for the one edge in deg that holds the minimum.
+//     METHOD 2 (where it fits the CU's LDS: 14520 x 29524 needs 151 KB) keeps a1 (8 bytes) and the flags (2 bytes up to check
+//     degree 12) of every check in LDS, the hard decisions as bits (a wave's 64 decisions are one ballot), and writes only a2
+//     to the workspace; the bit pass reads a1 and the flags from LDS and fetches a2 for the one edge in deg that holds the
+//     minimum -- its only gather.
 //     Product-sum (METHOD 0) keeps per-edge messages both ways -- the form min-sum had in rounds 1-3 too.
 // Visibility: messages written by one wave and read by another of the SAME workgroup go through
 // global memory between two __syncthreads() (workgroup-scope release/acquire; the waves share the
@@ -30,6 +31,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "portable_math.h"  // bit-reproducible tanh / log of the product-sum update
 
@@ -68,9 +71,13 @@ struct BpLargeParams {
     int* __restrict__ tail_flag;  // nullable, host-visible: set to 1 by the workgroup that finds the queue empty (the tail begins)
 };
 
-// a1_in_lds: the min-sum form that keeps every check's first scaled minimum in LDS (METHOD 2) adds 8 bytes per check
-__host__ __device__ inline size_t bp_large_lds_bytes(int m, int n, bool a1_in_lds = false) {
-    return (size_t)((n + 15) & ~15) + (size_t)((m + 31) / 32 + 2) * 4 + 8 * 4 + (a1_in_lds ? (size_t)((m + 1) & ~1) * 8 : 0);
+// per_check_in_lds (METHOD 2): a1 of every check (8 bytes) and its flags (2 bytes up to check degree 12, else 4) in LDS, the hard
+// decisions as one BIT per bit instead of one byte
+__host__ __device__ inline size_t bp_large_lds_bytes(int m, int n, bool per_check_in_lds = false, int dc = 12) {
+    const size_t tail = (size_t)((m + 31) / 32 + 2) * 4 + 8 * 4;
+    if (!per_check_in_lds) return (size_t)((n + 15) & ~15) + tail;
+    const size_t meta = ((size_t)m * (dc <= 12 ? 2 : 4) + 7) & ~(size_t)7;
+    return (size_t)((m + 1) & ~1) * 8 + meta + (size_t)((n + 63) / 64) * 8 + tail;
 }
 
 template <int DC, int DV, int METHOD>
@@ -83,15 +90,18 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
 
     constexpr bool REC = (METHOD == 1);                  // min-sum: one 32-byte record per check in the workspace
     constexpr bool RLDS = (METHOD == 2);                 // min-sum: a1 of every check in LDS, a2 and the flags in the workspace
-    constexpr int SLOTS = REC ? DC + 4 : (RLDS ? DC + 2 : DC);  // message planes + the per-check data
+    constexpr int SLOTS = REC ? DC + 4 : (RLDS ? DC + 1 : DC);  // message planes + the per-check data
+    using meta_t = typename std::conditional<(DC <= 12), unsigned short, unsigned int>::type;  // kmin | flips << 4
     double* a1lds = reinterpret_cast<double*>(smem);     // [m] (RLDS)
-    unsigned char* dec = smem + (RLDS ? (size_t)((m + 1) & ~1) * 8 : 0);              // [n] hard decisions
-    unsigned int* diffw = reinterpret_cast<unsigned int*>(dec + ((n + 15) & ~15));    // [m/32] mismatch bitmap
+    meta_t* metal = reinterpret_cast<meta_t*>(smem + (size_t)((m + 1) & ~1) * 8);       // [m] (RLDS)
+    unsigned long long* decw = reinterpret_cast<unsigned long long*>(smem + (size_t)((m + 1) & ~1) * 8 + (((size_t)m * sizeof(meta_t) + 7) & ~(size_t)7));  // [n / 64] (RLDS)
+    unsigned char* dec = smem;                                                        // [n] hard decisions (not RLDS)
+    unsigned int* diffw = RLDS ? reinterpret_cast<unsigned int*>(decw + (n + 63) / 64)
+                               : reinterpret_cast<unsigned int*>(dec + ((n + 15) & ~15));  // [m/32] mismatch bitmap
     int* sh = reinterpret_cast<int*>(diffw + ((m + 31) / 32 + 2));                    // flags / ids
     double* msg = P.msg_ws + (size_t)blockIdx.x * SLOTS * MP;
     double* rec = msg + (size_t)DC * MP;                 // REC: [MP][4]: a1, a2, (kmin | flips << 8), unused   (32-byte aligned: MP % 64 == 0)
-    double* a2g = rec;                                   // RLDS: [MP] a2, then [MP] 32-bit (kmin | flips << 8)
-    unsigned int* metag = reinterpret_cast<unsigned int*>(rec + MP);
+    double* a2g = rec;                                   // RLDS: [MP] a2
     double* llrt = P.llr_tmp + (size_t)blockIdx.x * n;
 
 #ifdef BPOSD_BPLARGE_DIAG  // phase clocks of the first workgroups, printed at exit (tools/bp_large_probe.py with a -D build)
@@ -136,9 +146,11 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
             } else {
                 for (int d = 0; d < deg; ++d) msg[P.var_pos[(size_t)d * n + i]] = l0;
             }
-            dec[i] = 0;
+            if (!RLDS) dec[i] = 0;
             llrt[i] = l0;
         }
+        if (RLDS)
+            for (int w = tid; w < (n + 63) / 64; w += NT) decw[w] = 0ull;
         __syncthreads();
 
         int it_done = 0;
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                         if (RLDS) {
                             a1lds[c] = m1 * alpha;
                             a2g[c] = m2 * alpha;
-                            metag[c] = (unsigned int)kmin | (flips << 8);
+                            metal[c] = (meta_t)((unsigned int)kmin | (flips << 4));
                         } else {
                             double2 r01;
                             r01.x = m1 * alpha;
@@ -264,22 +276,18 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                             ck[d] = 0;
                             if (d < deg) ck[d] = P.var_ck[(size_t)d * n + i];
                         }
-                        unsigned int meta[DV];
-#pragma unroll
-                        for (int d = 0; d < DV; ++d) {
-                            meta[d] = 0u;
-                            if (d < deg) meta[d] = metag[ck[d] >> 4];
-                        }
 #pragma unroll
                         for (int d = 0; d < DV; ++d) {
                             const int k = ck[d] & 15, c = ck[d] >> 4;
                             pos[d] = k * MP + c;
                             double mag = 0.0;
+                            unsigned int meta = 0u;
                             if (d < deg) {
+                                meta = (unsigned int)metal[c];
                                 mag = a1lds[c];
-                                if ((int)(meta[d] & 15u) == k) mag = a2g[c];  // the edge that holds the check's minimum: 1 in deg
+                                if ((int)(meta & 15u) == k) mag = a2g[c];  // the edge that holds the check's minimum: 1 in deg
                             }
-                            cm[d] = (d < deg) ? flip_sign(mag, ((meta[d] >> (8 + k)) & 1u) != 0u) : 0.0;
+                            cm[d] = (d < deg) ? flip_sign(mag, ((meta >> (4 + k)) & 1u) != 0u) : 0.0;
                         }
                     } else if (REC) {
                         int ck[DV];
@@ -332,8 +340,18 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
                             msg[pos[d]] = pre[d] + suf;
                             suf += cm[d];
                         }
-                    if (dnew != (int)dec[i]) {
-                        dec[i] = (unsigned char)dnew;
+                    int dold;
+                    if (RLDS) {
+                        // one bit per decision: the wave's 64 bits are one word (i - lane is a multiple of 64), read by every lane
+                        // before lane 0 replaces it with the ballot of the new decisions
+                        dold = (int)((decw[i >> 6] >> (i & 63)) & 1ull);
+                        const unsigned long long bal = __ballot(dnew != 0);
+                        if (lane == 0) decw[i >> 6] = bal;
+                    } else {
+                        dold = (int)dec[i];
+                        if (dnew != dold) dec[i] = (unsigned char)dnew;
+                    }
+                    if (dnew != dold) {
 #pragma unroll
                         for (int d = 0; d < DV; ++d)
                             if (d < deg) {
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
         const int slot = to_osd ? sh[3] : 0;
         for (int i = tid; i < n; i += NT) {
             const size_t o = (size_t)s * n + i;
-            const uint8_t b = dec[i];
+            const uint8_t b = RLDS ? (uint8_t)((decw[i >> 6] >> (i & 63)) & 1ull) : dec[i];
             if (P.out_bp) P.out_bp[o] = b;
             if (!to_osd) {
                 P.out_osdw[o] = b;

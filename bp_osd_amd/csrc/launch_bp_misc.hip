@@ -12,7 +12,7 @@ using namespace bposd_host;
 namespace bposd_host {
 template <int DC, int DV, int METHOD>
 static int launch_bp_large_tm(bposd_handle* h, BpLargeParams& P) {
-    const size_t lds = bp_large_lds_bytes(h->m, h->n, METHOD == 2);
+    const size_t lds = bp_large_lds_bytes(h->m, h->n, METHOD == 2, DC);
     auto k = bp_large_kernel<DC, DV, METHOD>;
     // persistent workgroups: what registers and LDS admit per CU (the message workspace is per workgroup)
     int wg_per_cu = 1;
@@ -24,7 +24,7 @@ static int launch_bp_large_tm(bposd_handle* h, BpLargeParams& P) {
     wg_per_cu = METHOD >= 1 ? 1 : occ;
     if (const char* e = getenv("BPOSD_LARGE_WG_CAP")) wg_per_cu = std::max(1, std::min(occ, atoi(e)));
     const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
-    constexpr int SLOTS = METHOD == 1 ? DC + 4 : (METHOD == 2 ? DC + 2 : DC);  // message planes (+ the check records of the min-sum form)
+    constexpr int SLOTS = METHOD == 1 ? DC + 4 : (METHOD == 2 ? DC + 1 : DC);  // message planes (+ the check records of the min-sum form)
     int rc;
     if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * SLOTS * P.mp))) return rc;
     if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
@@ -38,8 +38,8 @@ static int launch_bp_large_tm(bposd_handle* h, BpLargeParams& P) {
 template <int DC, int DV>
 static int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
     if (h->cfg.bp_method != BPOSD_BP_MIN_SUM) return launch_bp_large_tm<DC, DV, 0>(h, P);
-    // min-sum: a1 of every check in LDS where it fits (bp_variant 63 forces the form with whole records in the workspace)
-    const bool a1_in_lds = bp_large_lds_bytes(h->m, h->n, true) <= h->lds_per_cu && h->bp_variant != 63;
+    // min-sum: a1 and the flags of every check in LDS where they fit (bp_variant 63 forces the form with whole records in the workspace)
+    const bool a1_in_lds = bp_large_lds_bytes(h->m, h->n, true, DC) <= h->lds_per_cu && h->bp_variant != 63;
     return a1_in_lds ? launch_bp_large_tm<DC, DV, 2>(h, P) : launch_bp_large_tm<DC, DV, 1>(h, P);
 }
 
