@@ -436,10 +436,18 @@ def main():
         value = world * B * steps / elapsed
         # algorithmic bytes of the dominant kernel (BP): SURVEY.md §8(d)
         bytes_per_iter = (4 * E + 2 * n) * 8
+        large_note = "algorithmic fp64 message bytes (4E+2n)*8 per executed iteration; "
+        large_form = dec.bp_kernel_info()["read_cycles"] if large else 0  # (which form of bp_large_kernel ran: include/bposd_mi355x_debug.h)
         if large and bp_method == "ms":
-            # HBM-resident min-sum (round 4): bit->check messages as before (E written, E read), check->bit as ONE 32-byte record
-            # per check (written once, read at least once) -- bp_large_kernel.hip.h
-            bytes_per_iter = (2 * E + 2 * n) * 8 + 2 * 32 * m
+            # HBM-resident min-sum (round 4): bit->check messages as before (E written, E read); check->bit either as ONE 32-byte
+            # record per check (written once, read at least once), or -- per-check data in LDS -- only the second minimum
+            # through the workspace (8 bytes per check written, read once by the edge that holds the minimum)
+            bytes_per_iter = (2 * E + 2 * n) * 8 + (2 * 8 * m if large_form == 2 else 2 * 32 * m)
+            large_note = ("algorithmic bytes (2E+2n)*8 + %s per executed iteration: fp64 bit->check messages through HBM; the check->bit "
+                          "messages are rebuilt from two scaled minima per check%s ((4E+2n)*8 with per-edge messages both ways, rounds "
+                          "1-3); " % (("2*8*m", ", the first of them and the sign flags resident in LDS, the second through HBM")
+                                      if large_form == 2 else ("2*32*m", ", one 32-byte record per check through HBM")))
+        large_note += "messages stream through HBM (1.3 MB per syndrome, far beyond LDS)"
         avg_bp_ms = float(np.mean(bp_ms)) if bp_ms else float("nan")
         avg_iters = iters_tot / steps
         algo_bytes = avg_iters * bytes_per_iter + B * (m + n)
@@ -557,10 +565,7 @@ def main():
                 "avg_launch_ms": avg_bp_ms,
                 "isolated_launch_ms": t_last["bp_ms"],
                 "frac_isolated": (algo_bytes_last / (t_last["bp_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_last["bp_ms"] > 0 else None,
-                "note": ((("algorithmic bytes (2E+2n)*8 + 2*32*m per executed iteration: fp64 bit->check messages plus one 32-byte "
-                           "record per check from which the check->bit messages are rebuilt ((4E+2n)*8 with per-edge messages both "
-                           "ways, rounds 1-3); " if bp_method == "ms" else "algorithmic fp64 message bytes (4E+2n)*8 per executed iteration; ") +
-                          "messages stream through HBM (1.3 MB per syndrome, far beyond LDS)") if large else
+                "note": (large_note if large else
                          ("SURVEY.md 8(d)'s algorithmic fp64 message bytes (4E+2n)*8 per executed iteration over the HBM peak; "
                           "the messages never leave LDS / registers, so this fraction exceeds 1 and is NOT a utilisation -- "
                           "roofline_lds is the kernel's real bound")) +

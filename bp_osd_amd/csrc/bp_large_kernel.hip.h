@@ -80,8 +80,10 @@ __host__ __device__ inline size_t bp_large_lds_bytes(int m, int n, bool per_chec
     return (size_t)((m + 1) & ~1) * 8 + meta + (size_t)((n + 63) / 64) * 8 + tail;
 }
 
+constexpr int bp_large_threads(int method) { return method == 2 ? 1024 : 512; }  // METHOD 2: 80 VGPRs, one workgroup per CU (LDS): 16 waves
+
 template <int DC, int DV, int METHOD>
-__global__ __launch_bounds__(512) void bp_large_kernel(const BpLargeParams P) {
+__global__ __launch_bounds__(bp_large_threads(METHOD)) void bp_large_kernel(const BpLargeParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = P.m, n = P.n, MP = P.mp;
     const int NT = blockDim.x;

@@ -1016,6 +1016,8 @@ int bposd_bp_kernel_info(bposd_handle* h, int32_t* kernel, int64_t* lds_model) {
         } else if (h->last_bp_kernel == BPOSD_BP_KERNEL_CLASS) {
             lds_model[0] = h->class_read_cycles; lds_model[1] = h->class_read_floor;
             lds_model[2] = h->class_write_cycles; lds_model[3] = h->class_write_floor;
+        } else if (h->last_bp_kernel == BPOSD_BP_KERNEL_LARGE) {
+            lds_model[0] = h->large_form;  // (no bank model: which form of the kernel ran -- bp_large_kernel.hip.h)
         }
     }
     return BPOSD_OK;

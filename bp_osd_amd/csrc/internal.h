@@ -121,6 +121,7 @@ struct bposd_handle {
     // device tables
     int *d_rp = nullptr, *d_ci = nullptr;
     int *d_chk_deg = nullptr, *d_var_deg = nullptr, *d_var_pos = nullptr, *d_pos_bit = nullptr, *d_var_ck = nullptr;
+    int large_form = 0;  // form of the last bp_large_kernel launch: 0 per-edge messages (product-sum), 1 check records in the workspace, 2 per-check data in LDS
     int tab_np = 0;
     long layout_cost = 0, layout_cost_natural = 0, layout_cost_ideal = 0;  // simulated LDS cycles of the bit pass
     double* d_llr0 = nullptr;

@@ -12,12 +12,13 @@ using namespace bposd_host;
 namespace bposd_host {
 template <int DC, int DV, int METHOD>
 static int launch_bp_large_tm(bposd_handle* h, BpLargeParams& P) {
+    h->large_form = METHOD;
     const size_t lds = bp_large_lds_bytes(h->m, h->n, METHOD == 2, DC);
     auto k = bp_large_kernel<DC, DV, METHOD>;
     // persistent workgroups: what registers and LDS admit per CU (the message workspace is per workgroup)
     int wg_per_cu = 1;
     { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
-    { int rc_occ = cached_occupancy(h, (const void*)k, 512, lds, &wg_per_cu); if (rc_occ) return rc_occ; }
+    { int rc_occ = cached_occupancy(h, (const void*)k, bp_large_threads(METHOD), lds, &wg_per_cu); if (rc_occ) return rc_occ; }
     const int occ = std::max(1, std::min(wg_per_cu, 4));
     // The check records of the min-sum form are gathered ~11 times each in a bit pass; with one workgroup per CU the 256 record
     // arrays (465 KB each on 14520 x 29524) stay in the memory-side cache between uses: 72-74 -> 61-62 ms per 1024 syndromes.
@@ -30,7 +31,7 @@ static int launch_bp_large_tm(bposd_handle* h, BpLargeParams& P) {
     if ((rc = ensure_lanes(h, &Lane::bpl_llr, sizeof(double) * (size_t)grid * h->n))) return rc;
     P.msg_ws = (double*)h->cur->bpl_msg.p;
     P.llr_tmp = (double*)h->cur->bpl_llr.p;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, h->cur->stream, P);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(bp_large_threads(METHOD)), lds, h->cur->stream, P);
     HIP_TRY(h, hipGetLastError());
     return 0;
 }

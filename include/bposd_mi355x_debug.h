@@ -19,7 +19,9 @@ int bposd_layout_info(bposd_handle *h, int64_t *natural_cycles, int64_t *chosen_
 
 /* Diagnostics: which BP kernel the last decode call launched, and the bank-conflict model of its bit pass.
  * kernel: BPOSD_BP_KERNEL_*.  lds_model[4] (local-edge and class kernels, else zeros): modelled ds_read_b64 cycles of one
- * bit pass per workgroup, their conflict-free floor, modelled ds_write_b64 cycles, their floor.  Any pointer may be NULL. */
+ * bit pass per workgroup, their conflict-free floor, modelled ds_write_b64 cycles, their floor; after a bp_large_kernel launch
+ * lds_model[0] is the form that ran (0: per-edge messages both ways (product-sum); 1: min-sum, one 32-byte record per check in the
+ * workspace; 2: min-sum, per-check data in LDS).  Any pointer may be NULL. */
 #define BPOSD_BP_KERNEL_LDS 0    /* bp_kernel: every message in LDS, per-lane degree predicates */
 #define BPOSD_BP_KERNEL_LOCAL 1  /* bp_local_kernel: (3,6)-regular codes, a third of the messages in registers */
 #define BPOSD_BP_KERNEL_CLASS 2  /* bp_class_kernel: one check degree, bits sorted into degree classes */
