@@ -590,7 +590,7 @@ class BpOsdDecoder:
         return self.OSD_KERNEL_NAMES.get(self._lib.bposd_last_osd_kernel(self._h), "none")
 
     def set_bp_variant(self, variant: int):
-        """Tuning / test knob: 0 auto; 1, 2, 4 LDS kernel shapes; 16 .. 26 local-edge kernel; 32 class kernel; 64 any-degree kernel (slow; cross-checks) -- see the C header."""
+        """Tuning / test knob: 0 auto; 1, 2, 4 LDS kernel shapes; 16 .. 26 local-edge kernel; 32 class kernel; 63 HBM-resident min-sum with whole check records in the workspace; 64 any-degree kernel (slow; cross-checks) -- see the C header."""
         _lib.check(self._lib, self._h, self._lib.bposd_set_bp_variant(self._h, int(variant)))
 
     # ------------------------------------------------------------------ mutators / attributes

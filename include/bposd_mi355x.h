@@ -252,8 +252,9 @@ int bposd_last_osd_kernel(bposd_handle *h);
  * messages in registers; (3,6)-regular codes with n = 2m and min-sum only, BPOSD_ERR_UNSUPPORTED otherwise):
  * 2 checks per thread at <= 80 / <= 64 VGPRs, 1 check per thread.  Auto picks 16 where it applies.  All variants
  * return identical results.  32 = class kernel (one check degree, bit degrees of a compiled range; auto picks it where it
- * applies and the local-edge kernel does not).  64 = the any-degree kernel on any code (slow; a
- * second implementation for cross-checks, also of the HBM-resident BP kernel). */
+ * applies and the local-edge kernel does not).  63 = HBM-resident min-sum kernel with whole check records in the workspace
+ * (the form a code whose per-check data exceed the CU's LDS gets; ignored by the other kernels).  64 = the any-degree
+ * kernel on any code (slow; a second implementation for cross-checks, also of the HBM-resident BP kernel). */
 int bposd_set_bp_variant(bposd_handle *h, int32_t variant);
 
 /* Message for the last error on this handle (h == NULL: last create() failure). */
