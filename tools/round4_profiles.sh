@@ -18,7 +18,8 @@ bash tools/pmc_sq.sh r04_ps_clip20 --config h1922_ps_cs60_clip20 > $OUT/sq_count
 bash tools/pmc_sq.sh r04_ps_noclip --config h1922_ps_cs60 > $OUT/sq_counters_h1922_ps_cs60.txt 2>&1; echo "sq ps noclip done"
 cd $REPO
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 4 --warmup 1 \
-    --cpu-sample 0 --host-steps 0 --rehearse-on-one-gpu > $OUT/bench_rehearsal_2ranks.json 2> $OUT/bench_rehearsal_2ranks.err; echo "rehearsal rc $?"
+    --cpu-sample 0 --host-steps 0 --rehearse-on-one-gpu > $OUT/bench_rehearsal_2ranks.out 2> $OUT/bench_rehearsal_2ranks.err; echo "rehearsal rc $?"
+grep '^{' $OUT/bench_rehearsal_2ranks.out > $OUT/bench_rehearsal_2ranks.json   # (gloo prints its connection lines on stdout; RCCL runs do not)
 for t in pipe nopipe l29k hgp900; do
   f=$(find $REPO/gpurun_out/prof_r04_$t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_$t.csv
   python tools/pmc_traffic_summary.py $REPO/gpurun_out/prof_r04_$t > $OUT/pmc_traffic_$t.json 2>/dev/null
