@@ -36,7 +36,9 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     const size_t g = (size_t)grid;
     const bool wide_cs = Q.osd_method == BPOSD_OSD_CS && Q.osd_order > OSDL_MAXSPAN;
     const bool wide_fp = wide_cs && fpw;  // fp64 weights over a pair span beyond 16: 64-bit column words per row / per bit in HBM
-    const size_t sizes[17] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
+    const bool gauss = Q.osd_method != BPOSD_OSD_CS;  // Gaussian elimination + back-substitution: every pivot group keeps its rows
+    Q.pro_stride = gauss ? osd_large_pro_rows(Q.W) * 64 : (size_t)OSDL_K * Q.W * 64;
+    const size_t sizes[18] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
                              g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
                              g * sizeof(int) * (size_t)Q.nsort,                    // kidx
                              g * sizeof(int) * (size_t)h->n,                       // inv
@@ -45,22 +47,23 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
                              g * sizeof(int) * (size_t)64 * Q.W,                   // wt
                              g * (size_t)h->n,                                     // xout
                              g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.mrl,        // tmo
-                             g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.W * 64,     // pro
+                             g * sizeof(unsigned long long) * Q.pro_stride,                  // pro
                              fpw ? g * sizeof(double) * (size_t)h->n : 0,                    // costs_ws
                              fpw ? g * sizeof(double) * (size_t)Q.wdn : 0,                   // wd_ws
                              fpw ? g * sizeof(unsigned short) * (size_t)Q.mrl : 0,           // am_ws
                              g * sizeof(int) * (size_t)Q.mrl,                                // alist
                              wide_cs ? g * sizeof(unsigned long long) * (size_t)OSDL_MAXSPAN_CS * RPT * OSDL_NW : 0,  // colvec_ws
                              wide_fp ? g * sizeof(unsigned long long) * (size_t)Q.mrl : 0,                   // am64_ws
-                             wide_fp ? g * sizeof(unsigned long long) * (size_t)h->n : 0};                   // cm64_ws
+                             wide_fp ? g * sizeof(unsigned long long) * (size_t)h->n : 0,                    // cm64_ws
+                             gauss ? g * sizeof(unsigned long long) * (size_t)64 * Q.W : 0};                 // pmask
     size_t total = 0;
     for (size_t b : sizes) total += a256(b);
     int rc = ensure_lanes(h, &Lane::osdl_ws, total);
     if (rc) return rc;
-    unsigned char* ptrs[17];
+    unsigned char* ptrs[18];
     {
         unsigned char* base = (unsigned char*)h->cur->osdl_ws.p;
-        for (int i = 0; i < 17; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
+        for (int i = 0; i < 18; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
     }
     Q.alist = (int*)ptrs[13];
     Q.colvec_ws = wide_cs ? (unsigned long long*)ptrs[14] : nullptr;
@@ -79,6 +82,7 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     Q.xout = (uint8_t*)ptrs[7];
     Q.tmo = (unsigned long long*)ptrs[8];
     Q.pro = (unsigned long long*)ptrs[9];
+    Q.pmask = gauss ? (unsigned long long*)ptrs[17] : nullptr;
     const size_t lds = osd_large_lds_bytes(Q.W, RPT, fpw ? h->n : 0);
     if (lds > h->lds_per_cu) return fail(h, BPOSD_ERR_UNSUPPORTED, "large OSD kernel needs %zu bytes of LDS", lds);
 #define OSDL_LAUNCH(R)                                                                                      \

@@ -90,7 +90,13 @@ struct OsdLargeParams {
     int* __restrict__ rowpos;               // [grid][mrl]     pivot position of a row, -1 if unused
     int* __restrict__ wt;                   // [grid][64 * W]  weights of the single candidates
     unsigned long long* __restrict__ tmo;   // [grid][OSDL_K * mrl]     masks of the open groups
-    unsigned long long* __restrict__ pro;   // [grid][OSDL_K * W * 64]  pivot rows of the open groups, [g][word][q]
+    unsigned long long* __restrict__ pro;   // pivot rows of the pivot groups at their start state, [word][q] per group.  Gauss-Jordan
+                                            // (OSD-CS): [grid][OSDL_K * W * 64], the open groups only.  Gaussian (OSD-0 / OSD-E):
+                                            // [grid][osd_large_pro_rows(W) * 64] -- EVERY group keeps its rows (the group of word w: the
+                                            // words w + 1 .. W - 1), the back-substitution reads them from here
+    size_t pro_stride;                      // elements per workgroup of `pro`
+    unsigned long long* __restrict__ pmask; // [grid][64 * W] nullable (Gaussian only): by sorted column position, the pivot row's
+                                            // combination mask within its own group, own bit included
     int* __restrict__ alist;                // [grid][mrl]     rows the apply pass still updates (compacted, ascending)
     uint8_t* __restrict__ xout;             // [grid][n]
     long long* __restrict__ dbg;            // nullable: phase clocks of list slot 0 (s_memtime ticks)
@@ -112,6 +118,11 @@ struct OsdLargeParams {
 
 constexpr int OSDL_MAXPAIRS = OSDL_MAXSPAN * (OSDL_MAXSPAN - 1) / 2;
 
+// Gaussian mode: word rows (of 64 pivots) of `pro` per workgroup -- group of word w holds the words w + 1 .. W - 1 at row
+// osd_large_pro_base(W, w) + x
+__host__ __device__ inline long long osd_large_pro_base(int W, int w) { return (long long)w * (2 * W - w - 1) / 2 - (w + 1); }
+__host__ __device__ inline size_t osd_large_pro_rows(int W) { return (size_t)W * (W - 1) / 2 + 1; }
+
 // n_fp: block length when fp64 candidate weights are needed (adds the per-bit info words of that path), else 0
 __host__ __device__ inline size_t osd_large_union_bytes(int W, int RPT, int n_fp = 0) {
     size_t e3 = (size_t)OSDL_NW * (OSDL_K - 1) * 256 * 8;   // wave-private tables of E3
@@ -119,7 +130,7 @@ __host__ __device__ inline size_t osd_large_union_bytes(int W, int RPT, int n_fp
     size_t sw = (size_t)OSDL_MAXSPAN * RPT * OSDL_NW * 8 + (size_t)RPT * OSDL_NW * 8 + (size_t)W * 8 + 64 * 4;
     // region R behind them: the wspan + 1 solution vectors of the back-substitution, later the per-bit info words of the
     // fp64-weight path
-    const size_t zb = (size_t)(OSDL_MAXSPAN + 1) * (W + 1) * 8;
+    const size_t zb = (size_t)(OSDL_MAXSPAN + 1) * (W + 2) * 8;  // the vectors + two result words each
     const size_t fb = n_fp > 0 ? ((size_t)n_fp * 4 + 7) / 8 * 8 + (size_t)OSDL_MAXPAIRS * 8 : 0;
     sw += zb > fb ? zb : fb;
     size_t b = e3 > ap ? e3 : ap;
@@ -130,7 +141,7 @@ __host__ __device__ inline size_t osd_large_lds_bytes(int W, int RPT, int n_fp =
     size_t b = 0;
     b += (size_t)2 * OSDL_NW * 2 * 8;            // pbuf
     b += (size_t)2 * OSDL_NW * 4;                // pcol
-    b += (size_t)OSDL_K * 64 * 4 + OSDL_K * 4;   // grow, gnp
+    b += (size_t)OSDL_K * 64 * 4 + 2 * OSDL_K * 4;   // grow, gnp, gbo
     b += 2 * 8 + 16 * 4;                         // best64, misc
     b += osd_large_union_bytes(W, RPT, n_fp);
     return b + 64;
@@ -338,8 +349,8 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_lds(unsigned int lpw_a
 // state for every word to the right of w, written to PRO.  Not inlined, so that its registers are allocated on their own
 // (the kernel sits at its 128-VGPR cap: inside it, more than one word in flight per wave went to scratch and ran slower).
 __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long* U, const int* grow, const int* gnp, const unsigned long long* TmO,
-                                                              unsigned long long* PRO, const unsigned long long* M, int MRL, int W, int w, int ng,
-                                                              int npiv) {
+                                                              unsigned long long* PRO, const int* gbo, const unsigned long long* M, int MRL, int W, int w,
+                                                              int ng, int npiv) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
@@ -361,7 +372,7 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                         unsigned long long prq[OSDL_E3D][4], mvq[OSDL_E3D];
                         auto issue = [&](int d, int xx) {
                             if (xx < W) {
-                                const unsigned long long* src = PRO + ((size_t)(builder ? tg : 0) * W + xx) * 64 + q0;
+                                const unsigned long long* src = PRO + ((long long)gbo[builder ? tg : 0] + xx) * 64 + q0;
     #pragma unroll
                                 for (int kk = 0; kk < 4; ++kk) prq[d][kk] = src[kk];
                                 mvq[d] = M[(size_t)xx * MRL + row];
@@ -398,7 +409,7 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                                         v ^= tw[(g * 16 + grp) * 16 + (int)((mrow[g] >> (4 * grp)) & 15ull)];
                                 }
                             }
-                            PRO[((size_t)ng * W + x) * 64 + lane] = v;
+                            PRO[((long long)gbo[ng] + x) * 64 + lane] = v;
                             __builtin_amdgcn_wave_barrier();
                         };
                         const int xs = w + 1 + wave;
@@ -434,6 +445,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
     unsigned int* pcol = (unsigned int*)p; p += (size_t)2 * OSDL_NW * 4;
     int* grow = (int*)p; p += OSDL_K * 64 * 4;
     int* gnp = (int*)p; p += OSDL_K * 4;
+    int* gbo = (int*)p; p += OSDL_K * 4;  // word-row base of each open group in PRO: its word x is at PRO + (gbo[g] + x) * 64
     int* misc = (int*)p;
     // sweep-phase view of U
     unsigned long long* colvec = U;
@@ -451,7 +463,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
     int* wt = P.wt + (size_t)blockIdx.x * 64 * W;
     uint8_t* xout = P.xout + (size_t)blockIdx.x * n;
     unsigned long long* TmO = P.tmo + (size_t)blockIdx.x * OSDL_K * MRL;
-    unsigned long long* PRO = P.pro + (size_t)blockIdx.x * OSDL_K * W * 64;
+    unsigned long long* PRO = P.pro + (size_t)blockIdx.x * P.pro_stride;
+    unsigned long long* pmask = P.pmask ? P.pmask + (size_t)blockIdx.x * 64 * W : nullptr;
     int* alist = P.alist + (size_t)blockIdx.x * MRL;
 
     for (;;) {
@@ -642,7 +655,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     unsigned long long pr[5];
                     // unconditional (clamped) loads so that the five requests are in flight together
                     // unconditional (clamped) loads so that the five requests are in flight together
-                    const unsigned long long* src = PRO + ((size_t)g * W + (xx < cw ? x0 + xx : W - 1)) * 64;
+                    const unsigned long long* src = PRO + ((long long)gbo[g] + (xx < cw ? x0 + xx : W - 1)) * 64;
                     unsigned long long val[5];
 #pragma unroll
                     for (int kk = 0; kk < 5; ++kk) {
@@ -787,7 +800,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     unsigned long long v = 0ull;
                     const int np = gnp[g] - 4 * grp;
                     if (np > 0) {
-                        const unsigned long long* pr = PRO + ((size_t)g * W + w) * 64 + 4 * grp;  // (grp <= 15: all four words exist)
+                        const unsigned long long* pr = PRO + ((long long)gbo[g] + w) * 64 + 4 * grp;  // (grp <= 15: all four words exist)
                         unsigned long long val[4];
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) val[kk] = pr[kk];
@@ -1075,11 +1088,20 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             OSDL_COUNT(7);
             if (npiv > 0) {
                 OSDL_COUNT(8);
-                if (tid == 0) gnp[ng] = npiv;
+                if (tid == 0) {
+                    gnp[ng] = npiv;
+                    gbo[ng] = gauss ? (int)osd_large_pro_base(W, w) : ng * W;
+                }
                 __syncthreads();  // grow / gnp / TmO of the new group are visible
+                if (pmask && (int)threadIdx.x < npiv) {
+                    // what the back-substitution needs of this group besides its rows: pivot row q ends as the XOR of the START
+                    // states of the group's pivots in its mask (the ones it absorbed inside the panel) and its own
+                    const int r = grow[ng * 64 + (int)threadIdx.x];
+                    pmask[rowpos[r]] = TmO[(size_t)ng * MRL + r] ^ (1ull << threadIdx.x);
+                }
                 // ------------ E3: pivot rows of the new group at its start state, for every later word.
                 // One wave per word, wave-private tables (a wave's LDS operations complete in order).
-                if (w + 1 < W) osdl_e3_materialise(U, grow, gnp, TmO, PRO, M, (int)MRL, W, w, ng, npiv);
+                if (w + 1 < W) osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, w, ng, npiv);
                 ++ng;
                 __syncthreads();  // PRO of the new group is visible
                 OSDL_TICK(4);
@@ -1137,35 +1159,92 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             if (tid < ntc_g) zv[(size_t)tid * W + (tpos[tid] >> 6)] = 1ull << (tpos[tid] & 63);
             if (tid == 0) zv[(size_t)OSDL_MAXSPAN * W + (W - 1)] = 1ull << 63;
             __syncthreads();
-            #pragma clang loop unroll(disable)
-                        for (int w = wlast; w >= 0; --w) {
-                            const int prow = pivrow[w * 64 + lane];  // lane q: the pivot at sorted position 64 w + q, if any
-                            unsigned long long acc[NR];
-            #pragma unroll
-                            for (int c = 0; c < NR; ++c) acc[c] = 0ull;
-                            if (prow >= 0) {
-                                // (eight row words in flight per lane instead of one: measured slower, 13.3 -> 15.0 M cycles -- the loop is
-                                // not waiting for a single round trip but for the CU's gather rate: 64 distinct lines per wave-level load)
-                                for (int x = w + wave; x < W; x += OSDL_NW) {  // the 16 waves split the words to the right
-                                    const unsigned long long v = M[(size_t)x * MRL + prow];
-            #pragma unroll
-                                    for (int c = 0; c < NR; ++c) acc[c] ^= v & zv[(size_t)c * W + x];
-                                }
+            // The rows come from PRO, where every group has kept its pivot rows at their START state for the words to the right
+            // of its panel, [word][q] -- 64 lanes read 512 contiguous bytes -- and not from M, where a pivot row is one row
+            // among 16384 (rounds 1-3: 64 distinct cache lines per wave-level load, 3.3 M of them on this loop's critical
+            // path).  Pivot row p ended as XOR of start_l over l in S_p (pmask: the pivots of its own group it absorbed, and
+            // itself), so <row_p, z> over the words right of the panel = parity(popcount(S_p & A)) with A_l = <start_l, z>;
+            // the panel's own word is final in M and is read from there (one gather per step).
+            unsigned long long* resb = resw + NR;  // [NR] the own-word part, by column lane (behind resw: R has room for NR + 1 vectors' tails)
+            if (tid < NR) resb[tid] = 0ull;
+            __syncthreads();
+#pragma clang loop unroll(disable)
+            for (int w = wlast; w >= 0; --w) {
+                const int prow = pivrow[w * 64 + lane];  // lane q: the pivot at sorted position 64 w + q, if any
+                const unsigned long long pv = __ballot(prow >= 0);
+                if (pv == 0ull) continue;  // (uniform: no pivot in this word)
+                const int np = __popcll(pv);  // = the group's pivots: slots 0 .. np - 1 of its rows in PRO
+                unsigned long long acc[NR];
+#pragma unroll
+                for (int c = 0; c < NR; ++c) acc[c] = 0ull;
+                const unsigned long long* gp = PRO + osd_large_pro_base(W, w) * 64 + lane;
+                // the 16 waves split the words to the right; a wave keeps XB of its words in flight (the loads are coalesced now,
+                // so that is XB requests, not XB x 64), and the NR solution words of a position are read from LDS together
+                // before they are used: as first written the loop waited for every load and every LDS read on its own
+                // (47 k cycles per step, 20 M per elimination)
+                constexpr int XB = 8;
+                for (int x0 = w + 1 + wave; x0 < W; x0 += OSDL_NW * XB) {
+                    unsigned long long vx[XB];
+#pragma unroll
+                    for (int i = 0; i < XB; ++i) {
+                        const int x = x0 + i * OSDL_NW;
+                        vx[i] = gp[(size_t)(x < W ? x : W - 1) * 64];
+                    }
+#pragma unroll
+                    for (int i = 0; i < XB; ++i) {
+                        const int x = x0 + i * OSDL_NW;
+                        if (x < W) {  // uniform
+                            unsigned long long zz[NR];
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) zz[c] = zv[(size_t)c * W + x];
+                            static_assert(NR == 17, "the statement below names every element");
+                            asm volatile("" : "+v"(zz[0]), "+v"(zz[1]), "+v"(zz[2]), "+v"(zz[3]), "+v"(zz[4]), "+v"(zz[5]), "+v"(zz[6]), "+v"(zz[7]),
+                                         "+v"(zz[8]), "+v"(zz[9]), "+v"(zz[10]), "+v"(zz[11]), "+v"(zz[12]), "+v"(zz[13]), "+v"(zz[14]), "+v"(zz[15]),
+                                         "+v"(zz[16]));
+                            const unsigned int vlo = (unsigned int)vx[i], vhi = (unsigned int)(vx[i] >> 32);
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) {  // acc ^= v & z: one v_bitop3 per half (0x78 = a ^ (b & c))
+                                const unsigned int lo = __builtin_amdgcn_bitop3_b32((unsigned int)acc[c], vlo, (unsigned int)zz[c], 0x78);
+                                const unsigned int hi = __builtin_amdgcn_bitop3_b32((unsigned int)(acc[c] >> 32), vhi, (unsigned int)(zz[c] >> 32), 0x78);
+                                acc[c] = ((unsigned long long)hi << 32) | lo;
                             }
-            #pragma unroll
-                            for (int c = 0; c < NR; ++c) {
-                                if (c < ntc_g || c == OSDL_MAXSPAN) {  // uniform
-                                    const unsigned long long bits = __ballot(prow >= 0 && (__popcll(acc[c]) & 1));
-                                    if (lane == 0 && bits) atomicXor(&resw[c], bits);
-                                }
-                            }
-                            __syncthreads();
-                            if (tid < NR) {
-                                zv[(size_t)tid * W + w] ^= resw[tid];
-                                resw[tid] = 0ull;
-                            }
-                            __syncthreads();
                         }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    if (c < ntc_g || c == OSDL_MAXSPAN) {  // uniform
+                        const unsigned long long bits = __ballot(lane < np && (__popcll(acc[c]) & 1));
+                        if (lane == 0 && bits) atomicXor(&resw[c], bits);
+                    }
+                }
+                if (wave == 0) {
+                    const unsigned long long vb = prow >= 0 ? M[(size_t)w * MRL + prow] : 0ull;
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) {
+                        if (c < ntc_g || c == OSDL_MAXSPAN) {
+                            const unsigned long long bits = __ballot((__popcll(vb & zv[(size_t)c * W + w]) & 1) != 0);
+                            if (lane == 0) resb[c] = bits;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const unsigned long long S = prow >= 0 ? pmask[w * 64 + lane] : 0ull;
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) {
+                        if (c < ntc_g || c == OSDL_MAXSPAN) {
+                            const unsigned long long A = resw[c], Bw = resb[c];
+                            const unsigned long long xb = __ballot(prow >= 0 && (((__popcll(S & A) & 1) ^ (int)((Bw >> lane) & 1ull)) != 0));
+                            if (lane == 0) {
+                                zv[(size_t)c * W + w] ^= xb;
+                                resw[c] = 0ull;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
             OSDL_TICK(13);
             // reduced columns and reduced syndrome as bit vectors over the pivot ROWS (the layout the sweep below uses)
 #pragma unroll
