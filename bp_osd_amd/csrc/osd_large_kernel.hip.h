@@ -348,11 +348,23 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_lds(unsigned int lpw_a
 // E3 as a function of its own: the pivot rows of the new group (group index ng, npiv rows listed in grow) at their start
 // state for every word to the right of w, written to PRO.  Not inlined, so that its registers are allocated on their own
 // (the kernel sits at its 128-VGPR cap: inside it, more than one word in flight per wave went to scratch and ran slower).
-__device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long* U, const int* grow, const int* gnp, const unsigned long long* TmO,
-                                                              unsigned long long* PRO, const int* gbo, const unsigned long long* M, int MRL, int W, int w,
+__device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long* U, const int* grow_, const int* gnp_, const unsigned long long* TmO_,
+                                                              unsigned long long* PRO_, const int* gbo_, const unsigned long long* M_, int MRL, int W, int w,
                                                               int ng, int npiv) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    // The pointers arrive generic.  Left so, every access below is a FLAT instruction, which counts on the vector-memory AND the
+    // LDS counter: the wait before a stage's first table write then waits for every row word requested for the LATER stages too,
+    // and the OSDL_E3D-deep prefetch is no prefetch (measured: E3 ... -> ... M cycles per elimination).  Named address spaces
+    // give global_load / ds_read with their own counters.
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    typedef __attribute__((address_space(3))) int l_i32;
+    const g_u64* TmO = (const g_u64*)TmO_;
+    g_u64* PRO = (g_u64*)PRO_;
+    const g_u64* M = (const g_u64*)M_;
+    const l_i32* grow = (const l_i32*)grow_;
+    const l_i32* gnp = (const l_i32*)gnp_;
+    const l_i32* gbo = (const l_i32*)gbo_;
 
                         typedef volatile __attribute__((address_space(3))) unsigned long long* lds_rw;
                         lds_rw tw = (lds_rw)(U + (size_t)wave * (OSDL_K - 1) * 256);
@@ -372,7 +384,7 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                         unsigned long long prq[OSDL_E3D][4], mvq[OSDL_E3D];
                         auto issue = [&](int d, int xx) {
                             if (xx < W) {
-                                const unsigned long long* src = PRO + ((long long)gbo[builder ? tg : 0] + xx) * 64 + q0;
+                                const g_u64* src = PRO + ((long long)gbo[builder ? tg : 0] + xx) * 64 + q0;
     #pragma unroll
                                 for (int kk = 0; kk < 4; ++kk) prq[d][kk] = src[kk];
                                 mvq[d] = M[(size_t)xx * MRL + row];
@@ -647,13 +659,17 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 // builds one table: 5 pivot-row words in registers, then a Gray-code walk (one XOR + one LDS
                 // store per entry).  The walk starts at entry (lane & 31) so that the 32 lanes of a store
                 // instruction hit 32 different entries = all 64 banks once.
-                for (int tt = tid; tt < ng * OSDL_G5 * OSDL_CW; tt += NT) {
+                // Two threads per table (416 tables of 32 entries, 832 of the 1024 threads): thread 2t + h builds the 16 entries whose
+                // top index bit is h, by a 4-bit Gray-code walk.  A 16-lane store group holds 16 different low index nibbles
+                // (lane & 15 ^ the walk's code) of 8 tables 256 bytes apart: every bank pair once.
+                static_assert(2 * OSDL_K * OSDL_G5 * OSDL_CW <= OSDL_NT, "one pass builds every table");
+                if (tid < 2 * ng * OSDL_G5 * OSDL_CW) {
+                    const int tt = tid >> 1, h = tid & 1;
                     const int xx = tt & (OSDL_CW - 1), gg = tt >> 3;
                     static_assert(OSDL_CW == 8, "table index decode assumes 8-word chunks");
                     const int g = gg / OSDL_G5, grp = gg - g * OSDL_G5;
                     const int np = gnp[g] - 5 * grp;
                     unsigned long long pr[5];
-                    // unconditional (clamped) loads so that the five requests are in flight together
                     // unconditional (clamped) loads so that the five requests are in flight together
                     const unsigned long long* src = PRO + ((long long)gbo[g] + (xx < cw ? x0 + xx : W - 1)) * 64;
                     unsigned long long val[5];
@@ -668,20 +684,20 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     // removed that wait and made the row walks slower by as much or more -- measured twice, not kept.)
                     asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]), "+v"(val[4]));
 #ifdef BPOSD_OSD_DIAG
-                    if (tt == tid) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); OSDL_TICK(21); }
+                    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); OSDL_TICK(21); }
 #endif
 #pragma unroll
                     for (int kk = 0; kk < 5; ++kk) pr[kk] = (xx < cw && kk < np) ? val[kk] : 0ull;
-                    unsigned int idx = osdl_opaque((unsigned int)lane & 31u);  // (laundered: else all 32 indices are hoisted + spilled)
-                    unsigned long long v = 0ull;
+                    unsigned int idx = osdl_opaque(((unsigned int)lane & 15u) | ((unsigned int)h << 4));  // (laundered: else the indices are hoisted + spilled)
+                    unsigned long long v = h ? pr[4] : 0ull;
 #pragma unroll
-                    for (int kk = 0; kk < 5; ++kk)
+                    for (int kk = 0; kk < 4; ++kk)
                         if ((idx >> kk) & 1u) v ^= pr[kk];
                     unsigned long long* tabp = U + (size_t)tt * 32;
                     tabp[idx] = v;
 #pragma unroll
-                    for (int i = 1; i < 32; ++i) {
-                        const int bit = (i & 1) ? 0 : ((i & 2) ? 1 : ((i & 4) ? 2 : ((i & 8) ? 3 : 4)));  // ctz(i)
+                    for (int i = 1; i < 16; ++i) {
+                        const int bit = (i & 1) ? 0 : ((i & 2) ? 1 : ((i & 4) ? 2 : 3));  // ctz(i)
                         idx ^= 1u << bit;
                         v ^= pr[bit];
                         tabp[idx] = v;
@@ -835,26 +851,36 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 const unsigned int usedbefore = usedmask;
                 {
                     const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
-                    constexpr int HB = RPT < 8 ? RPT : 8;  // rows per batch: their loads are in flight together
+                    // rows per batch: a batch's panel words AND its masks in all open groups are requested together (one round trip per
+                    // batch; with the masks fetched group by group behind the words it was 1 + ng round trips per batch, ten per
+                    // panel word at four open groups)
+                    constexpr int HB = RPT < 4 ? RPT : 4;
 #pragma unroll
                     for (int k0 = 0; k0 < RPT; k0 += HB) {
-                        unsigned long long old[HB], v[HB];
+                        unsigned long long old[HB], v[HB], mk[OSDL_K][HB];
 #pragma unroll
-                        for (int i = 0; i < HB; ++i) {
+                        for (int i = 0; i < HB; ++i)
                             old[i] = ((skipmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + (k0 + i) * NT * 8);
-                            v[i] = old[i];
-                        }
+#pragma unroll
+                        for (int g = 0; g < OSDL_K; ++g)
+#pragma unroll
+                            for (int i = 0; i < HB; ++i)
+                                mk[g][i] = (g < ng && ((skipmask >> (k0 + i)) & 1u) == 0u) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8) : 0ull;
+                        if (HB == 4)
+                            asm volatile("" : "+v"(old[0]), "+v"(old[1]), "+v"(old[HB > 2 ? 2 : 0]), "+v"(old[HB > 3 ? 3 : 0]), "+v"(mk[0][0]), "+v"(mk[0][1]),
+                                         "+v"(mk[0][HB > 2 ? 2 : 0]), "+v"(mk[0][HB > 3 ? 3 : 0]), "+v"(mk[1][0]), "+v"(mk[1][1]), "+v"(mk[1][HB > 2 ? 2 : 0]),
+                                         "+v"(mk[1][HB > 3 ? 3 : 0]), "+v"(mk[2][0]), "+v"(mk[2][1]), "+v"(mk[2][HB > 2 ? 2 : 0]), "+v"(mk[2][HB > 3 ? 3 : 0]),
+                                         "+v"(mk[3][0]), "+v"(mk[3][1]), "+v"(mk[3][HB > 2 ? 2 : 0]), "+v"(mk[3][HB > 3 ? 3 : 0]));
+                        static_assert(OSDL_K == 4, "the statement above names the masks of four groups");
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) v[i] = old[i];
 #pragma unroll
                         for (int g = 0; g < OSDL_K; ++g) {
                             if (g < ng) {
                                 const int ngrp = (gnp[g] + 3) >> 2;
-                                unsigned long long mk[HB];
 #pragma unroll
                                 for (int i = 0; i < HB; ++i)
-                                    mk[i] = ((skipmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8);
-#pragma unroll
-                                for (int i = 0; i < HB; ++i)
-                                    for (int grp = 0; grp < ngrp; ++grp) v[i] ^= U[(g * 16 + grp) * 16 + (int)((mk[i] >> (4 * grp)) & 15ull)];
+                                    for (int grp = 0; grp < ngrp; ++grp) v[i] ^= U[(g * 16 + grp) * 16 + (int)((mk[g][i] >> (4 * grp)) & 15ull)];
                             }
                         }
 #pragma unroll
