@@ -557,16 +557,42 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, M + (size_t)x * MRL, ro + k * NT * 8) = 0ull;
         }
         __syncthreads();
-#pragma unroll
+        // A row's column positions are fetched together (its edges' bit indices, then their sorted positions: two round trips),
+        // the bits that share a word are combined in registers and every word is written once.  As first written each edge was a
+        // chain of three dependent round trips (bit index, position, read-modify-write of the word), 33 per row, 528 per thread.
+#pragma clang loop unroll(disable)
         for (int k = 0; k < RPT; ++k) {
             const int r = tid + k * NT;
             if (r < m) {
+                constexpr int CH = 12;  // edges per batch (the degree of a check of the codes this path serves; more: further batches)
                 const int e0 = P.rp[r], e1 = P.rp[r + 1];
-                for (int e = e0; e < e1; ++e) {
-                    const int j = inv[P.ci[e]];
-                    M[(size_t)(j >> 6) * MRL + r] |= 1ull << (j & 63);  // only the owner touches row r
+                const bool sb = (P.synd[(size_t)s * m + r] & 1) != 0;
+                for (int eb = e0; eb < e1 || eb == e0; eb += CH) {
+                    int jj[CH + 1];
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) jj[i] = (eb + i < e1) ? P.ci[eb + i] : -1;
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) jj[i] = (jj[i] >= 0) ? inv[jj[i]] : -1;
+                    jj[CH] = (eb == e0 && sb) ? (W - 1) * 64 + 63 : -1;  // the syndrome column, with the first batch
+#pragma unroll
+                    for (int i = 0; i <= CH; ++i) {
+                        if (jj[i] < 0) continue;
+                        unsigned long long word = 0ull;
+                        bool first = true;  // is i the first entry of its word in this batch?
+#pragma unroll
+                        for (int i2 = 0; i2 <= CH; ++i2) {
+                            const bool same = jj[i2] >= 0 && (jj[i2] >> 6) == (jj[i] >> 6);
+                            if (same) word |= 1ull << (jj[i2] & 63);
+                            if (same && i2 < i) first = false;
+                        }
+                        if (first) {
+                            unsigned long long* dst = M + (size_t)(jj[i] >> 6) * MRL + r;  // only the owner touches row r
+                            if (eb == e0) *dst = word;    // (the matrix is zero: no read)
+                            else *dst |= word;            // a later batch may meet a word of an earlier one
+                        }
+                    }
+                    if (e1 == e0) break;
                 }
-                if (P.synd[(size_t)s * m + r] & 1) M[(size_t)(W - 1) * MRL + r] |= 1ull << 63;
             }
         }
         if (tid < 2 * OSDL_NW) pcol[tid] = 64u;
@@ -791,9 +817,17 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         cur[xx] = 0ull;
                         if (xx < cw && live && v[xx] != 0ull) cur[xx] = OSDL_ROW_LD(M + (size_t)(x0 + xx) * MRL, ro);
                     }
+                    // The new words are formed for all eight positions in one straight-line block (the positions that do not change
+                    // hold 0 ^ 0) and pinned there: with the XOR inside each store's own branch the compiler waits vmcnt(0) before
+                    // EVERY store for "its" load -- and on gfx9 that counter counts stores too, so each store waited for the previous
+                    // one to complete: up to eight write round trips in a row per row and chunk.
+#pragma unroll
+                    for (int xx = 0; xx < OSDL_CW; ++xx) cur[xx] ^= v[xx];
+                    static_assert(OSDL_CW == 8, "the statement below names every word of a chunk");
+                    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
 #pragma unroll
                     for (int xx = 0; xx < OSDL_CW; ++xx)
-                        if (xx < cw && live && v[xx] != 0ull) OSDL_ROW_ST(M + (size_t)(x0 + xx) * MRL, ro, cur[xx] ^ v[xx]);
+                        if (xx < cw && live && v[xx] != 0ull) OSDL_ROW_ST(M + (size_t)(x0 + xx) * MRL, ro, cur[xx]);
                 }
             }
             __syncthreads();
