@@ -264,87 +264,6 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
     if (lane == 0) { misc[4] = (unsigned int)cnp; misc[5] = (unsigned int)cnr; misc[6] = cdone ? 1u : 0u; }
 }
 
-// E2c for longer lists (1024 < rows <= OSDL_E2C_CAP): the same one-wave pivot loop with the list left in LDS.  A lane owns
-// the entries lane, lane + 64, ...; the pass that applies a pivot also finds, per lane, the entry with the lowest
-// candidate column for the next one (its key goes into the DPP minimum, so the winning lane knows its entry without a
-// second scan).  ~14 instructions per entry and pivot: ~1.8 k cycles per pivot at 2048 rows against ~10 k for the all-rows form.
-__device__ __attribute__((noinline)) void osdl_e2_compact_lds(unsigned int lpw_addr, unsigned int misc_addr, int nnz,
-                                                             unsigned long long vmask, int rank, int nrank, int done_in) {
-    constexpr int CAP = OSDL_E2C_CAP;
-    static_assert(CAP <= 64 * 32, "one bit of the per-lane used mask per owned entry");
-    const int lane = threadIdx.x & 63;
-    osdl_lds_w64 Lpw = (osdl_lds_w64)(size_t)lpw_addr;
-    osdl_lds_w64 Lt = Lpw + CAP;
-    osdl_lds_w32 Lid = (osdl_lds_w32)(Lt + CAP);
-    osdl_lds_w32 Lpiv = Lid + CAP;
-    osdl_lds_w32 misc = (osdl_lds_w32)(size_t)misc_addr;
-    const int epl = (nnz + 63) >> 6;
-    unsigned int cu = 0u;      // bit s: my s-th entry is a pivot row
-    unsigned int bestl = 64u;  // lowest candidate column among my unused entries ...
-    int bests = 0;             // ... and the entry that has it
-#pragma clang loop unroll(disable)
-    for (int s2 = 0; s2 < epl; ++s2) {
-        const int e = s2 * 64 + lane;
-        if (e < nnz) {
-            Lt[e] = 0ull;
-            if (Lid[e] >> 31) {
-                cu |= 1u << s2;
-            } else {
-                const unsigned int l = osd_ffs64_or_64(Lpw[e] & vmask);
-                if (l < bestl) { bestl = l; bests = s2; }
-            }
-        }
-    }
-    int cnp = 0, cnr = nrank;
-    bool cdone = done_in != 0;
-#pragma clang loop unroll(disable)
-    for (;;) {
-        if (cnr >= rank) { cdone = true; break; }
-        const unsigned int wk = osd_wave_min_u32((bestl << 6) | (unsigned int)lane);  // wave-uniform
-        const int col = (int)(wk >> 6);
-        if (col >= 64) break;
-        const int first = (int)(wk & 63u);
-        const int kbw = bests;  // (meaningful in the winning lane)
-        unsigned long long a = 0ull, c = 0ull;
-        if (lane == first) {
-            a = Lpw[kbw * 64 + lane];
-            c = Lt[kbw * 64 + lane];
-            cu |= 1u << kbw;
-            Lpiv[cnp] = (unsigned int)(kbw * 64 + lane);
-            Lpiv[64 + cnp] = (unsigned int)col;
-        }
-        const unsigned long long pw_p =
-            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a >> 32), first) << 32) |
-            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)a, first);
-        const unsigned long long t_p =
-            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(c >> 32), first) << 32) |
-            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)c, first);
-        const unsigned long long tq = t_p ^ (1ull << cnp);
-        bestl = 64u;
-        bests = 0;
-#pragma clang loop unroll(disable)
-        for (int s2 = 0; s2 < epl; ++s2) {
-            const int e = s2 * 64 + lane;
-            if (e < nnz) {
-                unsigned long long w = Lpw[e];
-                const bool ispiv = (lane == first) && (s2 == kbw);  // the pivot row itself stays as it is
-                if (((w >> col) & 1ull) && !ispiv) {
-                    w ^= pw_p;
-                    Lpw[e] = w;
-                    Lt[e] = Lt[e] ^ tq;
-                }
-                if (((cu >> s2) & 1u) == 0u) {
-                    const unsigned int l = osd_ffs64_or_64(w & vmask);
-                    if (l < bestl) { bestl = l; bests = s2; }
-                }
-            }
-        }
-        ++cnp;
-        ++cnr;
-    }
-    if (lane == 0) { misc[4] = (unsigned int)cnp; misc[5] = (unsigned int)cnr; misc[6] = cdone ? 1u : 0u; }
-}
-
 // E3 as a function of its own: the pivot rows of the new group (group index ng, npiv rows listed in grow) at their start
 // state for every word to the right of w, written to PRO.  Not inlined, so that its registers are allocated on their own
 // (the kernel sits at its 128-VGPR cap: inside it, more than one word in flight per wave went to scratch and ran slower).
@@ -919,8 +838,17 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         }
 #pragma unroll
                         for (int i = 0; i < HB; ++i) {
-                            if (v[i] != 0ull) {
-                                const int pos = atomicAdd(&misc[7], 1);
+                            // list positions: ONE LDS atomic per wave and row slot (the wave's entries are consecutive) -- one per
+                            // entry serialised up to 16 k atomics on a single LDS word per panel
+                            const bool nz = v[i] != 0ull;
+                            const unsigned long long bal = __ballot(nz);
+                            int base = 0;
+                            if (bal) {  // uniform
+                                if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(&misc[7], __popcll(bal));
+                                base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(bal));
+                            }
+                            if (nz) {
+                                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
                                 if (pos < CAP) {
                                     Lpw[pos] = v[i];
                                     Lid[pos] = (unsigned int)((int)threadIdx.x + (k0 + i) * NT) | (((usedmask >> (k0 + i)) & 1u) << 31);
@@ -932,16 +860,82 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     }
                 }
                 __syncthreads();
+                OSDL_TICK(22);  // (E1c: panel words brought up to date and listed)
                 const int nnz = misc[7];
                 if (nnz <= CAP) {  // uniform
                     compact = true;
-                    if (wave == 0) {
+                    if (nnz > 1024) {
+                        // ---- long lists (1025 .. 2048 entries): ALL sixteen waves, two entries per lane in registers, one barrier
+                        // per pivot (every wave publishes its lowest candidate column and the entry that has it, double-buffered by
+                        // parity; the lowest column, lowest wave wins).  ~60 instructions and a barrier per pivot against ~450 from
+                        // one wave walking the list in LDS (osdl_e2_compact_lds: 24 M cycles per elimination, 90 M in the slowest).
+                        unsigned long long cp[2], ct[2];
+                        unsigned int cu = 0u;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int pos = s2 * NT + (int)threadIdx.x;
+                            cp[s2] = pos < nnz ? Lpw[pos] : 0ull;
+                            ct[s2] = 0ull;
+                            if (pos < nnz && (Lid[pos] >> 31)) cu |= 1u << s2;
+                        }
+                        int cnp = 0, cnr = nrank;
+                        bool cdone = done;
+#pragma clang loop unroll(disable)
+                        for (;;) {
+                            if (cnr >= P.rank) { cdone = true; break; }
+                            const unsigned long long cand = (((cu & 1u) ? 0ull : cp[0]) | ((cu & 2u) ? 0ull : cp[1])) & vmask;
+                            const unsigned int lb = osd_ffs64_or_64(cand);
+                            const unsigned int wk = osd_wave_min_u32((lb << 6) | (unsigned int)lane);  // wave-uniform
+                            const int colw = (int)(wk >> 6), firstl = (int)(wk & 63u);
+                            const int kb = ((((cp[0] >> (colw & 63)) & 1ull) != 0ull) && ((cu & 1u) == 0u)) ? 0 : 1;
+                            if (lane == firstl) {
+                                pcol[par * OSDL_NW + wave] = (unsigned int)(colw < 64 ? colw : 64);
+                                pbuf[(size_t)(par * OSDL_NW + wave) * 2 + 0] = kb ? cp[1] : cp[0];
+                                pbuf[(size_t)(par * OSDL_NW + wave) * 2 + 1] = kb ? ct[1] : ct[0];
+                            }
+                            __syncthreads();
+                            int mincol = 64, wv = 0;
+#pragma unroll
+                            for (int q = OSDL_NW - 1; q >= 0; --q) {
+                                const int pc = (int)pcol[par * OSDL_NW + q];
+                                if (pc <= mincol) { mincol = pc; wv = q; }
+                            }
+                            if (mincol >= 64) { par ^= 1; break; }
+                            const unsigned long long pw_p = pbuf[(size_t)(par * OSDL_NW + wv) * 2 + 0];
+                            const unsigned long long t_p = pbuf[(size_t)(par * OSDL_NW + wv) * 2 + 1];
+                            const unsigned long long tq = t_p ^ (1ull << cnp);
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                const unsigned long long mm = (unsigned long long)((long long)(cp[s2] << (63 - mincol)) >> 63);
+                                cp[s2] ^= pw_p & mm;
+                                ct[s2] ^= tq & mm;
+                            }
+                            if (wave == wv && lane == firstl) {  // the pivot row itself is put back
+                                if (kb) { cp[1] = pw_p; ct[1] = t_p; } else { cp[0] = pw_p; ct[0] = t_p; }
+                                cu |= 1u << kb;
+                                Lpiv[cnp] = (unsigned int)(kb * NT + (int)threadIdx.x);
+                                Lpiv[64 + cnp] = (unsigned int)mincol;
+                            }
+                            ++cnp;
+                            ++cnr;
+                            par ^= 1;
+                        }
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int pos = s2 * NT + (int)threadIdx.x;
+                            if (pos < nnz) {
+                                Lpw[pos] = cp[s2];
+                                Lt[pos] = ct[s2];
+                            }
+                        }
+                        if (tid == 0) { misc[4] = cnp; misc[5] = cnr; misc[6] = cdone ? 1 : 0; }
+                    } else if (wave == 0) {
                         const unsigned int la = (unsigned int)(size_t)(osdl_lds_w64)Lpw, ma = (unsigned int)(size_t)(osdl_lds_w32)misc;
                         if (nnz <= 256) osdl_e2_compact_wave<4>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
-                        else if (nnz <= 1024) osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
-                        else osdl_e2_compact_lds(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                        else osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
                     }
                     __syncthreads();
+                    OSDL_TICK(23);  // (E2c: the pivot search on the list, one wave)
                     npiv = misc[4];
                     nrank = misc[5];
                     done = misc[6] != 0;
@@ -1659,11 +1653,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         if (P.dbg && slot_id < 500 && tid == 0) {  // every elimination of the launch: total ticks, then the stamps 0..12 + 17..20
             long long tot = 0;
             for (int i = 0; i < 7; ++i) tot += tk[i];
-            tot += tk[17] + tk[18] + tk[19] + tk[20] + tk[21];
+            tot += tk[17] + tk[18] + tk[19] + tk[20] + tk[21] + tk[22] + tk[23];
             long long* d = P.dbg + 32 + slot_id * 16;
             d[0] = tot;
             for (int i = 0; i < 11; ++i) d[1 + i] = tk[i];
-            d[12] = tk[17] + tk[21]; d[13] = tk[18]; d[14] = tk[19]; d[15] = tk[21];
+            d[12] = tk[17] + tk[21]; d[13] = tk[22]; d[14] = tk[23]; d[15] = tk[21];
         }
 #endif
 #undef OSDL_TICK
