@@ -184,7 +184,8 @@ typedef const unsigned long long* osdl_lds_ptr;
 // (list position of pivot q, then its column), new-pivot bits [1024] u16 (bit k of entry t: row t + 1024 k).
 typedef volatile __attribute__((address_space(3))) unsigned long long* osdl_lds_w64;
 typedef volatile __attribute__((address_space(3))) unsigned int* osdl_lds_w32;
-constexpr int OSDL_E2C_CAP = 2048;
+constexpr int OSDL_E2C_CAP = 2048;   // longest panel list (rows); beyond it the all-rows form runs (4096: measured, no gain)
+constexpr int OSDL_MW_MIN = 1024;    // lists longer than this are searched by all sixteen waves (512 / 256: measured, 6 % slower)
 
 template <int CR>
 __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_addr, unsigned int misc_addr, int nnz,
@@ -864,15 +865,16 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 const int nnz = misc[7];
                 if (nnz <= CAP) {  // uniform
                     compact = true;
-                    if (nnz > 1024) {
-                        // ---- long lists (1025 .. 2048 entries): ALL sixteen waves, two entries per lane in registers, one barrier
+                    if (nnz > OSDL_MW_MIN) {
+                        // ---- long lists (1025 .. OSDL_E2C_CAP entries): ALL sixteen waves, CAP / 1024 entries per lane in registers, one barrier
                         // per pivot (every wave publishes its lowest candidate column and the entry that has it, double-buffered by
                         // parity; the lowest column, lowest wave wins).  ~60 instructions and a barrier per pivot against ~450 from
                         // one wave walking the list in LDS (osdl_e2_compact_lds: 24 M cycles per elimination, 90 M in the slowest).
-                        unsigned long long cp[2], ct[2];
+                        constexpr int MWR = OSDL_E2C_CAP / OSDL_NT;  // entries per lane
+                        unsigned long long cp[MWR], ct[MWR];
                         unsigned int cu = 0u;
 #pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
+                        for (int s2 = 0; s2 < MWR; ++s2) {
                             const int pos = s2 * NT + (int)threadIdx.x;
                             cp[s2] = pos < nnz ? Lpw[pos] : 0ull;
                             ct[s2] = 0ull;
@@ -883,15 +885,26 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #pragma clang loop unroll(disable)
                         for (;;) {
                             if (cnr >= P.rank) { cdone = true; break; }
-                            const unsigned long long cand = (((cu & 1u) ? 0ull : cp[0]) | ((cu & 2u) ? 0ull : cp[1])) & vmask;
+                            unsigned long long cand = 0ull;
+#pragma unroll
+                            for (int s2 = 0; s2 < MWR; ++s2) cand |= ((cu >> s2) & 1u) ? 0ull : cp[s2];
+                            cand &= vmask;
                             const unsigned int lb = osd_ffs64_or_64(cand);
                             const unsigned int wk = osd_wave_min_u32((lb << 6) | (unsigned int)lane);  // wave-uniform
                             const int colw = (int)(wk >> 6), firstl = (int)(wk & 63u);
-                            const int kb = ((((cp[0] >> (colw & 63)) & 1ull) != 0ull) && ((cu & 1u) == 0u)) ? 0 : 1;
+                            int kb = 0;
+                            unsigned long long a = 0ull, c = 0ull;
+#pragma unroll
+                            for (int s2 = MWR - 1; s2 >= 0; --s2) {
+                                const bool hit = (((cp[s2] >> (colw & 63)) & 1ull) != 0ull) && (((cu >> s2) & 1u) == 0u);
+                                kb = hit ? s2 : kb;
+                                a = hit ? cp[s2] : a;
+                                c = hit ? ct[s2] : c;
+                            }
                             if (lane == firstl) {
                                 pcol[par * OSDL_NW + wave] = (unsigned int)(colw < 64 ? colw : 64);
-                                pbuf[(size_t)(par * OSDL_NW + wave) * 2 + 0] = kb ? cp[1] : cp[0];
-                                pbuf[(size_t)(par * OSDL_NW + wave) * 2 + 1] = kb ? ct[1] : ct[0];
+                                pbuf[(size_t)(par * OSDL_NW + wave) * 2 + 0] = a;
+                                pbuf[(size_t)(par * OSDL_NW + wave) * 2 + 1] = c;
                             }
                             __syncthreads();
                             int mincol = 64, wv = 0;
@@ -905,13 +918,15 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             const unsigned long long t_p = pbuf[(size_t)(par * OSDL_NW + wv) * 2 + 1];
                             const unsigned long long tq = t_p ^ (1ull << cnp);
 #pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) {
+                            for (int s2 = 0; s2 < MWR; ++s2) {
                                 const unsigned long long mm = (unsigned long long)((long long)(cp[s2] << (63 - mincol)) >> 63);
                                 cp[s2] ^= pw_p & mm;
                                 ct[s2] ^= tq & mm;
                             }
                             if (wave == wv && lane == firstl) {  // the pivot row itself is put back
-                                if (kb) { cp[1] = pw_p; ct[1] = t_p; } else { cp[0] = pw_p; ct[0] = t_p; }
+#pragma unroll
+                                for (int s2 = 0; s2 < MWR; ++s2)
+                                    if (s2 == kb) { cp[s2] = pw_p; ct[s2] = t_p; }
                                 cu |= 1u << kb;
                                 Lpiv[cnp] = (unsigned int)(kb * NT + (int)threadIdx.x);
                                 Lpiv[64 + cnp] = (unsigned int)mincol;
@@ -921,7 +936,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             par ^= 1;
                         }
 #pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
+                        for (int s2 = 0; s2 < MWR; ++s2) {
                             const int pos = s2 * NT + (int)threadIdx.x;
                             if (pos < nnz) {
                                 Lpw[pos] = cp[s2];
