@@ -55,8 +55,9 @@ constexpr int OSDL_CW = 8;             // chunk width (words) of the apply pass
 constexpr int OSDL_K = 4;              // open (lazily applied) pivot groups
 constexpr int OSDL_G5 = 13;            // 5-bit fields of a 64-bit pivot mask in the apply pass (12 x 5 + 4)
 #ifndef OSDL_E3D
-#define OSDL_E3D 1   // words in flight per wave in E3 beyond the one being processed (measured: 3 and 4 are SLOWER, 42 -> 57 / 60 M
-                     // cycles per elimination -- E3 is bound by the gather rate of one CU, not by the latency of a round trip)
+#define OSDL_E3D 2   // words in flight per wave in E3 beyond the one being processed.  Round 3 measured 3 and 4 SLOWER (42 -> 57 / 60 M
+                     // cycles per elimination) -- with FLAT loads, whose waits also waited for every prefetch (see osdl_e3_materialise);
+                     // with global loads: 1 / 2 / 4 words give 8.09 / 8.16 / 8.07 k syndromes/s on l29k_ms_e15 (same box)
 #endif
 constexpr int OSDL_MAXSPAN = 16;       // max osd_e order, and max osd_cs order with fp64 (non-uniform channel) weights
 constexpr int OSDL_MAXSPAN_CS = 64;    // max osd_cs order with integer weights (uniform channel): as on the small path; the
@@ -275,7 +276,7 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
     const int wave = threadIdx.x >> 6;
     // The pointers arrive generic.  Left so, every access below is a FLAT instruction, which counts on the vector-memory AND the
     // LDS counter: the wait before a stage's first table write then waits for every row word requested for the LATER stages too,
-    // and the OSDL_E3D-deep prefetch is no prefetch (measured: E3 ... -> ... M cycles per elimination).  Named address spaces
+    // and the OSDL_E3D-deep prefetch is no prefetch (E3 34 -> 31 M cycles per elimination with the spaces named).  Named address spaces
     // give global_load / ds_read with their own counters.
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     typedef __attribute__((address_space(3))) int l_i32;
