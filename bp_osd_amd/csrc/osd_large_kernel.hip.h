@@ -523,6 +523,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         // ------------------------------------------------------- a9: blocked Gauss-Jordan, lazy groups
         unsigned int usedmask = 0u;  // bit k: my k-th row is a pivot row
         const bool gauss = P.osd_method != 3;  // OSD-0 / OSD-E: Gaussian elimination + back-substitution (see header)
+        unsigned int anymask = 0u;  // bit k: my k-th row has a non-zero combination mask in some OPEN group (kept as the groups are
+                                    // formed, so that neither E1c nor the apply pass's list build reads masks that are zero)
         unsigned int frozenmask = 0u;  // bit k: my k-th row takes no more updates (padding row, or a pivot row that an
                                        // apply pass has brought up to date -- gauss mode only)
 #pragma unroll
@@ -543,28 +545,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             // read nor written, and their masks are read here once instead of once per chunk.
             __syncthreads();  // U is free (the tables of the previous phase are no longer read)
             int* cnt = (int*)U;  // [RPT * NW + 1]
-            unsigned int touched = 0u;  // bit k: my k-th row takes part in this pass
-            {
-                const unsigned int ro = osdl_opaque((unsigned int)threadIdx.x * 8u);
-                // four rows' masks in flight together, frozen rows included (their masks are read and ignored): under a per-row
-                // `if (!frozen)` the compiler waits for each row's loads inside the branch, two round trips per row
-                constexpr int LB = RPT < 4 ? RPT : 4;
-#pragma unroll
-                for (int k0 = 0; k0 < RPT; k0 += LB) {
-                    unsigned long long any[LB];
-#pragma unroll
-                    for (int i = 0; i < LB; ++i) {
-                        any[i] = 0ull;
-#pragma unroll
-                        for (int g = 0; g < OSDL_K; ++g)
-                            if (g < ng) any[i] |= OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8);
-                    }
-                    if (LB == 4) asm volatile("" : "+v"(any[0]), "+v"(any[1]), "+v"(any[LB > 2 ? 2 : 0]), "+v"(any[LB > 3 ? 3 : 0]));
-#pragma unroll
-                    for (int i = 0; i < LB; ++i)
-                        if (any[i] != 0ull && ((frozenmask >> (k0 + i)) & 1u) == 0u) touched |= 1u << (k0 + i);
-                }
-            }
+            // (anymask is kept as the groups are formed: the list build used to read every row's masks in all open groups here)
+            const unsigned int touched = anymask & ~frozenmask;  // bit k: my k-th row takes part in this pass
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const unsigned long long bal = __ballot(((touched >> k) & 1u) != 0u);
@@ -753,6 +735,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             }
             __syncthreads();
             ng = 0;
+            anymask = 0u;  // no group is open: no masks
             if (gauss) frozenmask = padmask | usedmask;  // no group is open now: every pivot row found so far is complete
         };
 
@@ -798,8 +781,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 unsigned long long* PFW = (unsigned long long*)(Lnew + 1024);  // [64] by column: final panel word of the pivot there
                 unsigned long long* TF = PFW + 64;                             // [64] by column: its mask, own bit included
                 unsigned int* pcm = (unsigned int*)(TF + 64);                  // [2] pivot columns of this panel
+                unsigned short* Lany = (unsigned short*)(pcm + 2);             // [1024] bit k: row tid + 1024 k got a non-zero mask in the new group
                 if (tid == 0) { misc[7] = 0; pcm[0] = 0u; pcm[1] = 0u; }
                 Lnew[threadIdx.x] = 0;
+                Lany[threadIdx.x] = 0;
                 __syncthreads();  // tables, counter
                 unsigned int zmask = 0u;  // rows whose stored word is non-zero but whose up-to-date word is zero
                 const unsigned int skipmask = frozenmask | (jordan ? usedmask : 0u);  // rows that are not listed
@@ -820,7 +805,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         for (int g = 0; g < OSDL_K; ++g)
 #pragma unroll
                             for (int i = 0; i < HB; ++i)
-                                mk[g][i] = (g < ng && ((skipmask >> (k0 + i)) & 1u) == 0u) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8) : 0ull;
+                                mk[g][i] = (g < ng && (((anymask & ~skipmask) >> (k0 + i)) & 1u) != 0u) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8) : 0ull;
                         if (HB == 4)
                             asm volatile("" : "+v"(old[0]), "+v"(old[1]), "+v"(old[HB > 2 ? 2 : 0]), "+v"(old[HB > 3 ? 3 : 0]), "+v"(mk[0][0]), "+v"(mk[0][1]),
                                          "+v"(mk[0][HB > 2 ? 2 : 0]), "+v"(mk[0][HB > 3 ? 3 : 0]), "+v"(mk[1][0]), "+v"(mk[1][1]), "+v"(mk[1][HB > 2 ? 2 : 0]),
@@ -986,9 +971,15 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                 atomicOr(&pcm[col >> 5], 1u << (col & 31));
                             }
                         }
+                        for (int i = threadIdx.x; i < nnz; i += NT)
+                            if (Lt[i] != 0ull) {
+                                const int r = (int)(Lid[i] & 0x7fffffffu);
+                                atomicOr((unsigned int*)(Lany + ((r & (NT - 1)) & ~1)), (1u << (r / NT)) << (16 * (r & 1)));
+                            }
                         __syncthreads();  // zero masks before the list rows' masks; new-pivot bits; fix-up tables
                         for (int i = threadIdx.x; i < nnz; i += NT) TmO[(size_t)ng * MRL + (Lid[i] & 0x7fffffffu)] = Lt[i];
                         usedmask |= (unsigned int)Lnew[threadIdx.x];
+                        anymask |= (unsigned int)Lany[threadIdx.x];
                     }
                     if (jordan && usedbefore != 0u) {
                         // ---- Jordan fix-up: a pivot row u of an earlier panel, brought up to date by E1, must lose its ones in
@@ -1033,7 +1024,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                     tm ^= TF[c];
                                 }
                                 if (v[i] != old[i]) OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + (k0 + i) * NT * 8) = v[i];
-                                if (tm != 0ull) OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + (k0 + i) * NT * 8) = tm;
+                                if (tm != 0ull) {
+                                    OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + (k0 + i) * NT * 8) = tm;
+                                    anymask |= 1u << (k0 + i);
+                                }
                             }
                         }
                     }
@@ -1150,7 +1144,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 if (npiv > 0) {
 #pragma unroll
                     for (int k = 0; k < RPT; ++k)
-                        if (((frozenmask >> k) & 1u) == 0u) OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = t[k];
+                        if (((frozenmask >> k) & 1u) == 0u) {
+                            OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = t[k];
+                            if (t[k] != 0ull) anymask |= 1u << k;
+                        }
                 }
             }
             }  // ======== end of the all-rows form
