@@ -30,9 +30,13 @@
 // the (partly reduced) pivot rows from the last pivot word to the first.
 // OSD-CS weighs all k' single candidates, i.e. needs every non-pivot column reduced: it keeps Gauss-Jordan.
 // E2c (round 2): when few rows have a non-zero panel word -- the usual case on sparse codes -- those words go to an LDS list
-// and ONE wave runs the pivot loop on it without a barrier per pivot (osdl_e2_compact_wave / _lds below); Gauss-Jordan lists
+// and ONE wave runs the pivot loop on it without a barrier per pivot (osdl_e2_compact_wave below; up to 1024 rows); lists of
+// 1025-2048 rows are searched by all sixteen waves, two entries per lane, one barrier per pivot (round 4).  Gauss-Jordan lists
 // the unused rows only and brings the earlier pivot rows up to date afterwards in one step per row (Jordan fix-up).  The
 // all-rows E2 above remains for longer lists.  The apply pass (AP) walks only the rows that some open group touches.
+// Round 4 (Gaussian mode): every group KEEPS the rows E3 materialises for it (PRO holds all groups), and the
+// back-substitution reads them from there, coalesced, instead of gathering rows of M (pmask: which pivots of its own group
+// a pivot row absorbed).
 // Earlier words never change: a row that becomes a pivot later has zeros in every earlier non-pivot
 // column, so the reduced columns the sweep reads are final as soon as their word is stored.
 // Sort: bitonic network over a global key array (n up to 32767).  Sweep: per-wave ballots over the
@@ -40,7 +44,7 @@
 // Non-uniform channel (P.cost != null: channel_probs vector, update_channel_probs, per-shot two-valued channel): candidate
 // weights are fp64 sums of log(1/p_i) over the candidate's set bits accumulated in ASCENDING ORIGINAL BIT INDEX -- the
 // reference's order -- one candidate per lane, exactly as in osd_kernel.hip.h; see the "fp64 weights" block of the sweep.
-// Limits: m <= 16384, n <= 32767, osd_e order <= 16, osd_cs order <= 64 (<= 16 with a non-uniform channel).
+// Limits: m <= 16384, n <= 32767, osd_e order <= 16, osd_cs order <= 64 (any channel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         // ---- long lists (1025 .. OSDL_E2C_CAP entries): ALL sixteen waves, CAP / 1024 entries per lane in registers, one barrier
                         // per pivot (every wave publishes its lowest candidate column and the entry that has it, double-buffered by
                         // parity; the lowest column, lowest wave wins).  ~60 instructions and a barrier per pivot against ~450 from
-                        // one wave walking the list in LDS (osdl_e2_compact_lds: 24 M cycles per elimination, 90 M in the slowest).
+                        // one wave walking the list in LDS (rounds 2-3's form: 90 M cycles in the slowest elimination of an L29k batch).
                         constexpr int MWR = OSDL_E2C_CAP / OSDL_NT;  // entries per lane
                         unsigned long long cp[MWR], ct[MWR];
                         unsigned int cu = 0u;
