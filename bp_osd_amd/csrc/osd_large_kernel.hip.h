@@ -936,7 +936,9 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         if (tid == 0) { misc[4] = cnp; misc[5] = cnr; misc[6] = cdone ? 1 : 0; }
                     } else if (wave == 0) {
                         const unsigned int la = (unsigned int)(size_t)(osdl_lds_w64)Lpw, ma = (unsigned int)(size_t)(osdl_lds_w32)misc;
-                        if (nnz <= 256) osdl_e2_compact_wave<4>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                        if (nnz <= 128) osdl_e2_compact_wave<2>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                        else if (nnz <= 256) osdl_e2_compact_wave<4>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                        else if (nnz <= 512) osdl_e2_compact_wave<8>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
                         else osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
                     }
                     __syncthreads();
