@@ -270,6 +270,91 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
     if (lane == 0) { misc[4] = (unsigned int)cnp; misc[5] = (unsigned int)cnr; misc[6] = cdone ? 1u : 0u; }
 }
 
+// a8: bitonic network on (key, index), blocks of 8192 elements staged through LDS (96 KB): every exchange whose partners are
+// less than 8192 apart runs on LDS (114 of the 120 passes at NS = 32768); the three passes that cross blocks stay in the
+// workspace, eight exchanges per thread requested together.  All in the workspace it was 120 passes of sixteen exchanges per
+// thread, each waiting for its own loads: 7 M cycles per elimination, now 2.3 M.  A function of its own (named address
+// spaces, registers of its own): inlined, the same code left the sort faster and the apply pass's row walk 50 % slower -- the
+// kernel sits at its 128-VGPR cap and every change of its body moves the allocation of the hot loop.
+__device__ __attribute__((noinline)) void osdl_sort(unsigned long long* keys_, int* kidx_, unsigned int lds_addr, int NS) {
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    typedef __attribute__((address_space(1))) int g_i32;
+    typedef __attribute__((address_space(3))) unsigned long long l_u64;
+    typedef __attribute__((address_space(3))) int l_i32;
+    g_u64* keys = (g_u64*)keys_;
+    g_i32* kidx = (g_i32*)kidx_;
+    const int tid = threadIdx.x;
+    constexpr int NT = OSDL_NT;
+    const int BS = NS < 8192 ? NS : 8192;
+    l_u64* lk = (l_u64*)(size_t)lds_addr;                 // [BS]
+    l_i32* li = (l_i32*)(size_t)(lds_addr + 8192u * 8u);  // [BS]
+    auto lds_passes = [&](int base, int k, int jstart) {
+        for (int j = jstart; j > 0; j >>= 1) {
+            for (int t = tid; t < (BS >> 1); t += NT) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = (((base + lo) & k) == 0);
+                const unsigned long long ka = lk[lo], kb = lk[hi];
+                const int ia = li[lo], ib = li[hi];
+                const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+                if (a_gt_b == up) {
+                    lk[lo] = kb; lk[hi] = ka;
+                    li[lo] = ib; li[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    auto block_in = [&](int base) {
+        for (int i = tid; i < BS; i += NT) { lk[i] = keys[base + i]; li[i] = kidx[base + i]; }
+        __syncthreads();
+    };
+    auto block_out = [&](int base) {
+        for (int i = tid; i < BS; i += NT) { keys[base + i] = lk[i]; kidx[base + i] = li[i]; }
+        __syncthreads();
+    };
+    for (int base = 0; base < NS; base += BS) {
+        block_in(base);
+        for (int k = 2; k <= BS; k <<= 1) lds_passes(base, k, k >> 1);
+        block_out(base);
+    }
+    for (int k = BS << 1; k <= NS; k <<= 1) {
+        for (int j = k >> 1; j >= BS; j >>= 1) {
+            constexpr int SB = 8;  // (NS / 2 is a multiple of 8 * 1024 here)
+            for (int t0 = tid; t0 < (NS >> 1); t0 += NT * SB) {
+                unsigned long long ka[SB], kb[SB];
+                int ia[SB], ib[SB];
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int t = t0 + i * NT;
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int hi = lo | j;
+                    ka[i] = keys[lo]; kb[i] = keys[hi];
+                    ia[i] = kidx[lo]; ib[i] = kidx[hi];
+                }
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int t = t0 + i * NT;
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int hi = lo | j;
+                    const bool up = ((lo & k) == 0);
+                    const bool a_gt_b = (ka[i] > kb[i]) || (ka[i] == kb[i] && ia[i] > ib[i]);
+                    if (a_gt_b == up) {
+                        keys[lo] = kb[i]; keys[hi] = ka[i];
+                        kidx[lo] = ib[i]; kidx[hi] = ia[i];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int base = 0; base < NS; base += BS) {
+            block_in(base);
+            lds_passes(base, k, BS >> 1);
+            block_out(base);
+        }
+    }
+}
+
 // E3 as a function of its own: the pivot rows of the new group (group index ng, npiv rows listed in grow) at their start
 // state for every word to the right of w, written to PRO.  Not inlined, so that its registers are allocated on their own
 // (the kernel sits at its 128-VGPR cap: inside it, more than one word in flight per wave went to scratch and ran slower).
@@ -451,23 +536,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         if (am64)
             for (int i = tid; i < MRL; i += NT) am64[i] = 0ull;
         __syncthreads();
-        for (int k = 2; k <= NS; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (NS >> 1); t += NT) {
-                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const int hi = lo | j;
-                    const bool up = ((lo & k) == 0);
-                    const unsigned long long ka = keys[lo], kb = keys[hi];
-                    const int ia = kidx[lo], ib = kidx[hi];
-                    const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
-                    if (a_gt_b == up) {
-                        keys[lo] = kb; keys[hi] = ka;
-                        kidx[lo] = ib; kidx[hi] = ia;
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        osdl_sort(keys, kidx, (unsigned int)(size_t)(osdl_lds_w64)U, NS);
         if (P.tie_policy == 1) {
             for (int i = tid; i < n; i += NT) kidx[i] = n - 1 - kidx[i];
             __syncthreads();
