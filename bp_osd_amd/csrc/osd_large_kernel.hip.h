@@ -355,6 +355,60 @@ __device__ __attribute__((noinline)) void osdl_sort(unsigned long long* keys_, i
     }
 }
 
+// Build "my rows" of the permuted matrix (the matrix is zero on entry).  A row's column positions are fetched together (its
+// edges' bit indices, then their sorted positions: two round trips), the bits that share a word are combined in registers and
+// every word is written once.  As first written each edge was a chain of three dependent round trips (bit index, position,
+// read-modify-write of the word), 33 per row, 528 per thread.  A function of its own (see osdl_sort).
+template <int RPT>
+__device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_, const int* rp_, const int* ci_, const int* inv_, const uint8_t* synd_,
+                                                          long long s, int m, int W, int MRL) {
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    typedef __attribute__((address_space(1))) int g_i32;
+    typedef __attribute__((address_space(1))) uint8_t g_u8;
+    g_u64* M = (g_u64*)M_;
+    const g_i32* rp = (const g_i32*)rp_;
+    const g_i32* ci = (const g_i32*)ci_;
+    const g_i32* inv = (const g_i32*)inv_;
+    const g_u8* synd = (const g_u8*)synd_;
+    const int tid = threadIdx.x;
+    constexpr int NT = OSDL_NT;
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < RPT; ++k) {
+        const int r = tid + k * NT;
+        if (r < m) {
+            constexpr int CH = 12;  // edges per batch (the degree of a check of the codes this path serves; more: further batches)
+            const int e0 = rp[r], e1 = rp[r + 1];
+            const bool sb = (synd[(size_t)s * m + r] & 1) != 0;
+            for (int eb = e0; eb < e1 || eb == e0; eb += CH) {
+                int jj[CH + 1];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) jj[i] = (eb + i < e1) ? ci[eb + i] : -1;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) jj[i] = (jj[i] >= 0) ? inv[jj[i]] : -1;
+                jj[CH] = (eb == e0 && sb) ? (W - 1) * 64 + 63 : -1;  // the syndrome column, with the first batch
+#pragma unroll
+                for (int i = 0; i <= CH; ++i) {
+                    if (jj[i] < 0) continue;
+                    unsigned long long word = 0ull;
+                    bool first = true;  // is i the first entry of its word in this batch?
+#pragma unroll
+                    for (int i2 = 0; i2 <= CH; ++i2) {
+                        const bool same = jj[i2] >= 0 && (jj[i2] >> 6) == (jj[i] >> 6);
+                        if (same) word |= 1ull << (jj[i2] & 63);
+                        if (same && i2 < i) first = false;
+                    }
+                    if (first) {
+                        g_u64* dst = M + (size_t)(jj[i] >> 6) * MRL + r;  // only the owner touches row r
+                        if (eb == e0) *dst = word;    // (the matrix is zero: no read)
+                        else *dst |= word;            // a later batch may meet a word of an earlier one
+                    }
+                }
+                if (e1 == e0) break;
+            }
+        }
+    }
+}
+
 // E3 as a function of its own: the pivot rows of the new group (group index ng, npiv rows listed in grow) at their start
 // state for every word to the right of w, written to PRO.  Not inlined, so that its registers are allocated on their own
 // (the kernel sits at its 128-VGPR cap: inside it, more than one word in flight per wave went to scratch and ran slower).
@@ -551,44 +605,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, M + (size_t)x * MRL, ro + k * NT * 8) = 0ull;
         }
         __syncthreads();
-        // A row's column positions are fetched together (its edges' bit indices, then their sorted positions: two round trips),
-        // the bits that share a word are combined in registers and every word is written once.  As first written each edge was a
-        // chain of three dependent round trips (bit index, position, read-modify-write of the word), 33 per row, 528 per thread.
-#pragma clang loop unroll(disable)
-        for (int k = 0; k < RPT; ++k) {
-            const int r = tid + k * NT;
-            if (r < m) {
-                constexpr int CH = 12;  // edges per batch (the degree of a check of the codes this path serves; more: further batches)
-                const int e0 = P.rp[r], e1 = P.rp[r + 1];
-                const bool sb = (P.synd[(size_t)s * m + r] & 1) != 0;
-                for (int eb = e0; eb < e1 || eb == e0; eb += CH) {
-                    int jj[CH + 1];
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) jj[i] = (eb + i < e1) ? P.ci[eb + i] : -1;
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) jj[i] = (jj[i] >= 0) ? inv[jj[i]] : -1;
-                    jj[CH] = (eb == e0 && sb) ? (W - 1) * 64 + 63 : -1;  // the syndrome column, with the first batch
-#pragma unroll
-                    for (int i = 0; i <= CH; ++i) {
-                        if (jj[i] < 0) continue;
-                        unsigned long long word = 0ull;
-                        bool first = true;  // is i the first entry of its word in this batch?
-#pragma unroll
-                        for (int i2 = 0; i2 <= CH; ++i2) {
-                            const bool same = jj[i2] >= 0 && (jj[i2] >> 6) == (jj[i] >> 6);
-                            if (same) word |= 1ull << (jj[i2] & 63);
-                            if (same && i2 < i) first = false;
-                        }
-                        if (first) {
-                            unsigned long long* dst = M + (size_t)(jj[i] >> 6) * MRL + r;  // only the owner touches row r
-                            if (eb == e0) *dst = word;    // (the matrix is zero: no read)
-                            else *dst |= word;            // a later batch may meet a word of an earlier one
-                        }
-                    }
-                    if (e1 == e0) break;
-                }
-            }
-        }
+        osdl_build_rows<RPT>(M, P.rp, P.ci, inv, P.synd, s, m, W, (int)MRL);
         if (tid < 2 * OSDL_NW) pcol[tid] = 64u;
         __syncthreads();
 
