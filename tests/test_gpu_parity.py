@@ -1018,7 +1018,12 @@ def test_large_path_random_irregular_codes(gpu_ready):
         g = BpOsdDecoder(H, **kw)
         c = OracleDecoder(H, **kw)
         assert g.rank == c.rank
-        _compare_exact(_gpu_decode(g, syn), c.decode_batch(syn))
+        ref = c.decode_batch(syn)
+        _compare_exact(_gpu_decode(g, syn), ref)
+        if g.bp_kernel_info()["kernel"] == "bp_large_kernel":  # the other min-sum form too (32-bit flags beyond check degree 12)
+            g.set_bp_variant(63)
+            _compare_exact(_gpu_decode(g, syn), ref)
+            g.set_bp_variant(0)
         mats.append(H)
     # product-sum through the HBM BP kernel (trial 2's matrix) and through the mid-size LDS shape (trial 3's): integer
     # outputs of converged shots, to the documented tolerance
