@@ -1,9 +1,15 @@
 """Build libbposd_mi355x.so in-tree with hipcc for gfx950 (no cmake, no JIT cache).
 
 One translation unit per kernel family (csrc/launch_*.hip) next to the C-ABI (csrc/bposd_capi.hip); the units compile in
-parallel and only the stale ones are rebuilt (objects under csrc/_obj/, git-ignored)."""
+parallel and only the stale ones are rebuilt (objects under csrc/_obj/, git-ignored).
+
+Diagnostic / A-B builds (BPOSD_EXTRA_FLAGS="-DBPOSD_OSD_DIAG ...") never touch the product library: their objects go to
+csrc/_obj_<hash of the flags>/ and the library to bp_osd_amd/_variants/libbposd_mi355x_<hash>.so (or $BPOSD_LIB_OUT); load
+one with BPOSD_LIB=<path>.  A file lock serialises concurrent builders (two torchrun ranks on a stale tree)."""
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import re
 import shutil
@@ -18,6 +24,10 @@ SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 PUBLIC_HEADER = os.path.join(_HERE, "..", "include", "bposd_mi355x.h")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-pthread"]
 EXTRA = os.environ.get("BPOSD_EXTRA_FLAGS", "").split()
+if EXTRA:  # a build with extra flags is a different library: objects and output of its own
+    _TAG = hashlib.sha1(" ".join(EXTRA).encode()).hexdigest()[:10]
+    OBJ = os.path.join(CSRC, "_obj_" + _TAG)
+    LIB = os.environ.get("BPOSD_LIB_OUT") or os.path.join(_HERE, "_variants", f"libbposd_mi355x_{_TAG}.so")
 
 
 def _deps(path: str, seen=None) -> set:
@@ -44,14 +54,23 @@ def build_library(force: bool = False, verbose: bool = False, jobs: int | None =
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in SOURCES]
     alldeps = set().union(*[_deps(s) for s in srcs]) | {__file__}
-    if not force and not EXTRA and not _stale(LIB, alldeps):
+    if not force and not _stale(LIB, alldeps):
         return LIB  # (also the case on the GPU box: the built library travels with the snapshot, the objects do not)
-    todo = [(s, o) for s, o in zip(srcs, objs) if force or EXTRA or _stale(o, _deps(s) | {__file__})]
     if not os.path.exists(hipcc):
         if os.path.exists(LIB):
             return LIB  # prebuilt .so travelled with the snapshot
         raise RuntimeError("hipcc not found and libbposd_mi355x.so has not been built")
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)  # one builder at a time per object directory
+        if not force and not _stale(LIB, alldeps):
+            return LIB  # another process built it while this one waited
+        return _build_locked(hipcc, srcs, objs, force, verbose, jobs)
+
+
+def _build_locked(hipcc, srcs, objs, force, verbose, jobs) -> str:
+    todo = [(s, o) for s, o in zip(srcs, objs) if force or _stale(o, _deps(s) | {__file__})]
 
     def compile_one(so):
         cmd = [hipcc] + CFLAGS + EXTRA + ["-c", so[0], "-o", so[1]]

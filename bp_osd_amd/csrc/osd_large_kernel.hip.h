@@ -192,9 +192,22 @@ typedef volatile __attribute__((address_space(3))) unsigned int* osdl_lds_w32;
 constexpr int OSDL_E2C_CAP = 2048;   // longest panel list (rows); beyond it the all-rows form runs (4096: measured, no gain)
 constexpr int OSDL_MW_MIN = 1024;    // lists longer than this are searched by all sixteen waves (512 / 256: measured, 6 % slower)
 
+// Which ROW becomes the pivot of a column is free (the pivot SET, hence every output, does not depend on it -- SURVEY.md
+// Appendix A.4: upstream takes the lowest-weight row "only" to limit fill-in).  Round 5: among the candidates of a column the
+// row that has absorbed the FEWEST pivot rows so far wins -- key (absorbed << 14) | row, unique, so the choice no longer
+// depends on the order in which LDS atomics listed the rows.  "Absorbed" = sum over the closed panels of popcount(the row's
+// combination mask in that panel), kept for unused rows in rowpos[] as -1 - count (a used row holds its pivot position there,
+// >= 0), plus popcount(mask so far) inside the panel.  CPU model of L29k eliminations (tools/fillin_sim.c, policy 6 against 0):
+// row additions 348 k -> 205 k and 190 k -> 174 k, changed row-words 22.3 M -> 7.7 M and 9.9 M -> 5.4 M, longest panel list
+// 1199 -> 669 -- within 15 % of choosing by the exact remaining row weight (policy 1), which the lazy elimination cannot know.
+#ifndef OSDL_PIVOT_LIGHT
+#define OSDL_PIVOT_LIGHT 1
+#endif
+constexpr unsigned int OSDL_CNT_MAX = 16383u - 64u;  // stored counts saturate here: count + popcount(mask) stays below 2^14
+
 template <int CR>
 __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_addr, unsigned int misc_addr, int nnz,
-                                                              unsigned long long vmask, int rank, int nrank, int done_in) {
+                                                              unsigned long long vmask, int rank, int nrank, int done_in, int* rowpos_) {
     constexpr int CAP = OSDL_E2C_CAP;
     const int lane = threadIdx.x & 63;
     osdl_lds_w64 Lpw = (osdl_lds_w64)(size_t)lpw_addr;
@@ -202,8 +215,25 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
     osdl_lds_w32 Lid = (osdl_lds_w32)(Lt + CAP);
     osdl_lds_w32 Lpiv = Lid + CAP;
     osdl_lds_w32 misc = (osdl_lds_w32)(size_t)misc_addr;
+    typedef __attribute__((address_space(1))) int g_i32;
+    g_i32* rowpos = (g_i32*)rowpos_;
     unsigned long long cp[CR], ct[CR];
     unsigned int cu = 0u;  // bit s: my s-th entry is a pivot row
+#if OSDL_PIVOT_LIGHT
+    unsigned int key0[CR];  // (pivot rows absorbed in earlier panels << 14) | row
+#pragma unroll
+    for (int s2 = 0; s2 < CR; ++s2) {
+        const int pos = s2 * 64 + lane;
+        key0[s2] = pos < nnz ? (Lid[pos] & 0x3fffu) : 0u;
+    }
+    {
+        int rp[CR];  // the CR requests are in flight together
+#pragma unroll
+        for (int s2 = 0; s2 < CR; ++s2) rp[s2] = rowpos[key0[s2]];
+#pragma unroll
+        for (int s2 = 0; s2 < CR; ++s2) key0[s2] |= (rp[s2] < 0 ? (unsigned int)(-1 - rp[s2]) : 0u) << 14;
+    }
+#endif
 #pragma unroll
     for (int s2 = 0; s2 < CR; ++s2) {
         const int pos = s2 * 64 + lane;
@@ -224,10 +254,25 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
         const unsigned int wk = osd_wave_min_u32((lb << 6) | (unsigned int)lane);  // wave-uniform
         const int col = (int)(wk >> 6);
         if (col >= 64) break;
-        const int first = (int)(wk & 63u);
         // every lane picks "its" entry with a one in the column (only the winning lane's pick is read)
         int kb = 0;
         unsigned long long a = 0ull, c = 0ull;
+#if OSDL_PIVOT_LIGHT
+        unsigned int bk = ~0u;  // the lane's lightest candidate: fewest absorbed pivot rows, then lowest row
+#pragma unroll
+        for (int s2 = CR - 1; s2 >= 0; --s2) {
+            const bool hit = (((cp[s2] >> col) & 1ull) != 0ull) && (((cu >> s2) & 1u) == 0u);
+            const unsigned int key = key0[s2] + ((unsigned int)__popcll(ct[s2]) << 14);
+            const bool better = hit && key < bk;
+            bk = better ? key : bk;
+            kb = better ? s2 : kb;
+            a = better ? cp[s2] : a;
+            c = better ? ct[s2] : c;
+        }
+        const unsigned int wmin = osd_wave_min_u32(bk);  // (some lane has a hit: the column was proposed)
+        const int first = (int)__builtin_ctzll(__ballot(bk == wmin));
+#else
+        const int first = (int)(wk & 63u);
 #pragma unroll
         for (int s2 = CR - 1; s2 >= 0; --s2) {
             const bool hit = (((cp[s2] >> col) & 1ull) != 0ull) && (((cu >> s2) & 1u) == 0u);
@@ -235,6 +280,7 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
             a = hit ? cp[s2] : a;
             c = hit ? ct[s2] : c;
         }
+#endif
         const unsigned long long pw_p =
             ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a >> 32), first) << 32) |
             (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)a, first);
@@ -265,6 +311,13 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
         if (pos < nnz) {
             Lpw[pos] = cp[s2];
             Lt[pos] = ct[s2];
+#if OSDL_PIVOT_LIGHT
+            // the pivot rows this (still unused) row absorbed in the panel join its count
+            if (ct[s2] != 0ull && ((cu >> s2) & 1u) == 0u) {
+                const unsigned int cnt = (key0[s2] >> 14) + (unsigned int)__popcll(ct[s2]);
+                rowpos[key0[s2] & 0x3fffu] = -1 - (int)(cnt < OSDL_CNT_MAX ? cnt : OSDL_CNT_MAX);
+            }
+#endif
         }
     }
     if (lane == 0) { misc[4] = (unsigned int)cnp; misc[5] = (unsigned int)cnr; misc[6] = cdone ? 1u : 0u; }
@@ -949,12 +1002,21 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         constexpr int MWR = OSDL_E2C_CAP / OSDL_NT;  // entries per lane
                         unsigned long long cp[MWR], ct[MWR];
                         unsigned int cu = 0u;
+#if OSDL_PIVOT_LIGHT
+                        unsigned int key0[MWR];  // (pivot rows absorbed in earlier panels << 14) | row, see osdl_e2_compact_wave
+                        unsigned int* pkey = (unsigned int*)(Lany + 1024);  // [2][NW] the waves' lightest candidates, behind the lists
+#endif
 #pragma unroll
                         for (int s2 = 0; s2 < MWR; ++s2) {
                             const int pos = s2 * NT + (int)threadIdx.x;
                             cp[s2] = pos < nnz ? Lpw[pos] : 0ull;
                             ct[s2] = 0ull;
                             if (pos < nnz && (Lid[pos] >> 31)) cu |= 1u << s2;
+#if OSDL_PIVOT_LIGHT
+                            key0[s2] = pos < nnz ? (Lid[pos] & 0x3fffu) : 0u;
+                            const int rpv = rowpos[key0[s2]];
+                            key0[s2] |= (rpv < 0 ? (unsigned int)(-1 - rpv) : 0u) << 14;
+#endif
                         }
                         int cnp = 0, cnr = nrank;
                         bool cdone = done;
@@ -967,9 +1029,26 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             cand &= vmask;
                             const unsigned int lb = osd_ffs64_or_64(cand);
                             const unsigned int wk = osd_wave_min_u32((lb << 6) | (unsigned int)lane);  // wave-uniform
-                            const int colw = (int)(wk >> 6), firstl = (int)(wk & 63u);
+                            const int colw = (int)(wk >> 6);
                             int kb = 0;
                             unsigned long long a = 0ull, c = 0ull;
+#if OSDL_PIVOT_LIGHT
+                            unsigned int bk = ~0u;
+#pragma unroll
+                            for (int s2 = MWR - 1; s2 >= 0; --s2) {
+                                const bool hit = colw < 64 && (((cp[s2] >> (colw & 63)) & 1ull) != 0ull) && (((cu >> s2) & 1u) == 0u);
+                                const unsigned int key = key0[s2] + ((unsigned int)__popcll(ct[s2]) << 14);
+                                const bool better = hit && key < bk;
+                                bk = better ? key : bk;
+                                kb = better ? s2 : kb;
+                                a = better ? cp[s2] : a;
+                                c = better ? ct[s2] : c;
+                            }
+                            const unsigned int wmin = osd_wave_min_u32(bk);
+                            const int firstl = colw < 64 ? (int)__builtin_ctzll(__ballot(bk == wmin)) : 0;
+                            if (lane == firstl) pkey[par * OSDL_NW + wave] = wmin;
+#else
+                            const int firstl = (int)(wk & 63u);
 #pragma unroll
                             for (int s2 = MWR - 1; s2 >= 0; --s2) {
                                 const bool hit = (((cp[s2] >> (colw & 63)) & 1ull) != 0ull) && (((cu >> s2) & 1u) == 0u);
@@ -977,6 +1056,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                 a = hit ? cp[s2] : a;
                                 c = hit ? ct[s2] : c;
                             }
+#endif
                             if (lane == firstl) {
                                 pcol[par * OSDL_NW + wave] = (unsigned int)(colw < 64 ? colw : 64);
                                 pbuf[(size_t)(par * OSDL_NW + wave) * 2 + 0] = a;
@@ -984,11 +1064,21 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             }
                             __syncthreads();
                             int mincol = 64, wv = 0;
+#if OSDL_PIVOT_LIGHT
+                            unsigned int minkey = ~0u;  // lowest column, then the lightest row among the waves that propose it
+#pragma unroll
+                            for (int q = OSDL_NW - 1; q >= 0; --q) {
+                                const int pc = (int)pcol[par * OSDL_NW + q];
+                                const unsigned int pk = pkey[par * OSDL_NW + q];
+                                if (pc < mincol || (pc == mincol && pk <= minkey)) { mincol = pc; minkey = pk; wv = q; }
+                            }
+#else
 #pragma unroll
                             for (int q = OSDL_NW - 1; q >= 0; --q) {
                                 const int pc = (int)pcol[par * OSDL_NW + q];
                                 if (pc <= mincol) { mincol = pc; wv = q; }
                             }
+#endif
                             if (mincol >= 64) { par ^= 1; break; }
                             const unsigned long long pw_p = pbuf[(size_t)(par * OSDL_NW + wv) * 2 + 0];
                             const unsigned long long t_p = pbuf[(size_t)(par * OSDL_NW + wv) * 2 + 1];
@@ -1017,15 +1107,21 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             if (pos < nnz) {
                                 Lpw[pos] = cp[s2];
                                 Lt[pos] = ct[s2];
+#if OSDL_PIVOT_LIGHT
+                                if (ct[s2] != 0ull && ((cu >> s2) & 1u) == 0u) {
+                                    const unsigned int cnt = (key0[s2] >> 14) + (unsigned int)__popcll(ct[s2]);
+                                    rowpos[key0[s2] & 0x3fffu] = -1 - (int)(cnt < OSDL_CNT_MAX ? cnt : OSDL_CNT_MAX);
+                                }
+#endif
                             }
                         }
                         if (tid == 0) { misc[4] = cnp; misc[5] = cnr; misc[6] = cdone ? 1 : 0; }
                     } else if (wave == 0) {
                         const unsigned int la = (unsigned int)(size_t)(osdl_lds_w64)Lpw, ma = (unsigned int)(size_t)(osdl_lds_w32)misc;
-                        if (nnz <= 128) osdl_e2_compact_wave<2>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
-                        else if (nnz <= 256) osdl_e2_compact_wave<4>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
-                        else if (nnz <= 512) osdl_e2_compact_wave<8>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
-                        else osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0);
+                        if (nnz <= 128) osdl_e2_compact_wave<2>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                        else if (nnz <= 256) osdl_e2_compact_wave<4>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                        else if (nnz <= 512) osdl_e2_compact_wave<8>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                        else osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                     }
                     __syncthreads();
                     OSDL_TICK(23);  // (E2c: the pivot search on the list, one wave)
@@ -1240,6 +1336,16 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = t[k];
                             if (t[k] != 0ull) anymask |= 1u << k;
                         }
+#if OSDL_PIVOT_LIGHT
+                    // (this form takes whichever candidate row comes first, but keeps the rows' absorbed-pivot counts for the
+                    // compact panels that follow: rowpos = -1 - count for an unused row)
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k)
+                        if (((frozenmask >> k) & 1u) == 0u && ((usedmask >> k) & 1u) == 0u && t[k] != 0ull) {
+                            const int rp = OSDL_AT(int, rowpos, (ro >> 1) + k * NT * 4) - __popcll(t[k]);
+                            OSDL_AT(int, rowpos, (ro >> 1) + k * NT * 4) = rp > -1 - (int)OSDL_CNT_MAX ? rp : -1 - (int)OSDL_CNT_MAX;
+                        }
+#endif
                 }
             }
             }  // ======== end of the all-rows form

@@ -84,44 +84,64 @@ class StepPipeline:
     This is the loop `bench.py --gpus N` times and the loop tests/test_sharding_cpu.py drives on gloo with a stub
     decoder -- one code path.  The caller supplies the device-side work as callables, all asynchronous except `wait`:
 
-      launch(k, slot)      enqueue the decode of step k on decoder slot `slot` (a slot = one handle + its output buffers)
+      launch(k, slot, buf) enqueue the decode of step k on decoder slot `slot` (a slot = one handle + its output buffers);
+                           `buf` = the packed buffer of the step (None without the gather) -- where the kernels write
+                           bit-packed rows themselves the launch fills it
       pack(slot, buf)      enqueue the bit-packing of that slot's corrections into packed[buf], ordered after the decode
       wait(slot)           block until everything enqueued on that slot has finished
       on_finalised(k, timed)  optional: called once step k's decode has completed (kernel timings are read here)
       on_gathered(k, rows) optional, `dst` only: rows = the gathered packed corrections of step k, rank order, padding
-                           rows of short shards removed (the caller must synchronise before reading device tensors)
+                           rows of short shards removed; called when the gather is known to be complete (the caller
+                           must synchronise before reading device tensors)
+      gather_fn(src, bufs_or_None) optional: issues the gather and returns a handle with `.synchronize()` (or `.wait()`);
+                           default: `dist.gather` -- on CUDA tensors guarded by an event on torch's stream, on CPU
+                           tensors `async_op=True`
 
-    `packed` is a pair of tensors [rows_max, words] (rows_max = the largest shard over ranks: short shards are padded,
-    a gather needs equal shapes); step k uses packed[k & 1], and a buffer is packed again only after the gather that
-    read it has completed (event-guarded on CUDA tensors, synchronous on CPU tensors).  At most `nslots` steps are in
-    flight; a slot is reused only after its previous step has been finalised."""
+    `packed` is a list of `nbuf` tensors [rows_max, words] (rows_max = the largest shard over ranks: short shards are
+    padded, a gather needs equal shapes); step k uses packed[k % nbuf], and a buffer is written again only after the
+    gather that read it has completed.  The gather of step k is issued when step k is finalised, i.e. just before step
+    k + nslots is launched: with nbuf = nslots the launch of step k + nslots would wait for the gather issued a moment
+    before (one collective round trip on the critical path of every step -- rounds 1-4's double buffer); nbuf = nslots + 2
+    gives every gather two whole steps before its buffer is needed again, so a launch never waits for one.  nbuf < nslots
+    is refused (step k + nbuf would overwrite rows whose gather has not even been issued).  At most `nslots` steps are
+    in flight; a slot is reused only after its previous step has been finalised."""
 
     def __init__(self, nslots, launch, wait, pack=None, packed=None, rows=None, gather=True, group=None, dst=0,
-                 on_finalised=None, on_gathered=None):
+                 on_finalised=None, on_gathered=None, gather_fn=None):
+        import inspect
+
         import torch
         import torch.distributed as dist
 
         self._torch, self._dist = torch, dist
         self.nslots = int(nslots)
         self.launch, self.wait, self.pack = launch, wait, pack
+        try:  # launch(k, slot) of rounds 1-4 is still accepted
+            self._launch_takes_buf = len(inspect.signature(launch).parameters) >= 3
+        except (TypeError, ValueError):
+            self._launch_takes_buf = False
         self.on_finalised, self.on_gathered = on_finalised, on_gathered
         self.group, self.dst = group, dst
+        self.gather_fn = gather_fn
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.do_gather = bool(gather) and self.world > 1
-        if self.do_gather and self.nslots > 2:
-            # packed[k & 1] is gathered when step k is finalised; with three steps in flight step k + 2 would pack into
-            # the buffer of step k before that gather has read it
-            raise ValueError("with the gather on, at most 2 steps may be in flight (the packed rows are double-buffered)")
         self.packed = packed
+        self.nbuf = len(packed) if packed is not None else 0
+        if self.do_gather and packed is not None and self.nbuf < self.nslots:
+            # the gather of step k is issued when step k + nslots is about to be launched; with fewer buffers than steps
+            # in flight step k + nbuf would pack into the buffer of step k before that gather has read it
+            raise ValueError(f"with the gather on, {self.nslots} steps in flight need at least {self.nslots} packed buffers "
+                             f"(nslots + 2 keeps the gather off the launch path), got {self.nbuf}")
         self._gather_marks = []    # per gathered step: (start, end) CUDA events, or a host duration in seconds
         self.pending = []          # (k, timed) enqueued, not yet finalised
-        self.gather_done = [None, None]
+        self.inflight = [None] * max(self.nbuf, 1)   # per packed buffer: (handle, k, timed, t0 | start event) of its gather
+        self.launch_waited_for_gather = 0            # launches that found their buffer's gather still running
         self.gather_bufs = None
         self.counts = None
         if self.do_gather:
-            if pack is None or packed is None or len(packed) != 2:
-                raise ValueError("gathering needs `pack` and a pair of packed buffers")
+            if pack is None or packed is None or self.nbuf < 2:
+                raise ValueError("gathering needs `pack` and at least two packed buffers")
             rows = packed[0].shape[0] if rows is None else int(rows)
             if rows > packed[0].shape[0]:
                 raise ValueError("packed buffers are smaller than the local shard")
@@ -132,47 +152,84 @@ class StepPipeline:
             if max(self.counts) != packed[0].shape[0]:
                 raise ValueError(f"packed buffers must have max-shard rows = {max(self.counts)}, not {packed[0].shape[0]}")
             if self.rank == dst:
-                self.gather_bufs = [[torch.empty_like(packed[0]) for _ in range(self.world)] for _ in range(2)]
+                self.gather_bufs = [[torch.empty_like(packed[0]) for _ in range(self.world)] for _ in range(self.nbuf)]
+
+    @staticmethod
+    def _handle_done(h):
+        """True / False when the handle can tell without blocking, None when it cannot."""
+        for name in ("query", "is_completed", "done"):
+            f = getattr(h, name, None)
+            if callable(f):
+                try:
+                    return bool(f())
+                except Exception:
+                    return None
+        return None
+
+    def _retire(self, buf):
+        """Block until the gather that reads packed[buf] (if any) is complete; then its buffer may be written again."""
+        rec = self.inflight[buf]
+        if rec is None:
+            return
+        self.inflight[buf] = None
+        h, k, timed, t0 = rec
+        if isinstance(h, self._dist.Work):
+            h.wait()          # (a c10d Work also has a deprecated .synchronize that does not block)
+        else:
+            h.synchronize()   # CUDA event, or the handle of a caller-supplied gather_fn
+        if timed:
+            if self._torch.is_tensor(self.packed[buf]) and self.packed[buf].is_cuda and self.gather_fn is None:
+                self._gather_marks.append((t0, h))
+            else:  # host clock from issue to the moment the completion was observed (an upper bound)
+                import time as _time
+                self._gather_marks.append(_time.perf_counter() - t0)
+        if self.on_gathered is not None and self.rank == self.dst:
+            self.on_gathered(k, [b[:c] for b, c in zip(self.gather_bufs[buf], self.counts)])
 
     def _finalise(self, k, timed):
         self.wait(k % self.nslots)
         if self.on_finalised is not None:
             self.on_finalised(k, timed)
         if self.do_gather:
-            buf = k & 1
+            import time as _time
+
+            buf = k % self.nbuf
             src = self.packed[buf]
-            if src.is_cuda:
-                ev0 = self._torch.cuda.Event(enable_timing=True)
-                ev0.record()
-            else:
-                import time as _time
+            dstbufs = self.gather_bufs[buf] if self.rank == self.dst else None
+            if self.gather_fn is not None:
                 t0 = _time.perf_counter()
-            self._dist.gather(src, self.gather_bufs[buf] if self.rank == self.dst else None, dst=self.dst, group=self.group)
-            if src.is_cuda:  # the gather runs on torch's stream: guard the buffer's reuse with an event
-                ev = self._torch.cuda.Event(enable_timing=True)
-                ev.record()
-                self.gather_done[buf] = ev
-                if timed:
-                    self._gather_marks.append((ev0, ev))
-            elif timed:
-                self._gather_marks.append(_time.perf_counter() - t0)
-            if self.on_gathered is not None and self.rank == self.dst:
-                self.on_gathered(k, [b[:c] for b, c in zip(self.gather_bufs[buf], self.counts)])
+                h = self.gather_fn(src, dstbufs)
+            elif src.is_cuda:  # the gather runs on torch's stream: guard the buffer's reuse with an event
+                t0 = self._torch.cuda.Event(enable_timing=True)
+                t0.record()
+                self._dist.gather(src, dstbufs, dst=self.dst, group=self.group)
+                h = self._torch.cuda.Event(enable_timing=True)
+                h.record()
+            else:
+                t0 = _time.perf_counter()
+                h = self._dist.gather(src, dstbufs, dst=self.dst, group=self.group, async_op=True)
+            self.inflight[buf] = (h, k, timed, t0)
 
     def step(self, k, timed=True):
         slot = k % self.nslots
         while len(self.pending) >= self.nslots:  # slot (and its output buffers) of step k - nslots must be free
             self._finalise(*self.pending.pop(0))
+        buf = None
         if self.do_gather:
             # the packed buffer of this step must be free BEFORE the decode is enqueued: where the kernels write packed rows
-            # themselves (bposd_decode_batch_device_packed) the launch, not the pack step, fills it
-            buf = k & 1
-            if self.gather_done[buf] is not None:
-                self.gather_done[buf].synchronize()
-                self.gather_done[buf] = None
-        self.launch(k, slot)
+            # themselves (bposd_decode_batch_device_packed) the launch, not the pack step, fills it.  With nbuf = nslots + 2
+            # the gather in question was issued two steps ago.
+            buf = k % self.nbuf
+            if self.inflight[buf] is not None:
+                if self._handle_done(self.inflight[buf][0]) is False:
+                    self.launch_waited_for_gather += 1
+                self._retire(buf)
+        if self._launch_takes_buf:
+            self.launch(k, slot, buf)
+        else:
+            self.launch(k, slot)
         if self.do_gather:
-            self.pack(slot, k & 1)
+            self.pack(slot, buf)
         self.pending.append((k, timed))
 
     def gather_ms(self):
@@ -185,6 +242,9 @@ class StepPipeline:
     def drain(self):
         while self.pending:
             self._finalise(*self.pending.pop(0))
+        # gathers in step order (on_gathered sees the steps in order)
+        for rec_buf in sorted((b for b in range(len(self.inflight)) if self.inflight[b] is not None), key=lambda b: self.inflight[b][1]):
+            self._retire(rec_buf)
 
     def fence(self):
         """Everything enqueued so far is complete on every rank (the bracket of a timed region)."""

@@ -146,10 +146,10 @@ def _pipeline_worker(rank, world, port, total, steps, q_out):
         pipe.fence()
         assert log == [(0, False)] + [(k, True) for k in range(1, steps + 1)]
         assert len(pipe.gather_ms()) == steps  # one gather duration per timed step
-        # three steps in flight would repack a buffer before its gather has read it: refused
+        # three steps in flight on TWO packed buffers would repack a buffer before its gather has been issued: refused
         try:
             StepPipeline(3, launch, wait, pack=pack, packed=packed, rows=rows)
-            raise AssertionError("nslots = 3 with the gather on must be refused")
+            raise AssertionError("nslots = 3 with two packed buffers must be refused")
         except ValueError:
             pass
         if rank == 0:
@@ -174,6 +174,94 @@ def test_world_size_2_gloo_step_pipeline(total):
         p.join(timeout=180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+def _slow_gather_worker(rank, world, port, nbuf, q_out):
+    """Two steps in flight, a gather that takes 0.15 s and a decode that takes 0.2 s: with nslots + 2 packed buffers the launch of
+    step k + 2 is enqueued while gather k is still running and no launch ever waits for a gather; with the pair of
+    rounds 1-4 every launch waits for the gather issued just before it."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bp_osd_amd.sharding import StepPipeline
+
+        rows, wpr, nslots, steps = 8, 2, 2, 7
+        packed = [torch.zeros((rows, wpr), dtype=torch.int64) for _ in range(nbuf)]
+        launch_t, done_t, seen = {}, {}, []
+        pool = ThreadPoolExecutor(max_workers=1)  # ONE worker: the collectives keep their order on every rank
+        kq = []
+
+        class Handle:
+            def __init__(self, fut):
+                self.fut = fut
+
+            def query(self):
+                return self.fut.done()
+
+            def synchronize(self):
+                self.fut.result()
+
+        def gather_fn(src, bufs):
+            k = kq.pop(0)
+
+            def job():
+                time.sleep(0.15)
+                dist.gather(src, bufs, dst=0)
+                done_t[k] = time.perf_counter()
+
+            return Handle(pool.submit(job))
+
+        def launch(k, slot, buf):
+            launch_t[k] = time.perf_counter()
+            packed[buf].fill_(1000 * k + rank)  # the launch writes the packed rows itself (native packed decode)
+
+        def wait(slot):
+            time.sleep(0.2)
+
+        def on_finalised(k, timed):
+            kq.append(k)
+
+        def on_gathered(k, shards):
+            seen.append(k)
+            for r, s in enumerate(shards):
+                assert (s == 1000 * k + r).all(), (k, r)  # no buffer was overwritten before its gather had read it
+
+        pipe = StepPipeline(nslots, launch, wait, pack=lambda slot, buf: None, packed=packed, rows=rows,
+                            on_finalised=on_finalised, on_gathered=on_gathered, gather_fn=gather_fn)
+        for k in range(steps):
+            pipe.step(k, True)
+        pipe.fence()
+        pool.shutdown()
+        assert len(pipe.gather_ms()) == steps
+        if rank == 0:
+            assert seen == list(range(steps))
+        early = [launch_t[k + nslots] < done_t[k] for k in range(steps - nslots)]
+        q_out.put((rank, nbuf, pipe.launch_waited_for_gather, early))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nbuf", [4, 2])
+def test_gather_is_off_the_launch_path_with_nslots_plus_two_buffers(nbuf):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slow_gather_worker, args=(r, 2, port, nbuf, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for _ in range(2):
+        rank, nb, waited, early = q.get(timeout=5)
+        if nb == 4:  # step k + 2 was launched while gather k was still running, and never had to wait for a buffer
+            assert waited == 0 and all(early), (rank, waited, early)
+        else:        # the double buffer of rounds 1-4: every launch from step 2 on waits for the gather issued just before it
+            assert waited >= 4 and not any(early), (rank, waited, early)
 
 
 def test_step_pipeline_single_process_needs_no_process_group():
