@@ -205,7 +205,14 @@ constexpr int OSDL_MW_MIN = 1024;    // lists longer than this are searched by a
 #endif
 constexpr unsigned int OSDL_CNT_MAX = 16383u - 64u;  // stored counts saturate here: count + popcount(mask) stays below 2^14
 
-template <int CR>
+// GAUSS (OSD-0 / OSD-E, round 5): plain Gaussian elimination -- a pivot row takes no further row additions once it is chosen
+// (its word and mask go to the list at once and its registers are cleared, so it neither matches nor proposes again).  Rounds
+// 2-4 kept reducing the pivot rows of the open groups (Jordan steps inside the panel and the window); those rows carried 70 % of
+// all combination-mask bits (tools/fillin_sim.c: 17-64 bits per pivot row and pass against 1-2 for an unused row) and every
+// one of them was walked by the apply pass, for nothing: in Gaussian mode nobody reads a pivot row's words to the right of its
+// panel from M again (the back-substitution reads PRO).  What the Jordan steps bought -- the <= 64 pivots of a word being
+// independent in the back-substitution -- is now a 64-step loop of one wave per word there.
+template <int CR, bool GAUSS>
 __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_addr, unsigned int misc_addr, int nnz,
                                                               unsigned long long vmask, int rank, int nrank, int done_in, int* rowpos_) {
     constexpr int CAP = OSDL_E2C_CAP;
@@ -248,7 +255,7 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
         if (cnr >= rank) { cdone = true; break; }
         unsigned long long cand = 0ull;
 #pragma unroll
-        for (int s2 = 0; s2 < CR; ++s2) cand |= ((cu >> s2) & 1u) ? 0ull : cp[s2];
+        for (int s2 = 0; s2 < CR; ++s2) cand |= (!GAUSS && ((cu >> s2) & 1u)) ? 0ull : cp[s2];
         cand &= vmask;
         const unsigned int lb = osd_ffs64_or_64(cand);
         const unsigned int wk = osd_wave_min_u32((lb << 6) | (unsigned int)lane);  // wave-uniform
@@ -261,7 +268,7 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
         unsigned int bk = ~0u;  // the lane's lightest candidate: fewest absorbed pivot rows, then lowest row
 #pragma unroll
         for (int s2 = CR - 1; s2 >= 0; --s2) {
-            const bool hit = (((cp[s2] >> col) & 1ull) != 0ull) && (((cu >> s2) & 1u) == 0u);
+            const bool hit = (((cp[s2] >> col) & 1ull) != 0ull) && (GAUSS || ((cu >> s2) & 1u) == 0u);
             const unsigned int key = key0[s2] + ((unsigned int)__popcll(ct[s2]) << 14);
             const bool better = hit && key < bk;
             bk = better ? key : bk;
@@ -275,7 +282,7 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
         const int first = (int)(wk & 63u);
 #pragma unroll
         for (int s2 = CR - 1; s2 >= 0; --s2) {
-            const bool hit = (((cp[s2] >> col) & 1ull) != 0ull) && (((cu >> s2) & 1u) == 0u);
+            const bool hit = (((cp[s2] >> col) & 1ull) != 0ull) && (GAUSS || ((cu >> s2) & 1u) == 0u);
             kb = hit ? s2 : kb;
             a = hit ? cp[s2] : a;
             c = hit ? ct[s2] : c;
@@ -294,10 +301,14 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
             cp[s2] ^= pw_p & mm;
             ct[s2] ^= tq & mm;
         }
-        if (lane == first) {  // the pivot row itself is put back
+        if (lane == first) {
+            if (GAUSS) {  // the pivot row is final: to the list, out of the registers
+                Lpw[kb * 64 + lane] = pw_p;
+                Lt[kb * 64 + lane] = t_p;
+            }
 #pragma unroll
             for (int s2 = 0; s2 < CR; ++s2)
-                if (s2 == kb) { cp[s2] = pw_p; ct[s2] = t_p; }
+                if (s2 == kb) { cp[s2] = GAUSS ? 0ull : pw_p; ct[s2] = GAUSS ? 0ull : t_p; }  // (Jordan: the pivot row itself is put back)
             cu |= 1u << kb;
             Lpiv[cnp] = (unsigned int)(kb * 64 + lane);
             Lpiv[64 + cnp] = (unsigned int)col;
@@ -308,7 +319,7 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
 #pragma unroll
     for (int s2 = 0; s2 < CR; ++s2) {
         const int pos = s2 * 64 + lane;
-        if (pos < nnz) {
+        if (pos < nnz && !(GAUSS && ((cu >> s2) & 1u))) {
             Lpw[pos] = cp[s2];
             Lt[pos] = ct[s2];
 #if OSDL_PIVOT_LIGHT
@@ -1089,10 +1100,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                 cp[s2] ^= pw_p & mm;
                                 ct[s2] ^= tq & mm;
                             }
-                            if (wave == wv && lane == firstl) {  // the pivot row itself is put back
+                            if (wave == wv && lane == firstl) {  // Jordan: the pivot row itself is put back; Gaussian: it is final (see osdl_e2_compact_wave)
+                                if (gauss) {
+                                    Lpw[kb * NT + (int)threadIdx.x] = pw_p;
+                                    Lt[kb * NT + (int)threadIdx.x] = t_p;
+                                }
 #pragma unroll
                                 for (int s2 = 0; s2 < MWR; ++s2)
-                                    if (s2 == kb) { cp[s2] = pw_p; ct[s2] = t_p; }
+                                    if (s2 == kb) { cp[s2] = gauss ? 0ull : pw_p; ct[s2] = gauss ? 0ull : t_p; }
                                 cu |= 1u << kb;
                                 Lpiv[cnp] = (unsigned int)(kb * NT + (int)threadIdx.x);
                                 Lpiv[64 + cnp] = (unsigned int)mincol;
@@ -1104,7 +1119,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #pragma unroll
                         for (int s2 = 0; s2 < MWR; ++s2) {
                             const int pos = s2 * NT + (int)threadIdx.x;
-                            if (pos < nnz) {
+                            if (pos < nnz && !(gauss && ((cu >> s2) & 1u))) {
                                 Lpw[pos] = cp[s2];
                                 Lt[pos] = ct[s2];
 #if OSDL_PIVOT_LIGHT
@@ -1118,10 +1133,17 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         if (tid == 0) { misc[4] = cnp; misc[5] = cnr; misc[6] = cdone ? 1 : 0; }
                     } else if (wave == 0) {
                         const unsigned int la = (unsigned int)(size_t)(osdl_lds_w64)Lpw, ma = (unsigned int)(size_t)(osdl_lds_w32)misc;
-                        if (nnz <= 128) osdl_e2_compact_wave<2>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
-                        else if (nnz <= 256) osdl_e2_compact_wave<4>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
-                        else if (nnz <= 512) osdl_e2_compact_wave<8>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
-                        else osdl_e2_compact_wave<16>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                        if (gauss) {
+                            if (nnz <= 128) osdl_e2_compact_wave<2, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                            else if (nnz <= 256) osdl_e2_compact_wave<4, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                            else if (nnz <= 512) osdl_e2_compact_wave<8, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                            else osdl_e2_compact_wave<16, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                        } else {
+                            if (nnz <= 128) osdl_e2_compact_wave<2, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                            else if (nnz <= 256) osdl_e2_compact_wave<4, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                            else if (nnz <= 512) osdl_e2_compact_wave<8, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                            else osdl_e2_compact_wave<16, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                        }
                     }
                     __syncthreads();
                     OSDL_TICK(23);  // (E2c: the pivot search on the list, one wave)
@@ -1168,6 +1190,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         for (int i = threadIdx.x; i < nnz; i += NT) TmO[(size_t)ng * MRL + (Lid[i] & 0x7fffffffu)] = Lt[i];
                         usedmask |= (unsigned int)Lnew[threadIdx.x];
                         anymask |= (unsigned int)Lany[threadIdx.x];
+                        if (gauss) frozenmask |= (unsigned int)Lnew[threadIdx.x];  // Gaussian: a pivot row takes no more updates
                     }
                     if (jordan && usedbefore != 0u) {
                         // ---- Jordan fix-up: a pivot row u of an earlier panel, brought up to date by E1, must lose its ones in
@@ -1304,7 +1327,11 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 // row itself is put back afterwards by the one lane that owns it
 #pragma unroll
                 for (int k = 0; k < RPT; ++k) {
-                    const unsigned long long mm = (unsigned long long)((long long)(pw[k] << (63 - mincol)) >> 63);
+                    unsigned long long mm = (unsigned long long)((long long)(pw[k] << (63 - mincol)) >> 63);
+                    if (gauss) {  // (uniform) Gaussian: the pivot rows of this panel are final
+                        const unsigned int um = (unsigned int)__builtin_amdgcn_sbfe((int)usedmask, k, 1);  // -1 if used
+                        mm &= ~(((unsigned long long)um << 32) | um);
+                    }
                     pw[k] ^= pw_p & mm;
                     t[k] ^= tq & mm;
                 }
@@ -1348,6 +1375,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #endif
                 }
             }
+            if (gauss) frozenmask |= usedmask;  // Gaussian: a pivot row takes no more updates
             }  // ======== end of the all-rows form
             OSDL_TICK(3);
             OSDL_COUNT(7);
@@ -1483,29 +1511,42 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         if (lane == 0 && bits) atomicXor(&resw[c], bits);
                     }
                 }
-                if (wave == 0) {
-                    const unsigned long long vb = prow >= 0 ? M[(size_t)w * MRL + prow] : 0ull;
-#pragma unroll
-                    for (int c = 0; c < NR; ++c) {
-                        if (c < ntc_g || c == OSDL_MAXSPAN) {
-                            const unsigned long long bits = __ballot((__popcll(vb & zv[(size_t)c * W + w]) & 1) != 0);
-                            if (lane == 0) resb[c] = bits;
-                        }
-                    }
+                // Round 5: the pivot rows of a word are no longer reduced against each other (plain Gaussian elimination, see
+                // osdl_e2_compact_wave), so pivot row q has entries at the columns of the word's LATER pivots and the word is solved
+                // from its last pivot column to its first: x[j] = parity(S_j & A) ^ <own word of row j, z[w]>, z[w] |= x[j] << j.
+                // One wave, right-hand side c on lane c, the row's own word broadcast by v_readlane: <= 64 short dependent steps
+                // per word (~1.5 M cycles per elimination) for the Jordan steps the panel phase and the apply passes no longer do.
+                unsigned long long vb = 0ull, S = 0ull;
+                if (wave == 0 && prow >= 0) {  // (requested before the barrier)
+                    vb = M[(size_t)w * MRL + prow];
+                    S = pmask[w * 64 + lane];
                 }
                 __syncthreads();
                 if (wave == 0) {
-                    const unsigned long long S = prow >= 0 ? pmask[w * 64 + lane] : 0ull;
 #pragma unroll
                     for (int c = 0; c < NR; ++c) {
-                        if (c < ntc_g || c == OSDL_MAXSPAN) {
-                            const unsigned long long A = resw[c], Bw = resb[c];
-                            const unsigned long long xb = __ballot(prow >= 0 && (((__popcll(S & A) & 1) ^ (int)((Bw >> lane) & 1ull)) != 0));
-                            if (lane == 0) {
-                                zv[(size_t)c * W + w] ^= xb;
-                                resw[c] = 0ull;
-                            }
+                        if (c < ntc_g || c == OSDL_MAXSPAN) {  // bit j: parity(S_j & A_c), the part from the words to the right
+                            const unsigned long long pa = __ballot(prow >= 0 && (__popcll(S & resw[c]) & 1) != 0);
+                            if (lane == 0) resb[c] = pa;
                         }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const bool mine = lane < NR && (lane < ntc_g || lane == OSDL_MAXSPAN);
+                    unsigned long long z = mine ? zv[(size_t)lane * W + w] : 0ull;
+                    const unsigned long long pa = mine ? resb[lane] : 0ull;
+                    unsigned long long pvm = pv;  // wave-uniform
+                    while (pvm) {
+                        const int j = 63 - __builtin_clzll(pvm);
+                        pvm &= ~(1ull << j);
+                        const unsigned long long vbj =
+                            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(vb >> 32), j) << 32) |
+                            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)vb, j);
+                        const unsigned long long bit = ((pa >> j) ^ (unsigned long long)__popcll(vbj & z)) & 1ull;
+                        z |= bit << j;  // (no right-hand side has a bit of its own at a pivot column)
+                    }
+                    if (mine) {
+                        zv[(size_t)lane * W + w] = z;
+                        resw[lane] = 0ull;
                     }
                 }
                 __syncthreads();
