@@ -1161,9 +1161,10 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             h->last_osd_kernel = 3;
             if ((rc = launch_osd_large(h, Q, B, nullptr))) return rc;
             if (Q.dbg) {
-                long long st[24];
+                long long st[28];
                 HIP_TRY(h, hipStreamSynchronize(h->osd_now));
                 HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[bposd large osd, sparse apply passes %lld: %lld ticks, %lld listed rows, %lld mask bits]\n", st[12], st[24], st[25], st[26]);
                 fprintf(stderr, "[bposd large osd, s_memtime ticks, list slot 0] sort %lld  build %lld  E1 %lld  E2 %lld  E3 %lld  apply %lld  "
                         "sweep %lld (back-substitution %lld, column vectors %lld, candidates %lld, write-out %lld) | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld | apply pass: row walks %lld, wait for the slowest walker %lld, own table build %lld, wait for the builders %lld, list builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5] + st[17] + st[18] + st[19] + st[20], st[6], st[13], st[14], st[15], st[16], st[7], st[8], st[9], st[10], st[11], st[5], st[19], st[17], st[18], st[20]);
                 {   // every elimination of the launch (osd_large_kernel writes 16 numbers per list slot behind the first 32)
@@ -1178,7 +1179,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
                         }
                     if (v.size() > 1) {
                         std::sort(v.begin(), v.end());
-                        fprintf(stderr, "[bposd large osd, all %zu eliminations of the launch, sorted by ticks] M ticks: total | sort build E2 E3 row-walks sweep | words groups applies | own-table-build E1c E2c-one-wave of-the-build:loads (E2 column = the rest of the panel phase)\n", v.size());
+                        fprintf(stderr, "[bposd large osd, all %zu eliminations of the launch, sorted by ticks] M ticks: total | sort build E2 E3 row-walks sweep | words groups applies | own-table-build E1c E2c-one-wave sparse-apply-passes (E2 column = the rest of the panel phase)\n", v.size());
                         for (size_t i = 0; i < v.size(); i += (i + 8 < v.size() ? v.size() / 8 : 1)) {
                             const auto& a = v[i];
                             fprintf(stderr, "  [%3zu] %.0f | %.1f %.1f %.1f %.1f %.1f %.1f | %lld %lld %lld | %.1f %.1f %.1f %.1f\n", i, a[0] * 1e-6, a[1] * 1e-6, a[2] * 1e-6, a[4] * 1e-6, a[5] * 1e-6,

@@ -49,6 +49,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "osd_kernel.hip.h"
 
 namespace bposd {
@@ -562,6 +564,200 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                         }
 }
 
+// AP, sparse form (round 5).  The table walk of the apply pass costs the same whatever the rows' combination masks hold: per
+// listed row and word one look-up per 5-bit field of every open group (46 of 52 on L29k, measured), although with plain
+// Gaussian elimination a pass lists ~300 rows with 4-5 mask bits each (tools/fillin_sim.c) -- 96 % of the look-ups return entry
+// 0 because SOME lane of the wave needs that field.  Here the pass works on the SET BITS of the masks: every bit is one
+// entry (row, group, pivot) of a work list in LDS, the pivot rows of the open groups are staged raw (16 KB per 8-word chunk,
+// double-buffered, requested three chunks ahead: no Gray-code table build), an entry reads the pivot row's eight words and
+// sends each non-zero one to the matrix as a returnless atomic XOR.  Chosen per pass when the bits fit the list
+// (OSDL_SPARSE_LIST; the caller keeps the count as the groups are formed); denser passes keep the table walk, whose cost per
+// row does not grow with the bits.  Measured on l29k_ms_e15 (same box, tools/ab_libs_l29k.sh): 8.65 k -> 10.4 k syndromes/s
+// together with the two changes it builds on (lightest pivot row; pivot rows final when chosen), OSD alone 118 -> 99 ms per
+// 252 eliminations, median elimination 203 M -> 133 M cycles; what a pass still costs (~230 k cycles) is the rate at which a
+// CU's vector-memory path takes scattered 64-bit atomics (~60 k per pass, ~4 cycles each).
+// A function of its own: registers allocated on their own (the kernel body sits at its 128-VGPR cap), nothing of the caller's
+// per-thread state is needed -- the row list, the masks, PRO and M are all in memory.
+#ifndef OSDL_SPARSE_LIST
+#define OSDL_SPARSE_LIST 6144  // passes with at most this many mask bits take the sparse form (eight entries per walking thread)
+#endif
+__device__ __attribute__((noinline)) void osdl_apply_sparse(unsigned long long* U_, const int* alist_, const unsigned long long* TmO_,
+                                                            const unsigned long long* PRO_, unsigned long long* M_, const int* gnp_, const int* gbo_,
+                                                            int MRL, int W, int xlo, int ng, int nact) {
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    typedef __attribute__((address_space(1))) int g_i32;
+    typedef __attribute__((address_space(1))) char g_char;
+    typedef __attribute__((address_space(3))) unsigned long long l_u64;
+    typedef __attribute__((address_space(3))) int l_i32;
+    typedef __attribute__((address_space(3))) unsigned int l_u32;
+    // The arguments of a non-inlined function arrive in VECTOR registers: left so, every address below is 64-bit vector
+    // arithmetic on values the compiler must take for divergent (128 VGPRs and spills inside the loop in the first build).  Moved
+    // to scalar registers once, the bases are SGPR pairs and the accesses take the base + 32-bit offset form.
+    auto uni = [](const void* p_) {
+        const unsigned long long a = (unsigned long long)p_;
+        return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(a >> 32)) << 32) |
+               (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+    };
+    MRL = __builtin_amdgcn_readfirstlane(MRL); W = __builtin_amdgcn_readfirstlane(W); xlo = __builtin_amdgcn_readfirstlane(xlo);
+    ng = __builtin_amdgcn_readfirstlane(ng); nact = __builtin_amdgcn_readfirstlane(nact);
+    const g_i32* alist = (const g_i32*)uni(alist_);
+    const g_u64* TmO = (const g_u64*)uni(TmO_);
+    const g_u64* PRO = (const g_u64*)uni(PRO_);
+    g_u64* M = (g_u64*)uni(M_);
+    const l_i32* gnp = (const l_i32*)(size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(const l_i32*)gnp_);
+    const l_i32* gbo = (const l_i32*)(size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(const l_i32*)gbo_);
+    l_u64* PRW = (l_u64*)(size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(l_u64*)U_);  // [2][OSDL_K][OSDL_CW][64]
+    constexpr int NT = OSDL_NT;
+    constexpr int BUF = OSDL_K * 64 * OSDL_CW;
+    constexpr int NSW = 4;                       // staging waves
+    constexpr int NST = NSW * 64;                // staging threads
+    constexpr int NWT = NT - NST;                // walking threads
+    constexpr int EPT = BUF / NST;               // staged words per staging thread and chunk
+    constexpr int EPW = OSDL_SPARSE_LIST / NWT;  // list entries per walking thread
+    static_assert(BUF % NST == 0 && OSDL_CW == 8, "staging assumes 8-word chunks and a whole number of words per thread");
+    static_assert(OSDL_SPARSE_LIST % NWT == 0, "whole entries per walking thread");
+    const int tid = threadIdx.x;
+    const int nch = (W - xlo + OSDL_CW - 1) / OSDL_CW;
+    l_u32* ELIST = (l_u32*)(PRW + 2 * BUF);      // [OSDL_SPARSE_LIST] the pass's (row, group, pivot) entries
+    l_i32* ecount = (l_i32*)(ELIST + OSDL_SPARSE_LIST);
+    // ---- The work list of the pass: one entry per SET BIT of a listed row's masks -- (row, group, pivot), i.e. "row absorbs that
+    // pivot row" -- packed as  row * 8 | (group * 512 + pivot) << 17.  A lane walks ENTRIES, not rows: a row's mask over the
+    // start states of a group's pivot rows has 1-2 bits as a rule but 30-100 for one row in twelve (a pivot row that absorbed
+    // many others before it was chosen hands its whole combination on), and a wave that walks rows runs as long as its
+    // heaviest row (first build: 25 k cycles per chunk, as slow as the table walk).  Entries are all alike.  Their changes of
+    // one matrix word need no combining: XOR atomics commute.
+    if (tid == 0) *ecount = 0;
+    __syncthreads();
+    for (int i = tid; i < nact; i += NT) {
+        const int row = alist[i];
+        unsigned long long mk[OSDL_K];
+        int nb = 0;
+#pragma unroll
+        for (int g = 0; g < OSDL_K; ++g) {
+            mk[g] = g < ng ? TmO[(size_t)g * MRL + row] : 0ull;
+            nb += __popcll(mk[g]);
+        }
+        if (nb) {
+            int pos = atomicAdd((int*)ecount, nb);
+#pragma unroll
+            for (int g = 0; g < OSDL_K; ++g) {
+                unsigned long long m = mk[g];
+                while (m) {
+                    const int q = (int)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    if (pos < OSDL_SPARSE_LIST) ELIST[pos] = ((unsigned int)row << 3) | ((unsigned int)(g * (64 * OSDL_CW) + q) << 17);
+                    ++pos;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nent = *ecount < OSDL_SPARSE_LIST ? *ecount : OSDL_SPARSE_LIST;  // (the caller takes this form only when the bits fit)
+    // ---- The pass is a chain of short steps (a few hundred cycles of LDS work per chunk), and anything a step WAITS for from
+    // HBM costs it a round trip (~6 k cycles with 250 eliminations in flight).  Two things keep waits off the steps' path:
+    // (i) a row's words are not loaded at all -- the change goes out as a returnless 64-bit atomic XOR per changed word
+    // (performed in the L2); the workgroup's later plain loads of M come after a barrier and an invalidation of this CU's L1.
+    // (ii) The waves are SPECIALISED: four of them only stage (the words of chunk c + 3 are requested in step c and wait in
+    // registers), the other twelve only walk and never wait for memory.  In one instruction stream the two do not mix: the
+    // vector-memory counter of gfx9 counts loads and atomics together and in order, and the number of atomics a step issues is
+    // not a compile-time constant, so every wait for a staging word also waited for the previous step's atomics to come back
+    // from the L2 (one round trip per step again).  Steps are separated by a bare s_barrier (LDS counter drained by hand, no
+    // memory fence: the atomics need not be complete before the END of the pass).
+#define OSDL_STEP_BARRIER()                                   \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_s_barrier();                         \
+        asm volatile("" ::: "memory");                        \
+    } while (0)
+    if (tid < NST) {
+        // ================= staging waves.  Element e = tid + i * 256 of a chunk's block: group e / 512, word (e >> 6) & 7, pivot
+        // e & 63 (a wave reads 512 contiguous bytes of PRO); LDS layout [group][word][pivot] = e
+        auto load_chunk = [&](int c, unsigned long long (&val)[EPT]) {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int e = tid + i * NST;
+                const int g = e >> 9, xx = (e >> 6) & 7, q = e & 63;
+                const int x = xlo + c * OSDL_CW + xx;
+                const bool ok = c < nch && g < ng && x < W;
+                val[i] = PRO[((long long)gbo[ok ? g : 0] + (ok ? x : xlo)) * 64 + q];  // (clamped, unconditional: no branch, no wait)
+            }
+        };
+        auto store_chunk = [&](int c, const unsigned long long (&val)[EPT]) {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int e = tid + i * NST;
+                const int g = e >> 9, xx = (e >> 6) & 7, q = e & 63;
+                const bool ok = g < ng && xlo + c * OSDL_CW + xx < W && q < gnp[g < ng ? g : 0];
+                PRW[(c & 1) * BUF + e] = ok ? val[i] : 0ull;  // [group][word][pivot]: e itself
+            }
+        };
+        // R[c mod 3]: the words of chunk c.  The step is unrolled three times so that the ring is indexed by constants (a rotation
+        // by register moves would wait for the newest request).
+        unsigned long long R[3][EPT];
+        load_chunk(0, R[0]);
+        load_chunk(1, R[1]);
+        load_chunk(2, R[2]);
+        store_chunk(0, R[0]);
+        load_chunk(3, R[0]);
+        auto step = [&](int c, auto IC) {
+            constexpr int i = decltype(IC)::value;  // c mod 3
+            OSDL_STEP_BARRIER();  // block c is complete; every walker has left chunk c - 1, which read the other block
+            store_chunk(c + 1, R[(i + 1) % 3]);   // (requested three steps ago)
+            load_chunk(c + 4, R[(i + 1) % 3]);
+        };
+        // (the loop is left where the chunks end, not skipped through: a path "step 0, skip, skip, step 0" would make the compiler
+        // wait in step 0 for the request step 0 has just made)
+#pragma clang loop unroll(disable)
+        for (int c = 0;;) {
+            step(c, std::integral_constant<int, 0>{});
+            if (++c >= nch) break;
+            step(c, std::integral_constant<int, 1>{});
+            if (++c >= nch) break;
+            step(c, std::integral_constant<int, 2>{});
+            if (++c >= nch) break;
+        }
+    } else {
+        // ================= walking waves: thread wt takes entries wt, wt + 768, ... (in registers for the whole pass)
+        const int wt = tid - NST;
+        const int nj = (nent + NWT - 1) / NWT;
+        unsigned int ent[EPW];
+#pragma unroll
+        for (int j = 0; j < EPW; ++j) ent[j] = (wt + j * NWT < nent) ? ELIST[wt + j * NWT] : 0xffffffffu;
+#pragma clang loop unroll(disable)
+        for (int c = 0; c < nch; ++c) {
+            OSDL_STEP_BARRIER();
+            const int x0 = xlo + c * OSDL_CW;
+            const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
+            const l_u64* blk = PRW + (c & 1) * BUF;
+#pragma unroll
+            for (int j = 0; j < EPW; ++j) {
+                if (j >= nj) break;  // uniform
+                if (ent[j] != 0xffffffffu) {
+                    // [group][word][pivot]: the lanes of one read differ in (group, pivot), bank pair = pivot mod 32 -- two lanes
+                    // collide when their pivots are 32 apart.  ([group][pivot][8 words] with 128-bit reads put all 64 lanes on 16
+                    // banks: 16-way conflicts.)  Volatile: single ds_read_b64 with immediate offsets, not the half-rate
+                    // ds_read2st64_b64 pairs (same finding as in the table walk).
+                    const volatile l_u64* src = (const volatile l_u64*)(blk + (ent[j] >> 17));
+                    const unsigned int ro = ent[j] & 0x1ffffu;
+                    unsigned long long v[OSDL_CW];
+#pragma unroll
+                    for (int xx = 0; xx < OSDL_CW; ++xx) v[xx] = src[xx * 64];
+#pragma unroll
+                    for (int xx = 0; xx < OSDL_CW; ++xx)
+                        if (xx < cw && v[xx] != 0ull)
+                            __hip_atomic_fetch_xor((g_u64*)((g_char*)(M + (size_t)(x0 + xx) * MRL) + ro), v[xx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+#undef OSDL_STEP_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my atomics have been performed ...
+    __syncthreads();                                   // ... and so have everyone's
+    // The atomics were performed in the L2; this CU's vector L1 may still hold lines of M from before.  Agent-scope acquire =
+    // invalidate the L1.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // (The apply pass as a non-inlined function of its own was measured too: 90 -> 104-113 M cycles per elimination -- its list build and
 // its row loop live on state of the caller (row masks, frozen / used bits) that then crosses the call in memory.  It stays inlined.)
 // (The back-substitution loop as a non-inlined function of its own: 13 -> 29 M cycles per elimination; it stays inlined.  E3 is the one
@@ -618,7 +814,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         const double* llr = P.llr_ws + (size_t)slot_id * n;
 
 #ifdef BPOSD_OSD_DIAG
-        long long tk[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 17..20 (apply pass): own table build, wait for the builders, wait for the row walkers, list build  // 13..16: back-substitution, column vectors, candidate sweep, write-out  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
+        long long tk[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 12: sparse apply passes, 24: their ticks  // 17..20 (apply pass): own table build, wait for the builders, wait for the row walkers, list build  // 13..16: back-substitution, column vectors, candidate sweep, write-out  // sort, build, E1, E2, E3, AP, sweep, words, groups, applies,
                                                                // apply look-ups per thread, apply row-words per thread
         long long t0 = (long long)__builtin_amdgcn_s_memtime();
 #define OSDL_TICK(i)                                                     \
@@ -671,6 +867,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         __syncthreads();
         osdl_build_rows<RPT>(M, P.rp, P.ci, inv, P.synd, s, m, W, (int)MRL);
         if (tid < 2 * OSDL_NW) pcol[tid] = 64u;
+        if (tid == 0) misc[8] = 0;  // mask bits of the open groups
         __syncthreads();
 
         OSDL_TICK(1);
@@ -725,9 +922,20 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             }
             const int nact = cnt[RPT * OSDL_NW];
             const int nk = (nact + NT - 1) / NT;  // list entries per thread (the last round may be partial)
+            const int passbits = misc[8];       // mask bits of the open groups (kept as the groups are formed)
             __syncthreads();
             OSDL_TICK(20);
-            for (int x0 = xlo; x0 < W && nact > 0; x0 += OSDL_CW) {
+            // sparse masks (the rule in Gaussian mode): walk the set bits, no tables -- osdl_apply_sparse
+            const bool sparse_pass = OSDL_SPARSE_LIST > 0 && nact > 0 && xlo < W && passbits <= OSDL_SPARSE_LIST;
+            if (sparse_pass) {
+                OSDL_COUNT(12);
+                OSDL_TICK(5);
+                osdl_apply_sparse(U, alist, TmO, PRO, M, gnp, gbo, (int)MRL, W, xlo, ng, nact);
+                OSDL_TICK(24);
+                OSDL_ADD(25, nact);
+                OSDL_ADD(26, passbits);
+            }
+            for (int x0 = xlo; x0 < W && nact > 0 && !sparse_pass; x0 += OSDL_CW) {
                 OSDL_FRESH_TID();
                 const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
                 OSDL_TICK(5);
@@ -887,6 +1095,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         if (xx < cw && live && v[xx] != 0ull) OSDL_ROW_ST(M + (size_t)(x0 + xx) * MRL, ro, cur[xx]);
                 }
             }
+            if (threadIdx.x == 0) misc[8] = 0;
             __syncthreads();
             ng = 0;
             anymask = 0u;  // no group is open: no masks
@@ -1181,11 +1390,18 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                 atomicOr(&pcm[col >> 5], 1u << (col & 31));
                             }
                         }
-                        for (int i = threadIdx.x; i < nnz; i += NT)
-                            if (Lt[i] != 0ull) {
-                                const int r = (int)(Lid[i] & 0x7fffffffu);
-                                atomicOr((unsigned int*)(Lany + ((r & (NT - 1)) & ~1)), (1u << (r / NT)) << (16 * (r & 1)));
-                            }
+                        {
+                            int mybits = 0;
+                            for (int i = threadIdx.x; i < nnz; i += NT)
+                                if (Lt[i] != 0ull) {
+                                    const int r = (int)(Lid[i] & 0x7fffffffu);
+                                    atomicOr((unsigned int*)(Lany + ((r & (NT - 1)) & ~1)), (1u << (r / NT)) << (16 * (r & 1)));
+                                    mybits += __popcll(Lt[i]);
+                                }
+                            // (Gaussian: the new pivot rows are final and will not be listed -- their masks do not count)
+                            if (gauss && (int)threadIdx.x < npiv) mybits -= __popcll(Lt[Lpiv[threadIdx.x]]);
+                            if (mybits) atomicAdd(&misc[8], mybits);
+                        }
                         __syncthreads();  // zero masks before the list rows' masks; new-pivot bits; fix-up tables
                         for (int i = threadIdx.x; i < nnz; i += NT) TmO[(size_t)ng * MRL + (Lid[i] & 0x7fffffffu)] = Lt[i];
                         usedmask |= (unsigned int)Lnew[threadIdx.x];
@@ -1238,6 +1454,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                                 if (tm != 0ull) {
                                     OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + (k0 + i) * NT * 8) = tm;
                                     anymask |= 1u << (k0 + i);
+                                    atomicAdd(&misc[8], __popcll(tm));
                                 }
                             }
                         }
@@ -1363,6 +1580,13 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             OSDL_AT(unsigned long long, TmO + (size_t)ng * MRL, ro + k * NT * 8) = t[k];
                             if (t[k] != 0ull) anymask |= 1u << k;
                         }
+                    {
+                        int mybits = 0;
+#pragma unroll
+                        for (int k = 0; k < RPT; ++k)
+                            if (((frozenmask >> k) & 1u) == 0u) mybits += __popcll(t[k]);
+                        if (mybits) atomicAdd(&misc[8], mybits);
+                    }
 #if OSDL_PIVOT_LIGHT
                     // (this form takes whichever candidate row comes first, but keeps the rows' absorbed-pivot counts for the
                     // compact panels that follow: rowpos = -1 - count for an unused row)
@@ -1901,15 +2125,15 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #ifdef BPOSD_OSD_DIAG
         tk[6] = tk[13] + tk[14] + tk[15] + tk[16];
         if (P.dbg && slot_id == 0 && tid == 0)
-            for (int i = 0; i < 24; ++i) P.dbg[i] = tk[i];
+            for (int i = 0; i < 28; ++i) P.dbg[i] = tk[i];
         if (P.dbg && slot_id < 500 && tid == 0) {  // every elimination of the launch: total ticks, then the stamps 0..12 + 17..20
             long long tot = 0;
             for (int i = 0; i < 7; ++i) tot += tk[i];
-            tot += tk[17] + tk[18] + tk[19] + tk[20] + tk[21] + tk[22] + tk[23];
+            tot += tk[17] + tk[18] + tk[19] + tk[20] + tk[21] + tk[22] + tk[23] + tk[24];
             long long* d = P.dbg + 32 + slot_id * 16;
             d[0] = tot;
             for (int i = 0; i < 11; ++i) d[1 + i] = tk[i];
-            d[12] = tk[17] + tk[21]; d[13] = tk[22]; d[14] = tk[23]; d[15] = tk[21];
+            d[12] = tk[17] + tk[21]; d[13] = tk[22]; d[14] = tk[23]; d[15] = tk[24];  // (15: sparse apply passes; was the builders' loads)
         }
 #endif
 #undef OSDL_TICK

@@ -3,7 +3,7 @@
 // of a column's candidate rows becomes the pivot row changes no output, only how fast the matrix fills in.  Test / analysis
 // tool: nothing in the product path uses it.
 //
-//   fillin_sim <matrix.bin> <policy>     (matrix.bin: int32 m, n, then for each row int32 count + sorted column positions)
+//   fillin_sim <matrix.bin> <policy> [pure=1]     (matrix.bin: int32 m, n, then for each row int32 count + sorted column positions)
 //
 // Policies: 0 lowest row index, 1 exact remaining weight, 2 additive estimate (est[r] += est[p], saturating),
 //           3 number of absorbed pivots, 4 popcount of the panel word only, 5 estimate, ties by panel-word popcount,
@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 2;
     const int policy = atoi(argv[2]);
+    const int pure = argc > 3 ? atoi(argv[3]) : 1;  // 1: plain Gaussian elimination (a pivot row is final when chosen, round 5); 0: rounds 2-4 (pivot rows of the open groups keep absorbing)
     int32_t m, n;
     if (fread(&m, 4, 1, f) != 1 || fread(&n, 4, 1, f) != 1) return 2;
     const int W = (n + 63) / 64;
@@ -83,7 +84,7 @@ int main(int argc, char** argv) {
                     if (key < best) { best = key; p = r; }
                 }
             }
-            used[p] = 2;
+            used[p] = pure ? 1 : 2;
             ++rank;
             const uint64_t* pr = M + (size_t)p * W;
             int pw = 0;
