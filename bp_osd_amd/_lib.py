@@ -73,7 +73,7 @@ class BposdConfig(C.Structure):
         ("schedule", C.c_int32),
         ("ps_clip", C.c_double),
         ("osd_e_bit_order", C.c_int32),
-        ("reserved", C.c_int32 * 1),
+        ("ps_math_form", C.c_int32),
     ]
 
 

@@ -31,6 +31,7 @@ struct BpAnyParams {
     int bp_method;  // 0 product-sum, 1 min-sum
     double ms_scaling;
     double ps_clip;
+    int ps_form;  // product-sum evaluation order (portable_math.h: pm_ps_tanh_half)
     int osd_enabled;
     const uint8_t* __restrict__ synd;     // [B, m]
     const double* __restrict__ llr0;      // [n]
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(BPA_NT) void bp_anydeg_kernel(const BpAnyParams P) 
                             dpar ^= dec[P.ci[e]];
                             if (last) continue;
                             pre[e] = t;
-                            const double th = pm_tanh_half(msg[e]);
+                            const double th = pm_ps_tanh_half(msg[e], P.ps_form);
                             thv[e] = th;
                             t *= th;
                         }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(BPA_NT) void bp_anydeg_kernel(const BpAnyParams P) 
                             const double sg = sbit ? -1.0 : 1.0;
                             for (int e = e1 - 1; e >= e0; --e) {
                                 const double x = pre[e] * t;
-                                double o = sg * pm_log_quot(1 + x, 1 - x);
+                                double o = sg * pm_ps_log_ratio(x, P.ps_form);
                                 if (P.ps_clip > 0.0) {  // the comparisons are false for NaN, as on the CPU
                                     if (o > P.ps_clip) o = P.ps_clip;
                                     if (o < -P.ps_clip) o = -P.ps_clip;

@@ -183,7 +183,7 @@ __device__ __forceinline__ void check_pass_deg(msg_ptr mc, bool sbit, int alpha_
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             pre[k] = t;
-            th[k] = pm_tanh_half(v[k]);
+            th[k] = pm_ps_tanh_half(v[k], METHOD == 0);
             t *= th[k];
         }
         t = 1.0;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void check_pass_deg(msg_ptr mc, bool sbit, int alpha_
 #pragma unroll
         for (int k = D - 1; k >= 0; --k) {
             const double x = pre[k] * t;
-            double o = sg * pm_log_quot(1 + x, 1 - x);
+            double o = sg * pm_ps_log_ratio(x, METHOD == 0);
             if (ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
                 if (o > ps_clip) o = ps_clip;
                 if (o < -ps_clip) o = -ps_clip;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void check_pass_arm(int D, msg_ptr mc, bool sbit, int
 
 // DCLO .. DC: check degrees that occur (DC also sizes the message array);  DVLO .. DVHI: bit degrees that occur;  CPT / VPT: check / bit slots per thread;
 // MPT: LDS stride (power of two >= m);  NTMAX: table stride = largest workgroup this instantiation is launched with;
-// METHOD: 0 product-sum, 1 min-sum;  UPRIOR: uniform channel and no per-shot channel (prior in a scalar pair)
+// METHOD: 0 product-sum (two divisions per edge), 2 product-sum in the reference's operation order (portable_math.h), 1 min-sum;  UPRIOR: uniform channel and no per-shot channel (prior in a scalar pair)
 template <int DCLO, int DC, int DVLO, int DVHI, int CPT, int VPT, int MPT, int NTMAX, int MINW, int METHOD, bool UPRIOR>
 __global__ __launch_bounds__(NTMAX, MINW) void bp_class_kernel(const BpClassParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -158,7 +158,7 @@ __device__ __forceinline__ double flip_sign(double x, bool flip) {
 // DC / DV: edge slots per check / per bit (compile-time maxima)
 // CPT / VPT: checks / bits owned by one thread;  blockDim.x * CPT >= m, blockDim.x * VPT >= n
 // REG: every check has exactly DC edges and every bit exactly DV (no predication)
-// METHOD: 0 product-sum, 1 min-sum
+// METHOD: 0 product-sum (two divisions per edge), 2 product-sum in the reference's operation order (portable_math.h), 1 min-sum
 // MINW: minimum waves per SIMD the register allocation must allow (occupancy target)
 // MPT: compile-time check stride (0 = take P.mp); always a power of two and == blockDim.x * CPT,
 //      so LDS offsets k * MP * 8 become instruction immediates
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                                 pre[k] = t;
                                 th[k] = 1.0;
                                 if (REG || k < deg) {
-                                    th[k] = pm_tanh_half(v[k]);
+                                    th[k] = pm_ps_tanh_half(v[k], METHOD == 0);
                                     t *= th[k];
                                 }
                             }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(MAXNT, MINW) void bp_kernel(const BpParams P) {
                             for (int k = DC - 1; k >= 0; --k) {
                                 if (REG || k < deg) {
                                     const double x = pre[k] * t;
-                                    double o = sg * pm_log_quot(1 + x, 1 - x);
+                                    double o = sg * pm_ps_log_ratio(x, METHOD == 0);
                                     if (P.ps_clip > 0.0) {  // uniform; the comparisons are false for NaN, as on the CPU
                                         if (o > P.ps_clip) o = P.ps_clip;
                                         if (o < -P.ps_clip) o = -P.ps_clip;

@@ -46,6 +46,7 @@ struct BpLargeParams {
     int max_iter;
     double ms_scaling;
     double ps_clip;  // product-sum: 0 = none, C > 0 = check->bit messages clamped to [-C, C]
+    int ps_form;     // product-sum: 0 the reference's operation order (four divisions per edge), 1 two divisions (portable_math.h)
     int osd_enabled;
     int mp;                              // check stride of the message layout (m rounded up to 64)
     const uint8_t* __restrict__ synd;    // [B, m]
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(bp_large_threads(METHOD)) void bp_large_kernel(cons
                             pre[k] = t;
                             th[k] = 1.0;
                             if (k < deg) {
-                                th[k] = pm_tanh_half(v[k]);
+                                th[k] = pm_ps_tanh_half(v[k], P.ps_form);
                                 t *= th[k];
                             }
                         }
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(bp_large_threads(METHOD)) void bp_large_kernel(cons
                         for (int k = DC - 1; k >= 0; --k) {
                             if (k < deg) {
                                 const double x = pre[k] * t;
-                                double o = sg * pm_log_quot(1 + x, 1 - x);
+                                double o = sg * pm_ps_log_ratio(x, P.ps_form);
                                 if (P.ps_clip > 0.0) {
                                     if (o > P.ps_clip) o = P.ps_clip;
                                     if (o < -P.ps_clip) o = -P.ps_clip;

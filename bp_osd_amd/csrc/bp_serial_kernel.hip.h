@@ -32,6 +32,7 @@ struct BpSerialParams {
     int bp_method;  // 0 product-sum, 1 min-sum
     double ms_scaling;
     double ps_clip;
+    int ps_form;  // product-sum evaluation order (portable_math.h: pm_ps_tanh_half)
     int osd_enabled;
     int nlevels;
     const uint8_t* __restrict__ synd;     // [B, m]
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(BPS_NT) void bp_serial_kernel(const BpSerialParams 
                             if (P.bp_method == 0) {
                                 double prod = 1.0;
                                 for (int g = g0; g < g1; ++g)
-                                    if (g != e) prod *= pm_tanh_half(b2c[g]);
-                                msg = ((syn[c] & 1) ? -1.0 : 1.0) * pm_log_quot(1 + prod, 1 - prod);
+                                    if (g != e) prod *= pm_ps_tanh_half(b2c[g], P.ps_form);
+                                msg = ((syn[c] & 1) ? -1.0 : 1.0) * pm_ps_log_ratio(prod, P.ps_form);
                                 if (P.ps_clip > 0.0) {
                                     if (msg > P.ps_clip) msg = P.ps_clip;
                                     if (msg < -P.ps_clip) msg = -P.ps_clip;

@@ -729,8 +729,8 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
         return fail(nullptr, BPOSD_ERR_INVALID, "sort_tie_policy / weight_fn out of range");
     if (cfg->osd_e_bit_order < 0 || cfg->osd_e_bit_order > 1)
         return fail(nullptr, BPOSD_ERR_INVALID, "osd_e_bit_order must be 0 (LSB first) or 1 (MSB first)");
-    if (cfg->reserved[0] != 0)
-        return fail(nullptr, BPOSD_ERR_INVALID, "reserved config fields must be 0");
+    if (cfg->ps_math_form < 0 || cfg->ps_math_form > 1)
+        return fail(nullptr, BPOSD_ERR_INVALID, "ps_math_form must be 0 (the reference's operation order) or 1 (two divisions per edge)");
     if (cfg->schedule != 0 && cfg->schedule != 1) return fail(nullptr, BPOSD_ERR_INVALID, "schedule must be 0 (parallel) or 1 (serial)");
     if (!(cfg->ps_clip >= 0.0) || std::isinf(cfg->ps_clip)) return fail(nullptr, BPOSD_ERR_INVALID, "ps_clip must be 0 (off) or a finite positive bound");
     if (indptr[0] != 0) return fail(nullptr, BPOSD_ERR_INVALID, "csr_indptr[0] must be 0");

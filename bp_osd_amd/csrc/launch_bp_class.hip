@@ -55,7 +55,9 @@ static int launch_bp_class_shape(bposd_handle* h, const BpClassParams& C, bool u
 #define BPOSD_CLASS_MP(MPV)                                                                                              \
     if (h->class_mp == MPV) {                                                                                            \
         if (ms) return uprior ? launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_MS, 1, true>(h, C) : launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_MS, 1, false>(h, C); \
-        return uprior ? launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 0, true>(h, C) : launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 0, false>(h, C); \
+        if (h->cfg.ps_math_form) /* product-sum, two divisions per edge */                                               \
+            return uprior ? launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 0, true>(h, C) : launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 0, false>(h, C); \
+        return uprior ? launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 2, true>(h, C) : launch_bp_class_t<DCLO, DC, DVLO, DVHI, MPV, MINW_PS, 2, false>(h, C); \
     }
     BPOSD_CLASS_MP(256)
     BPOSD_CLASS_MP(512)

@@ -19,8 +19,12 @@ static int launch_bp_t(bposd_handle* h, const BpParams& P, int NT) {
         auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 1, MPT>;
         { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
-    } else {
+    } else if (h->cfg.ps_math_form) {  // product-sum, two divisions per edge
         auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 0, MPT>;
+        { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
+    } else {                            // product-sum in the reference's operation order (the default)
+        auto k = bp_kernel<DC, DV, CPT, VPT, MAXNT, MINW, REG, 2, MPT>;
         { int rc_lds = set_max_lds(h, (const void*)k, lds); if (rc_lds) return rc_lds; }
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, h->cur->stream, P);
     }

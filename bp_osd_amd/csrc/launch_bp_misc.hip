@@ -46,7 +46,7 @@ static int launch_bp_large_t(bposd_handle* h, BpLargeParams& P) {
 
 int launch_bp_large(bposd_handle* h, const BpParams& G) {
     BpLargeParams P{};
-    P.m = G.m; P.n = G.n; P.B = G.B; P.max_iter = G.max_iter; P.ms_scaling = G.ms_scaling; P.ps_clip = G.ps_clip;
+    P.m = G.m; P.n = G.n; P.B = G.B; P.max_iter = G.max_iter; P.ms_scaling = G.ms_scaling; P.ps_clip = G.ps_clip; P.ps_form = h->cfg.ps_math_form;
     P.osd_enabled = G.osd_enabled; P.mp = h->tab_mp;
     P.synd = G.synd; P.llr0 = G.llr0; P.sel = G.sel; P.llr0_alt = G.llr0_alt;
     P.chk_deg = h->d_chk_deg; P.var_deg = h->d_var_deg; P.var_pos = h->d_var_pos; P.var_ck = h->d_var_ck;
@@ -61,7 +61,7 @@ int launch_bp_large(bposd_handle* h, const BpParams& G) {
 int launch_bp_serial(bposd_handle* h, const BpParams& P) {
     BpSerialParams S{};
     S.m = P.m; S.n = P.n; S.E = h->E; S.B = P.B; S.max_iter = P.max_iter; S.bp_method = h->cfg.bp_method;
-    S.ms_scaling = P.ms_scaling; S.ps_clip = P.ps_clip; S.osd_enabled = P.osd_enabled; S.nlevels = h->nlevels;
+    S.ms_scaling = P.ms_scaling; S.ps_clip = P.ps_clip; S.ps_form = h->cfg.ps_math_form; S.osd_enabled = P.osd_enabled; S.nlevels = h->nlevels;
     S.synd = P.synd; S.llr0 = P.llr0; S.sel = P.sel; S.llr0_alt = P.llr0_alt;
     S.rp = h->d_rp; S.ci = h->d_ci; S.cp = h->d_cp; S.ce = h->d_ce; S.erow = h->d_erow;
     S.lvl_ptr = h->d_lvl_ptr; S.lvl_bits = h->d_lvl_bits;
@@ -85,7 +85,7 @@ int launch_bp_serial(bposd_handle* h, const BpParams& P) {
 int launch_bp_any(bposd_handle* h, const BpParams& P) {
     BpAnyParams A{};
     A.m = P.m; A.n = P.n; A.E = h->E; A.B = P.B; A.max_iter = P.max_iter; A.bp_method = h->cfg.bp_method;
-    A.ms_scaling = P.ms_scaling; A.ps_clip = P.ps_clip; A.osd_enabled = P.osd_enabled;
+    A.ms_scaling = P.ms_scaling; A.ps_clip = P.ps_clip; A.ps_form = h->cfg.ps_math_form; A.osd_enabled = P.osd_enabled;
     A.synd = P.synd; A.llr0 = P.llr0; A.sel = P.sel; A.llr0_alt = P.llr0_alt;
     A.rp = h->d_rp; A.ci = h->d_ci; A.cp = h->d_cp; A.ce = h->d_ce;
     A.out_bp = P.out_bp; A.out_osd0 = P.out_osd0; A.out_osdw = P.out_osdw; A.out_conv = P.out_conv; A.out_iters = P.out_iters;

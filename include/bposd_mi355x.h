@@ -72,7 +72,12 @@ typedef struct {
                                   w - 1 - b.  Only the tie between equally light patterns depends on it (the first one
                                   enumerated wins).  An UNVERIFIED-upstream-behaviour switch like sort_tie_policy /
                                   weight_fn; was reserved[0]: a zero-filled old config means LSB first */
-    int32_t reserved[1];       /* must be 0                                                  */
+    int32_t ps_math_form;      /* product-sum: evaluation order of the check update (bp_osd_amd/csrc/portable_math.h).  0 =
+                                  the reference's operation order -- tanh(b2c / 2), then log of the rounded quotient
+                                  (1 + x) / (1 - x): four divisions per edge; closest to the platform libm the reference calls
+                                  (188 of 2048 clipped BASELINE configs[2] shots differ from it in an integer output).  1 = two
+                                  divisions per edge (pm_tanh_half, pm_log_quot): 1.4 x the throughput, 207 of 2048.  Was
+                                  reserved[0]: a zero-filled old config means the reference order */
 } bposd_config;
 
 /* Number of visible HIP devices (0 if none / runtime unavailable). */

@@ -168,13 +168,13 @@ static void bp_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *converged,
     for (int it = 1; it <= d->max_iter; it++) {
         if (d->cfg.bp_method == 0) {
             /* a5 product-sum: forward/backward partial products of tanh(b2c/2) */
-            const int pm = d->cfg.ps_math == 1;
+            const int pm = d->cfg.ps_math;  /* 0 libm, 1 portable routines with two divisions per edge, 2 portable routines in the reference's operation order */
             for (int c = 0; c < m; c++) {
                 d->cand[c] = 0;
                 double temp = 1.0;
                 for (int e = d->rp[c]; e < d->rp[c + 1]; e++) {
                     d->c2b[e] = temp;
-                    temp *= pm ? pm_tanh_half(d->b2c[e]) : tanh(d->b2c[e] / 2);
+                    temp *= pm ? pm_ps_tanh_half(d->b2c[e], pm == 1) : tanh(d->b2c[e] / 2);
                 }
                 temp = 1;
                 for (int e = d->rp[c + 1] - 1; e >= d->rp[c]; e--) {
@@ -182,13 +182,13 @@ static void bp_decode(oracle_decoder *d, const uint8_t *syn, uint8_t *converged,
                     int message_sign = syn[c] ? -1 : 1;
                     /* ps_math = 1: the kernels' routines (portable_math.h, "round 4": same operation order, the quotient folded
                      * into the logarithm) */
-                    d->c2b[e] = message_sign * (pm ? pm_log_quot(1 + d->c2b[e], 1 - d->c2b[e]) : log((1 + d->c2b[e]) / (1 - d->c2b[e])));
+                    d->c2b[e] = message_sign * (pm ? pm_ps_log_ratio(d->c2b[e], pm == 1) : log((1 + d->c2b[e]) / (1 - d->c2b[e])));
                     if (d->cfg.ps_clip > 0) { /* build-owned switch; upstream does not clip (Appendix A.3 [M]) */
                         if (d->c2b[e] > d->cfg.ps_clip) d->c2b[e] = d->cfg.ps_clip;
                         if (d->c2b[e] < -d->cfg.ps_clip) d->c2b[e] = -d->cfg.ps_clip;
                     }
                     if (!d->diag_first_nonfinite && !isfinite(d->c2b[e])) d->diag_first_nonfinite = it;
-                    temp *= pm ? pm_tanh_half(d->b2c[e]) : tanh(d->b2c[e] / 2);
+                    temp *= pm ? pm_ps_tanh_half(d->b2c[e], pm == 1) : tanh(d->b2c[e] / 2);
                 }
             }
         } else {
@@ -279,7 +279,7 @@ static void bp_decode_serial(oracle_decoder *d, const uint8_t *syn, uint8_t *con
     const int m = d->m, n = d->n;
     int conv = 0, it_done = 0;
     d->diag_first_nonfinite = d->diag_has_inf = d->diag_has_nan = 0;
-    const int pm = d->cfg.ps_math == 1;
+    const int pm = d->cfg.ps_math;  /* 0 libm, 1 portable routines with two divisions per edge, 2 portable routines in the reference's operation order */
     for (int i = 0; i < n; i++)
         for (int k = d->cp[i]; k < d->cp[i + 1]; k++) d->b2c[d->ce[k]] = d->llr0[i];
     for (int it = 1; it <= d->max_iter; it++) {
@@ -294,8 +294,8 @@ static void bp_decode_serial(oracle_decoder *d, const uint8_t *syn, uint8_t *con
                 if (d->cfg.bp_method == 0) {
                     double prod = 1.0;
                     for (int g = d->rp[c]; g < d->rp[c + 1]; g++)
-                        if (g != e) prod *= pm ? pm_tanh_half(d->b2c[g]) : tanh(d->b2c[g] / 2);
-                    msg = (syn[c] ? -1 : 1) * (pm ? pm_log_quot(1 + prod, 1 - prod) : log((1 + prod) / (1 - prod)));
+                        if (g != e) prod *= pm ? pm_ps_tanh_half(d->b2c[g], pm == 1) : tanh(d->b2c[g] / 2);
+                    msg = (syn[c] ? -1 : 1) * (pm ? pm_ps_log_ratio(prod, pm == 1) : log((1 + prod) / (1 - prod)));
                     if (d->cfg.ps_clip > 0) {
                         if (msg > d->cfg.ps_clip) msg = d->cfg.ps_clip;
                         if (msg < -d->cfg.ps_clip) msg = -d->cfg.ps_clip;

@@ -44,9 +44,11 @@ typedef struct {
                                  (bits in ascending index, each bit's check->bit messages recomputed from the latest
                                  bit->check messages; SURVEY.md §8 f4, restated from memory like Appendix A) */
     int32_t ps_math;          /* product-sum only: 0 = tanh / log of the platform libm (what the reference calls);
-                                 1 = the bit-reproducible routines of bp_osd_amd/csrc/portable_math.h, which is what the
-                                 GPU kernels evaluate -- with 1 the oracle and the GPU agree bit for bit, with 0 they
-                                 differ by the libm's last-bit behaviour (tests state both bars) */
+                                 1 / 2 = the bit-reproducible routines of bp_osd_amd/csrc/portable_math.h, which is what the
+                                 GPU kernels evaluate: 2 in the reference's operation order (the kernels' default,
+                                 ps_math_form 0), 1 with two divisions per edge (ps_math_form 1) -- with the matching mode
+                                 the oracle and the GPU agree bit for bit, with 0 they differ by the libm's last-bit
+                                 behaviour (tests state both bars) */
     int32_t osd_e_bit_order;  /* osd_e: bit b of pattern i stands for T position b (0, LSB first) or w - 1 - b (1); only
                                  ties between equally light patterns depend on it.  UNVERIFIED upstream behaviour, a
                                  switch like sort_tie_policy */

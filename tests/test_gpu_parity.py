@@ -296,7 +296,7 @@ def test_product_sum_vs_oracle(gpu_ready, h1922):
     glibc's in the last bit on ~1 % of arguments -> tolerance parity, stated here (the bit-exact comparison against the
     oracle's portable-math mode is test_product_sum_clip_vs_oracle_live / test_config2_...): on shots that
     converge in the same iteration on both sides (>= 98% of shots) the integer outputs are identical
-    and LLRs agree to 1e-9 relative after clipping to +-30 on all but 3e-4 of entries; every output,
+    and LLRs agree to 1e-9 relative after clipping to +-30 on all but 1e-4 of entries (3e-4 for ps_math_form = 1); every output,
     converged or not, reproduces its syndrome; OSD outputs of non-converged shots are compared
     statistically (mean correction weight within 3%), see the comment at the end."""
     from bp_osd_amd import BpOsdDecoder
@@ -312,9 +312,15 @@ def test_product_sum_vs_oracle(gpu_ready, h1922):
     conv = same & r["converged"]
     assert (r["osdw"][conv] == ref["osdw"][conv]).all()
     bad, nanfrac = _ps_llr_mismatch_fraction(r["llr"][conv], ref["llr"][conv])
-    # (round 4: the kernels fold the quotient (1 + x) / (1 - x) into the logarithm -- one division instead of two -- so 8 % of
-    # their log evaluations differ from glibc's in the last bits instead of 2 %; measured here 1.5e-4, four-division form 0.6e-4)
-    assert bad <= 3e-4, (bad, nanfrac)
+    # (the default evaluation order, ps_math_form = 0: measured 0.6e-4.  The two-division form folds the quotient
+    # (1 + x) / (1 - x) into the logarithm, 8 % of its log evaluations differ from glibc's in the last bits instead of 2 %:
+    # 1.5e-4, checked below against its own bound)
+    assert bad <= 1e-4, (bad, nanfrac)
+    r1 = _gpu_decode(BpOsdDecoder(h1922.hz, ps_math_form=1, **kw), syn)
+    same1 = (r1["iters"] == ref["iters"]) & (r1["converged"] == ref["converged"].astype(bool))
+    assert same1.mean() >= 0.98, same1.mean()
+    bad1, _ = _ps_llr_mismatch_fraction(r1["llr"][same1 & r1["converged"]], ref["llr"][same1 & r1["converged"]])
+    assert bad1 <= 3e-4, bad1
     assert (_syndrome_of(h1922.hz, r["osdw"]) == syn).all()
     # Non-converged shots: the LLRs handed to OSD contain +-inf and NaN on both sides (saturated
     # messages), for which the reliability order is not even well defined in the reference (its
@@ -631,7 +637,7 @@ def test_large_code_rank_deficient_osd(gpu_ready):
     for clip in (0.0, 12.0):
         kw = dict(error_rate=0.06, max_iter=12, bp_method="ps", osd_method="osd_0", ps_clip=clip)
         r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
-        ref = OracleDecoder(H, ps_math=1, **kw).decode_batch(syn)
+        ref = OracleDecoder(H, ps_math=2, **kw).decode_batch(syn)
         assert (np.isnan(r["llr"]) == np.isnan(ref["llr"])).all()
         nonan = ~np.isnan(ref["llr"]).any(axis=1)
         _compare_exact({k: (v[nonan] if k == "llr" else v) for k, v in r.items()},
@@ -823,7 +829,7 @@ def test_class_kernel_equals_lds_kernel_and_oracle(gpu_ready, seed_file):
     cases = [
         dict(error_rate=q, max_iter=3000, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=9),
         dict(channel_probs=probs, max_iter=30, bp_method="ms", ms_scaling_factor=0.75, osd_method="osd_e", osd_order=6),
-        dict(error_rate=q, max_iter=25, bp_method="ps", ps_clip=20.0, ps_math=1, osd_method="osd_cs", osd_order=5),
+        dict(error_rate=q, max_iter=25, bp_method="ps", ps_clip=20.0, ps_math=2, osd_method="osd_cs", osd_order=5),
     ]
     for kw in cases:
         gkw = {k: v for k, v in kw.items() if k != "ps_math"}
@@ -867,7 +873,7 @@ def test_class_kernel_other_degree_families(gpu_ready, family):
     q = 0.06
     _, syn = _syndromes(H, q, 300, n)
     for kw in (dict(error_rate=q, max_iter=40, bp_method="ms", ms_scaling_factor=0, osd_method="osd_cs", osd_order=6),
-               dict(error_rate=q, max_iter=15, bp_method="ps", ps_clip=20.0, ps_math=1, osd_method="osd_e", osd_order=5)):
+               dict(error_rate=q, max_iter=15, bp_method="ps", ps_clip=20.0, ps_math=2, osd_method="osd_e", osd_order=5)):
         gkw = {k: v for k, v in kw.items() if k != "ps_math"}
         a = BpOsdDecoder(H, **gkw)
         ra = _gpu_decode(a, syn)
@@ -1224,7 +1230,10 @@ def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
     assert B >= 2048
     unpack = lambda k: np.unpackbits(g[k], axis=1)[:, :n]
     ref = dict(osdw=unpack("osdw"), osd0=unpack("osd0"), bp=unpack("bp"), converged=g["converged"].astype(bool), iters=g["iters"])
-    r = _gpu_decode(BpOsdDecoder(H, **cfg), syn)
+    # the *_pm fixtures froze the oracle's ps_math = 1 mode = the kernels' TWO-division form (ps_math_form = 1); the libm
+    # fixtures are compared with the kernels' default, the reference's operation order (ps_math_form = 0)
+    form = 1 if name.endswith("_pm") else 0
+    r = _gpu_decode(BpOsdDecoder(H, ps_math_form=form, **cfg), syn)
     assert (_syndrome_of(H, r["osdw"]) == syn).all() and (_syndrome_of(H, r["osd0"]) == syn).all()
 
     fin_g, gap_g, abs_g = _llr_margins(r["llr"])
@@ -1259,7 +1268,8 @@ def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
         # iteration of convergence (or a near-tie of the final order) on ~10 % of the others (measured: 188 of 2048 with the
         # four-division evaluation of rounds 1-3, 207 with round 4's two-division one; a ONE-division form that keeps tanh as a
         # fraction moved the roundings of 1 - x and changed 374 -- measured, not kept: portable_math.h)
-        assert (~same).mean() <= 0.15, (~same).mean()
+        # bound = the count measured for the default form (188) + 10 %
+        assert int((~same).sum()) <= 207, int((~same).sum())
     else:
         assert (clean | allnan).mean() >= 0.55, (clean | allnan).mean()
         assert (~same & rest).mean() <= 0.05, (~same & rest).mean()   # ulp-level events among the saturated, converged shots
@@ -1277,7 +1287,7 @@ def test_config2_product_sum_cs60_vs_golden(gpu_ready, h1922, name):
 
 def test_product_sum_clip_vs_oracle_live(gpu_ready, h1922, hgp400):
     """Product-sum through the whole stack against the live oracle: bit for bit (LLR doubles included) when the oracle
-    evaluates tanh / log with portable_math.h like the kernels do (ps_math = 1), and within the libm's last-bit noise
+    evaluates tanh / log with portable_math.h like the kernels do (ps_math = 2 / 1 for ps_math_form = 0 / 1), and within the libm's last-bit noise
     when it calls the platform libm as the reference does (ps_math = 0).  Several clip values, clipping off, two codes."""
     from bp_osd_amd import BpOsdDecoder
     from oracle import OracleDecoder
@@ -1286,29 +1296,31 @@ def test_product_sum_clip_vs_oracle_live(gpu_ready, h1922, hgp400):
         _, syn = _syndromes(H, q, B, 77)
         for clip in (0.0, 8.0, 20.0, 37.0):
             kw = dict(error_rate=q, max_iter=40, bp_method="ps", osd_method="osd_cs", osd_order=10, ps_clip=clip)
-            r = _gpu_decode(BpOsdDecoder(H, **kw), syn)
-            ref = OracleDecoder(H, ps_math=1, **kw).decode_batch(syn)
-            assert (np.isnan(r["llr"]) == np.isnan(ref["llr"])).all()
-            for k in ("converged", "iters", "bp"):  # BP itself: identical on every shot
-                assert (r[k] == ref[k]).all(), (k, clip)
-            # OSD on a vector that MIXES numbers and NaN (unclipped runs cut off at 40 iterations) has no defined order:
-            # the reference's comparator calls NaN equal to everything, so what its sort returns depends on the sort's
-            # internals.  Those shots must still reproduce their syndrome; every other shot is compared bit for bit.
-            mixed = np.isnan(ref["llr"]).any(axis=1) & ~np.isnan(ref["llr"]).all(axis=1)
-            assert clip == 0.0 or not mixed.any()
-            keep = ~mixed
-            nonan = keep & ~np.isnan(ref["llr"]).any(axis=1)
-            _compare_exact({k: (v[nonan] if k == "llr" else v[keep]) for k, v in r.items()},
-                           {k: (v[nonan] if k == "llr" else v[keep]) for k, v in ref.items()})
-            assert (_syndrome_of(H, r["osdw"]) == syn).all() and (_syndrome_of(H, r["osd0"]) == syn).all()
-            if clip > 0:
-                assert np.isfinite(r["llr"]).all()
-                lib = OracleDecoder(H, ps_math=0, **kw).decode_batch(syn)
-                same = (r["iters"] == lib["iters"]) & (r["converged"] == lib["converged"].astype(bool)) & \
-                       (r["osdw"] == lib["osdw"]).all(axis=1) & (r["osd0"] == lib["osd0"]).all(axis=1)
-                assert same.mean() >= 0.9, (clip, same.mean())
-                close = np.abs(r["llr"][same] - lib["llr"][same]) <= 1e-9 * (1 + np.abs(lib["llr"][same]))
-                assert close.mean() >= 0.99, close.mean()
+            # both evaluation orders: the reference's (default; oracle ps_math = 2) and two divisions per edge (ps_math = 1)
+            for form in (0, 1):
+                r = _gpu_decode(BpOsdDecoder(H, ps_math_form=form, **kw), syn)
+                ref = OracleDecoder(H, ps_math=2 - form, **kw).decode_batch(syn)
+                assert (np.isnan(r["llr"]) == np.isnan(ref["llr"])).all()
+                for k in ("converged", "iters", "bp"):  # BP itself: identical on every shot
+                    assert (r[k] == ref[k]).all(), (k, clip)
+                # OSD on a vector that MIXES numbers and NaN (unclipped runs cut off at 40 iterations) has no defined order:
+                # the reference's comparator calls NaN equal to everything, so what its sort returns depends on the sort's
+                # internals.  Those shots must still reproduce their syndrome; every other shot is compared bit for bit.
+                mixed = np.isnan(ref["llr"]).any(axis=1) & ~np.isnan(ref["llr"]).all(axis=1)
+                assert clip == 0.0 or not mixed.any()
+                keep = ~mixed
+                nonan = keep & ~np.isnan(ref["llr"]).any(axis=1)
+                _compare_exact({k: (v[nonan] if k == "llr" else v[keep]) for k, v in r.items()},
+                               {k: (v[nonan] if k == "llr" else v[keep]) for k, v in ref.items()})
+                assert (_syndrome_of(H, r["osdw"]) == syn).all() and (_syndrome_of(H, r["osd0"]) == syn).all()
+                if clip > 0:
+                    assert np.isfinite(r["llr"]).all()
+                    lib = OracleDecoder(H, ps_math=0, **kw).decode_batch(syn)
+                    same = (r["iters"] == lib["iters"]) & (r["converged"] == lib["converged"].astype(bool)) & \
+                           (r["osdw"] == lib["osdw"]).all(axis=1) & (r["osd0"] == lib["osd0"]).all(axis=1)
+                    assert same.mean() >= 0.9, (clip, same.mean())
+                    close = np.abs(r["llr"][same] - lib["llr"][same]) <= 1e-9 * (1 + np.abs(lib["llr"][same]))
+                    assert close.mean() >= 0.99, close.mean()
     with pytest.raises(ValueError):
         BpOsdDecoder(h1922.hz, error_rate=0.05, bp_method="ps", ps_clip=-1.0)
 
@@ -1430,7 +1442,7 @@ def test_serial_schedule_vs_oracle(gpu_ready, surface13, hgp400, h1922, bp_metho
             g = BpOsdDecoder(H, **full)
             assert g.schedule == "serial"
             r = _gpu_decode(g, syn)
-            ref = OracleDecoder(H, ps_math=1, **full).decode_batch(syn)
+            ref = OracleDecoder(H, ps_math=2, **full).decode_batch(syn)
             _compare_exact(r, ref)
             assert r["iters"][0] == 0 and r["converged"][0]
     # the serial schedule is a different decoder: far fewer sweeps than flooding on the same syndromes
@@ -1631,7 +1643,7 @@ def test_degree_class_codes_randomized_settings_vs_oracle(gpu_ready):
         _, syn = _syndromes(H, q, 120, trial)
         g = BpOsdDecoder(H, **kw)
         g.set_osd_variant(2 if rng.random() < 0.7 else 1)  # (auto would keep batches this small on the workgroup kernel)
-        o = OracleDecoder(H, ps_math=1, **kw)
+        o = OracleDecoder(H, ps_math=2, **kw)
         if chan == 2:  # per-shot two-valued channel (the harness's channel_update)
             sel = (rng.random((len(syn), n)) < 0.15).astype(np.uint8)
             alt = np.full(n, 0.3)
@@ -1683,7 +1695,7 @@ def test_any_degree_codes_vs_oracle(gpu_ready):
             g = BpOsdDecoder(Hs, **kw)
             r = _gpu_decode(g, syn)
             assert g.bp_kernel_info()["kernel"] == "bp_anydeg_kernel"
-            _compare_exact(r, OracleDecoder(Hs, ps_math=1, **kw).decode_batch(syn))
+            _compare_exact(r, OracleDecoder(Hs, ps_math=2, **kw).decode_batch(syn))
             assert r["iters"][0] == 0 and r["converged"][0]
         if m < 1000:  # per-shot two-valued channel
             sel = (rng.random((B, n)) < 0.2).astype(np.uint8)
