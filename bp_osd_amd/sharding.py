@@ -125,7 +125,9 @@ class StepPipeline:
         self.gather_fn = gather_fn
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.do_gather = bool(gather) and self.world > 1
+        # gather="force": run the exchange step at world size 1 too (bench.py --force-gather: the first execution of the RCCL
+        # backend and of the device-tensor gather on a one-GPU box)
+        self.do_gather = bool(gather) and (self.world > 1 or gather == "force")
         self.packed = packed
         self.nbuf = len(packed) if packed is not None else 0
         if self.do_gather and packed is not None and self.nbuf < self.nslots:
