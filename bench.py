@@ -689,6 +689,10 @@ def measure(P, rank, local_rank, world):
             "achieved": lds_achieved, "peak": lds_peak_gbs, "unit": "GB/s",
             "frac": lds_achieved / lds_peak_gbs if lds_peak_gbs > 0 else None,
             "frac_isolated": out["roofline_lds"]["frac_isolated"],
+            # the same bound over the STEP (ms_per_step: BP, OSD and everything else of a step in steady state, consecutive steps
+            # overlapped) -- a launch's own duration always carries its max_iter = n straggler tail (2.3 ms on H1922), which a
+            # single persistent launch cannot hide and the next step's launch does
+            "frac_of_step": bound_ms(avg_iters) / (1e3 * elapsed / steps) if elapsed > 0 else None,
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_ms": avg_bp_ms, "isolated_launch_ms": t_last["bp_ms"],
             "hbm_algorithmic_frac": hbm_algo_gbs / HBM_PEAK_GBS, "hbm_algorithmic": hbm_algorithmic,
@@ -846,7 +850,7 @@ def summary(rec):
         "workload": rec["config"]["workload"], "per_gpu_batch": rec["config"]["per_gpu_batch"], "steps": rec["steps"], "warmup": rec["warmup"],
         "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
         "kernel_ms": rec["kernel_ms"], "kernel_ms_isolated": rec["kernel_ms_isolated"],
-        "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_isolated", "hbm_algorithmic_frac")},
+        "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_isolated", "frac_of_step", "hbm_algorithmic_frac")},
         **({"roofline_osd": {k: rec["roofline_osd"].get(k) for k in ("bound", "frac", "frac_isolated", "avg_launch_ms", "isolated_launch_ms")}}
            if "roofline_osd" in rec else {}),
         "cross_kernel_check": rec["cross_kernel_check"], "math_form": rec["math_form"],

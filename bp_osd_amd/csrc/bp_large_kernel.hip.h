@@ -47,6 +47,7 @@ struct BpLargeParams {
     double ms_scaling;
     double ps_clip;  // product-sum: 0 = none, C > 0 = check->bit messages clamped to [-C, C]
     int ps_form;     // product-sum: 0 the reference's operation order (four divisions per edge), 1 two divisions (portable_math.h)
+    int packed_io;   // 1: synd is [B][ceil(m/64)] and out_bp / out_osd0 / out_osdw are rows of ceil(n/64) little-endian 64-bit words
     int osd_enabled;
     int mp;                              // check stride of the message layout (m rounded up to 64)
     const uint8_t* __restrict__ synd;    // [B, m]
@@ -125,11 +126,12 @@ __global__ __launch_bounds__(bp_large_threads(METHOD)) void bp_large_kernel(cons
             break;
         }
         const uint8_t* syn = P.synd + (size_t)s * m;
+        const unsigned long long* synw = (const unsigned long long*)P.synd + (size_t)s * (size_t)((m + 63) >> 6);  // (packed_io)
 
         // mismatch bitmap = syndrome; messages = priors; decisions = 0
         for (int c0 = tid - lane; c0 < m; c0 += NT) {
             const int c = c0 + lane;
-            const bool sb = (c < m) && (syn[c] & 1);
+            const bool sb = (c < m) && (P.packed_io ? ((synw[c >> 6] >> (c & 63)) & 1ull) != 0ull : (syn[c] & 1) != 0);
             const unsigned long long bal = __ballot(sb);
             if (lane == 0) {
                 diffw[c0 >> 5] = (unsigned int)bal;
@@ -383,6 +385,28 @@ __global__ __launch_bounds__(bp_large_threads(METHOD)) void bp_large_kernel(cons
         }
         __syncthreads();
         const int slot = to_osd ? sh[3] : 0;
+        if (P.packed_io) {
+            // bit-packed result rows: bit (i & 63) of word (i >> 6) = entry i (the hard decisions are 64-bit words already in the
+            // LDS form; bits beyond n are cleared)
+            const int wpn = (n + 63) >> 6;
+            for (int w = tid; w < wpn; w += NT) {
+                unsigned long long v = 0ull;
+                if (RLDS) {
+                    v = decw[w];
+                    if (64 * w + 64 > n) v &= (1ull << (n - 64 * w)) - 1ull;
+                } else {
+                    for (int b = 0; b < 64 && 64 * w + b < n; ++b) v |= (unsigned long long)(dec[64 * w + b] & 1) << b;
+                }
+                const size_t o = (size_t)s * wpn + w;
+                if (P.out_bp) ((unsigned long long*)P.out_bp)[o] = v;
+                if (!to_osd) {
+                    ((unsigned long long*)P.out_osdw)[o] = v;
+                    if (P.out_osd0) ((unsigned long long*)P.out_osd0)[o] = v;
+                }
+            }
+            if (to_osd)
+                for (int i = tid; i < n; i += NT) P.llr_ws[(size_t)slot * n + i] = llrt[i];
+        } else
         for (int i = tid; i < n; i += NT) {
             const size_t o = (size_t)s * n + i;
             const uint8_t b = RLDS ? (uint8_t)((decw[i >> 6] >> (i & 63)) & 1ull) : dec[i];

@@ -837,6 +837,7 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     const int shp = h->bp_any ? 0 : pick_shape(h);
     h->bp_hbm = !h->bp_any && (!shp || bp_lds_bytes(pair.dc, shape_threads(h, shp) * shape_cpt(shp)) > h->lds_per_cu);
     h->large = (m > 1024) || (osd_words(n) == 0) || h->bp_hbm;
+    if (const char* e = getenv("BPOSD_FORCE_LARGE_OSD")) h->large = h->large || e[0] == '1';  // (probe: the HBM-resident OSD kernel on a small code)
     if (h->large) {
         h->nlanes = 2;
         if (const char* e = getenv("BPOSD_LARGE_LANES")) h->nlanes = std::max(1, std::min(BPOSD_LANES, atoi(e)));
@@ -1230,7 +1231,7 @@ int bposd_decode_batch_device_packed(bposd_handle* h, const uint64_t* d_synd_wor
                                      uint64_t* d_osd0_words, uint64_t* d_bp_words, uint8_t* d_conv, int32_t* d_iters) {
     if (!h) return BPOSD_ERR_INVALID;
     if (!native_packed(h))
-        return fail(h, BPOSD_ERR_UNSUPPORTED, "this code's kernels take byte rows (HBM-resident path, any-degree or serial-schedule kernel): "
+        return fail(h, BPOSD_ERR_UNSUPPORTED, "this code's kernels take byte rows (any-degree or serial-schedule kernel): "
                     "use bposd_decode_batch_device and bposd_pack_rows_device");
     h->packed_now = true;
     const int rc = decode_device_impl(h, (const uint8_t*)d_synd_words, B, nullptr, (uint8_t*)d_osdw_words, (uint8_t*)d_osd0_words,

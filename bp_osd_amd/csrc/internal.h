@@ -189,7 +189,7 @@ int osd_large_maxspan(bool cs);
 // do the kernels this handle runs read packed syndromes / write packed rows themselves (else unpack / pack kernels surround them)?
 inline bool native_packed(const bposd_handle* h) {
     // (forced local-edge variants 16 .. 26 have no packed instantiation; the LDS and class kernels switch at run time)
-    return !h->large && !h->bp_any && h->cfg.schedule == 0 && h->bp_variant != 64 && !(h->bp_variant >= 16 && h->bp_variant <= 26);
+    return !h->bp_any && h->cfg.schedule == 0 && h->bp_variant != 64 && !(h->bp_variant >= 16 && h->bp_variant <= 26);
 }
 
 }  // namespace bposd_host

@@ -52,7 +52,7 @@ int launch_bp_large(bposd_handle* h, const BpParams& G) {
     P.chk_deg = h->d_chk_deg; P.var_deg = h->d_var_deg; P.var_pos = h->d_var_pos; P.var_ck = h->d_var_ck;
     P.out_bp = G.out_bp; P.out_osd0 = G.out_osd0; P.out_osdw = G.out_osdw; P.out_conv = G.out_conv;
     P.out_iters = G.out_iters; P.out_llr = G.out_llr; P.llr_ws = G.llr_ws; P.osd_list = G.osd_list;
-    P.counters = G.counters; P.iter_total = G.iter_total; P.tail_flag = G.tail_flag;
+    P.counters = G.counters; P.iter_total = G.iter_total; P.tail_flag = G.tail_flag; P.packed_io = G.packed_io;
     if (h->dc_max <= 12 && h->dv_max <= 6) return launch_bp_large_t<12, 6>(h, P);
     if (h->dc_max <= 16 && h->dv_max <= 8) return launch_bp_large_t<16, 8>(h, P);
     return fail(h, BPOSD_ERR_UNSUPPORTED, "check degree %d / bit degree %d exceed the built kernels (16 / 8)", h->dc_max, h->dv_max);

@@ -24,7 +24,7 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     while (Q.nsort < h->n) Q.nsort <<= 1;
     Q.mrl = OSDL_NT * RPT;
     Q.synd = P.synd; Q.rp = P.rp; Q.ci = P.ci; Q.llr_ws = P.llr_ws; Q.osd_list = P.osd_list; Q.counters = P.counters;
-    Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.cmp_osd0 = P.cmp_osd0; Q.cmp_osdw = P.cmp_osdw; Q.rank_out = d_rank_out; Q.dbg = P.dbg;
+    Q.packed_io = P.packed_io; Q.out_osd0 = P.out_osd0; Q.out_osdw = P.out_osdw; Q.cmp_osd0 = P.cmp_osd0; Q.cmp_osdw = P.cmp_osdw; Q.rank_out = d_rank_out; Q.dbg = P.dbg;
     // fp64 index-order candidate weights (non-uniform channel) -- only OSD-E / OSD-CS rank candidates
     const bool fpw = P.cost != nullptr && Q.osd_method >= BPOSD_OSD_E && Q.osd_order > 0;
     Q.cost = fpw ? P.cost : nullptr; Q.sel = fpw ? P.sel : nullptr; Q.cost_alt = P.cost_alt;

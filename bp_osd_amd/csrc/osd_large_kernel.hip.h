@@ -121,6 +121,7 @@ struct OsdLargeParams {
     unsigned long long* __restrict__ am64_ws;  // [grid][mrl] nullable
     unsigned long long* __restrict__ cm64_ws;  // [grid][n]   nullable: per original bit, its entries in the first <= 64 non-pivot columns
     int wdn;                                // max(64 * W, 2^16)
+    int packed_io;                          // 1: synd is [B][ceil(m/64)] words, out_* / cmp_* are rows of ceil(n/64) 64-bit words (osd_kernel.hip.h)
 };
 
 constexpr int OSDL_MAXPAIRS = OSDL_MAXSPAN * (OSDL_MAXSPAN - 1) / 2;
@@ -427,7 +428,7 @@ __device__ __attribute__((noinline)) void osdl_sort(unsigned long long* keys_, i
 // read-modify-write of the word), 33 per row, 528 per thread.  A function of its own (see osdl_sort).
 template <int RPT>
 __device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_, const int* rp_, const int* ci_, const int* inv_, const uint8_t* synd_,
-                                                          long long s, int m, int W, int MRL) {
+                                                          long long s, int m, int W, int MRL, int packed) {
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     typedef __attribute__((address_space(1))) int g_i32;
     typedef __attribute__((address_space(1))) uint8_t g_u8;
@@ -444,7 +445,8 @@ __device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_
         if (r < m) {
             constexpr int CH = 12;  // edges per batch (the degree of a check of the codes this path serves; more: further batches)
             const int e0 = rp[r], e1 = rp[r + 1];
-            const bool sb = (synd[(size_t)s * m + r] & 1) != 0;
+            const bool sb = packed ? ((((const __attribute__((address_space(1))) unsigned long long*)synd)[(size_t)s * (size_t)((m + 63) >> 6) + (r >> 6)] >> (r & 63)) & 1ull) != 0ull
+                                   : (synd[(size_t)s * m + r] & 1) != 0;
             for (int eb = e0; eb < e1 || eb == e0; eb += CH) {
                 int jj[CH + 1];
 #pragma unroll
@@ -865,7 +867,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, M + (size_t)x * MRL, ro + k * NT * 8) = 0ull;
         }
         __syncthreads();
-        osdl_build_rows<RPT>(M, P.rp, P.ci, inv, P.synd, s, m, W, (int)MRL);
+        osdl_build_rows<RPT>(M, P.rp, P.ci, inv, P.synd, s, m, W, (int)MRL, P.packed_io);
         if (tid < 2 * OSDL_NW) pcol[tid] = 64u;
         if (tid == 0) misc[8] = 0;  // mask bits of the open groups
         __syncthreads();
@@ -1808,10 +1810,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             if (usedk && y[k]) xout[kidx[rowpos[tid + k * NT]]] = 1;
         }
         __syncthreads();
-        if (P.out_osd0)
-            for (int i = tid; i < n; i += NT) P.out_osd0[(size_t)s * n + i] = xout[i];
-        if (P.cmp_osd0)
-            for (int i = tid; i < n; i += NT) P.cmp_osd0[(size_t)slot_id * n + i] = xout[i];
+        osd_store_row(P.out_osd0, P.packed_io, (size_t)s, n, xout, tid, NT);
+        osd_store_row(P.cmp_osd0, P.packed_io, (size_t)slot_id, n, xout, tid, NT);
         OSDL_TICK(14);
         int w0 = 0;
         for (int q = 0; q < NCV; ++q) w0 += __popcll(yvec[q]);
@@ -2077,10 +2077,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         OSDL_TICK(15);
         // ------------------------------------------------- write the OSD-W solution
         if (sel_a == -1) {
-            for (int i = tid; i < n; i += NT) {
-                P.out_osdw[(size_t)s * n + i] = xout[i];
-                if (P.cmp_osdw) P.cmp_osdw[(size_t)slot_id * n + i] = xout[i];
-            }
+            osd_store_row(P.out_osdw, P.packed_io, (size_t)s, n, xout, tid, NT);
+            osd_store_row(P.cmp_osdw, P.packed_io, (size_t)slot_id, n, xout, tid, NT);
         } else {
             __syncthreads();
             for (int i = tid; i < n; i += NT) xout[i] = 0;
@@ -2119,10 +2117,8 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 }
             }
             __syncthreads();
-            for (int i = tid; i < n; i += NT) {
-                P.out_osdw[(size_t)s * n + i] = xout[i];
-                if (P.cmp_osdw) P.cmp_osdw[(size_t)slot_id * n + i] = xout[i];
-            }
+            osd_store_row(P.out_osdw, P.packed_io, (size_t)s, n, xout, tid, NT);
+            osd_store_row(P.cmp_osdw, P.packed_io, (size_t)slot_id, n, xout, tid, NT);
         }
         __syncthreads();
         OSDL_TICK(16);

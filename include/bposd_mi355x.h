@@ -150,7 +150,7 @@ int bposd_decode_batch_device(bposd_handle *h, const uint8_t *d_syndromes, int64
 
 /* The device-pointer call with bit-packed rows (the layout of bposd_decode_batch_packed; every pointer a device pointer):
  * the kernels read packed syndromes and write packed result rows themselves -- no pack kernel between the decode and the
- * multi-GPU gather.  Codes on the HBM-resident path (m > 1024 or n > 2047), on the any-degree BP kernel or with the serial
+ * multi-GPU gather (the HBM-resident kernels included, since round 5).  Codes on the any-degree BP kernel or with the serial
  * schedule return BPOSD_ERR_UNSUPPORTED: there bposd_decode_batch_device + bposd_pack_rows_device do the same.
  * Asynchronous like bposd_decode_batch_device. */
 int bposd_decode_batch_device_packed(bposd_handle *h, const uint64_t *d_syndrome_words, int64_t B, uint64_t *d_osdw_words,

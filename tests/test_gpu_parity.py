@@ -1950,8 +1950,9 @@ def test_async_host_api_stream_of_batches(gpu_ready, h1922, hgp4050):
 
 def test_device_pointer_packed_api_with_torch(gpu_ready, h1922, hgp400, hgp4050):
     """bposd_decode_batch_device_packed: packed syndromes and packed result rows in device memory, written by the kernels
-    themselves (local-edge, class and generic BP kernels; workgroup, wave and multi-wave OSD kernels) -- equal to the byte API;
-    the HBM-resident path refuses it (there the byte rows are packed by bposd_pack_rows_device)."""
+    themselves (local-edge, class and generic BP kernels; workgroup, wave and multi-wave OSD kernels; since round 5 the
+    HBM-resident BP and OSD kernels too: the 2025 x 4050 case) -- equal to the byte API; the any-degree kernel and the serial
+    schedule refuse it (there the byte rows are packed by bposd_pack_rows_device)."""
     import torch
 
     from bp_osd_amd import BpOsdDecoder
@@ -1961,7 +1962,9 @@ def test_device_pointer_packed_api_with_torch(gpu_ready, h1922, hgp400, hgp4050)
     cases = [(h1922.hz, 20000, 0.06, dict(max_iter=30, osd_method="osd_cs", osd_order=7), 0),
              (hgp400.hz, 9000, 0.07, dict(max_iter=10, osd_method="osd_cs", osd_order=42), 0),
              (hgp400.hx, 5000, 0.07, dict(max_iter=10, osd_method="osd_e", osd_order=6), 1),     # generic LDS BP kernel, workgroup OSD kernel
-             (hgp(rep_code(21), compute_logicals=False).hz, 6000, 0.06, dict(max_iter=8, osd_method="osd_cs", osd_order=9), 0)]  # osd_mw_kernel
+             (hgp(rep_code(21), compute_logicals=False).hz, 6000, 0.06, dict(max_iter=8, osd_method="osd_cs", osd_order=9), 0),  # osd_mw_kernel
+             (hgp4050.hz, 700, 0.06, dict(max_iter=8, osd_method="osd_cs", osd_order=7), 0),    # bp_large_kernel + osd_large_kernel (Gauss-Jordan)
+             (hgp4050.hz, 300, 0.06, dict(max_iter=6, osd_method="osd_e", osd_order=5), 0)]     # ... Gaussian mode
     for H, B, q, kw, variant in cases:
         m, n = H.shape
         _, syn = _syndromes(H, q, B, 321)
@@ -1983,6 +1986,6 @@ def test_device_pointer_packed_api_with_torch(gpu_ready, h1922, hgp400, hgp4050)
         for k in ("osdw", "osd0", "bp"):
             assert (d.unpack_rows(o[k].cpu().numpy().view(np.uint64), n) == want[k]).all(), (H.shape, k)
         assert (conv.cpu().numpy().astype(bool) == want["conv"]).all() and (iters.cpu().numpy() == want["iters"]).all()
-    big = BpOsdDecoder(hgp4050.hz, error_rate=0.05, max_iter=4, bp_method="ms", osd_method="osd0")
+    ser = BpOsdDecoder(hgp400.hz, error_rate=0.05, max_iter=4, bp_method="ms", osd_method="osd0", schedule="serial")
     with pytest.raises(ValueError):
-        big.decode_batch_device_packed(d_syn.data_ptr(), 1, o["osdw"].data_ptr())
+        ser.decode_batch_device_packed(d_syn.data_ptr(), 1, o["osdw"].data_ptr())
