@@ -193,7 +193,11 @@ typedef const unsigned long long* osdl_lds_ptr;
 typedef volatile __attribute__((address_space(3))) unsigned long long* osdl_lds_w64;
 typedef volatile __attribute__((address_space(3))) unsigned int* osdl_lds_w32;
 constexpr int OSDL_E2C_CAP = 2048;   // longest panel list (rows); beyond it the all-rows form runs (4096: measured, no gain)
-constexpr int OSDL_MW_MIN = 1024;    // lists longer than this are searched by all sixteen waves (512 / 256: measured, 6 % slower)
+#ifndef OSDL_MW_MIN
+#define OSDL_MW_MIN 512   // lists longer than this are searched by all sixteen waves.  Rounds 2-4: 1024 (512 / 256 measured 6 % slower then); with the
+                          // lightest-row choice the sixteen-entries-per-lane instance of the one-wave loop spilled 63 dwords, and lists beyond 512 rows have
+                          // become rare (pivot rows are no longer listed in Gaussian mode, fill-in is steered)
+#endif
 
 // Which ROW becomes the pivot of a column is free (the pivot SET, hence every output, does not depend on it -- SURVEY.md
 // Appendix A.4: upstream takes the lowest-weight row "only" to limit fill-in).  Round 5: among the candidates of a column the
@@ -1347,12 +1351,12 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                         if (gauss) {
                             if (nnz <= 128) osdl_e2_compact_wave<2, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                             else if (nnz <= 256) osdl_e2_compact_wave<4, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
-                            else if (nnz <= 512) osdl_e2_compact_wave<8, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                            else if (nnz <= 512 || OSDL_MW_MIN < 1024) osdl_e2_compact_wave<8, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                             else osdl_e2_compact_wave<16, true>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                         } else {
                             if (nnz <= 128) osdl_e2_compact_wave<2, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                             else if (nnz <= 256) osdl_e2_compact_wave<4, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
-                            else if (nnz <= 512) osdl_e2_compact_wave<8, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
+                            else if (nnz <= 512 || OSDL_MW_MIN < 1024) osdl_e2_compact_wave<8, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                             else osdl_e2_compact_wave<16, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                         }
                     }
