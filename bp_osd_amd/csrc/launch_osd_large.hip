@@ -32,32 +32,52 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     long long grid = std::min<long long>(B, h->num_cu);
     if (grid < 1) grid = 1;
     auto a256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    // every sub-array is [grid][count], laid out back to back in one allocation
-    const size_t g = (size_t)grid;
     const bool wide_cs = Q.osd_method == BPOSD_OSD_CS && Q.osd_order > OSDL_MAXSPAN;
     const bool wide_fp = wide_cs && fpw;  // fp64 weights over a pair span beyond 16: 64-bit column words per row / per bit in HBM
     const bool gauss = Q.osd_method != BPOSD_OSD_CS;  // Gaussian elimination + back-substitution: every pivot group keeps its rows
     Q.pro_stride = gauss ? osd_large_pro_rows(Q.W) * 64 : (size_t)OSDL_K * Q.W * 64;
-    const size_t sizes[18] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
-                             g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
-                             g * sizeof(int) * (size_t)Q.nsort,                    // kidx
-                             g * sizeof(int) * (size_t)h->n,                       // inv
-                             g * sizeof(int) * (size_t)64 * Q.W,                   // pivrow
-                             g * sizeof(int) * (size_t)Q.mrl,                      // rowpos
-                             g * sizeof(int) * (size_t)64 * Q.W,                   // wt
-                             g * (size_t)h->n,                                     // xout
-                             g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.mrl,        // tmo
-                             g * sizeof(unsigned long long) * Q.pro_stride,                  // pro
-                             fpw ? g * sizeof(double) * (size_t)h->n : 0,                    // costs_ws
-                             fpw ? g * sizeof(double) * (size_t)Q.wdn : 0,                   // wd_ws
-                             fpw ? g * sizeof(unsigned short) * (size_t)Q.mrl : 0,           // am_ws
-                             g * sizeof(int) * (size_t)Q.mrl,                                // alist
-                             wide_cs ? g * sizeof(unsigned long long) * (size_t)OSDL_MAXSPAN_CS * RPT * OSDL_NW : 0,  // colvec_ws
-                             wide_fp ? g * sizeof(unsigned long long) * (size_t)Q.mrl : 0,                   // am64_ws
-                             wide_fp ? g * sizeof(unsigned long long) * (size_t)h->n : 0,                    // cm64_ws
-                             gauss ? g * sizeof(unsigned long long) * (size_t)64 * Q.W : 0};                 // pmask
-    size_t total = 0;
-    for (size_t b : sizes) total += a256(b);
+    size_t sizes[18];
+    // every sub-array is [grid][count], laid out back to back in one allocation
+    auto layout = [&](size_t g) {
+        const size_t sz[18] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
+                               g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
+                               g * sizeof(int) * (size_t)Q.nsort,                    // kidx
+                               g * sizeof(int) * (size_t)h->n,                       // inv
+                               g * sizeof(int) * (size_t)64 * Q.W,                   // pivrow
+                               g * sizeof(int) * (size_t)Q.mrl,                      // rowpos
+                               g * sizeof(int) * (size_t)64 * Q.W,                   // wt
+                               g * (size_t)h->n,                                     // xout
+                               g * sizeof(unsigned long long) * (size_t)OSDL_K * Q.mrl,        // tmo
+                               g * sizeof(unsigned long long) * Q.pro_stride,                  // pro
+                               fpw ? g * sizeof(double) * (size_t)h->n : 0,                    // costs_ws
+                               fpw ? g * sizeof(double) * (size_t)Q.wdn : 0,                   // wd_ws
+                               fpw ? g * sizeof(unsigned short) * (size_t)Q.mrl : 0,           // am_ws
+                               g * sizeof(int) * (size_t)Q.mrl,                                // alist
+                               wide_cs ? g * sizeof(unsigned long long) * (size_t)OSDL_MAXSPAN_CS * RPT * OSDL_NW : 0,  // colvec_ws
+                               wide_fp ? g * sizeof(unsigned long long) * (size_t)Q.mrl : 0,                   // am64_ws
+                               wide_fp ? g * sizeof(unsigned long long) * (size_t)h->n : 0,                    // cm64_ws
+                               gauss ? g * sizeof(unsigned long long) * (size_t)64 * Q.W : 0};                 // pmask
+        size_t t = 0;
+        for (int i = 0; i < 18; ++i) { sizes[i] = sz[i]; t += a256(sz[i]); }
+        return t;
+    };
+    size_t total = layout((size_t)grid);
+    // The workspace is allocated on every lane of the handle (the packed matrix plus, in Gaussian mode, the kept pivot rows of
+    // every group: 61 + 54.5 MB per workgroup on the 14520 x 29524 code = 29.6 GB per lane at 256 workgroups).  Where the device
+    // cannot hold that, fewer workgroups share the queue instead of a hipMalloc failing in the middle of a decode.
+    if (total > h->lanes[0].osdl_ws.bytes) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
+        size_t have = 0;
+        for (int l = 0; l < h->nlanes; ++l) have += h->lanes[l].osdl_ws.bytes;   // (released before the larger block is allocated)
+        const size_t budget = (size_t)((double)(free_b + have) * 0.92);
+        const size_t per_wg = layout(1) * (size_t)h->nlanes;
+        if (per_wg > budget)
+            return fail(h, BPOSD_ERR_HIP, "the HBM-resident OSD kernel needs %.2f GB of workspace per workgroup (%d lanes); %.2f GB are free", per_wg * 1e-9,
+                        h->nlanes, free_b * 1e-9);
+        if (total * (size_t)h->nlanes > budget) grid = std::max<long long>(1, (long long)(budget / per_wg));
+        total = layout((size_t)grid);
+    }
     int rc = ensure_lanes(h, &Lane::osdl_ws, total);
     if (rc) return rc;
     unsigned char* ptrs[18];

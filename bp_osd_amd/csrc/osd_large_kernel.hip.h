@@ -194,9 +194,9 @@ typedef volatile __attribute__((address_space(3))) unsigned long long* osdl_lds_
 typedef volatile __attribute__((address_space(3))) unsigned int* osdl_lds_w32;
 constexpr int OSDL_E2C_CAP = 2048;   // longest panel list (rows); beyond it the all-rows form runs (4096: measured, no gain)
 #ifndef OSDL_MW_MIN
-#define OSDL_MW_MIN 512   // lists longer than this are searched by all sixteen waves.  Rounds 2-4: 1024 (512 / 256 measured 6 % slower then); with the
-                          // lightest-row choice the sixteen-entries-per-lane instance of the one-wave loop spilled 63 dwords, and lists beyond 512 rows have
-                          // become rare (pivot rows are no longer listed in Gaussian mode, fill-in is steered)
+#define OSDL_MW_MIN 1024  // lists longer than this are searched by all sixteen waves (512 / 256: measured 6 % slower in round 4; 512 again in round 5, when
+                          // the sixteen-entries-per-lane instance of the one-wave loop had begun to spill 63 dwords under the lightest-row keys:
+                          // l29k_ms_e15 10.39 k against 10.26 k syndromes/s, OSD alone 96.8 against 102 ms -- the spilling instance still wins)
 #endif
 
 // Which ROW becomes the pivot of a column is free (the pivot SET, hence every output, does not depend on it -- SURVEY.md

@@ -229,7 +229,9 @@ class BpOsdDecoder:
         """Host-pointer decode of bit-packed rows into caller-owned C-contiguous arrays: ``uint64 [B, ceil(m/64)]`` in,
         ``uint64 [B, ceil(n/64)]`` out (page-locked arrays from :meth:`pinned_empty` make the copies asynchronous).
         ``wait=False``: the call is only enqueued (``bposd_decode_batch_packed_async``) and the lane to
-        :meth:`synchronize` on is returned; the arrays must stay untouched until then."""
+        :meth:`synchronize` on is returned (None for an empty batch); the arrays must stay untouched until then (the decoder
+        keeps them referenced).  One handle serves one caller thread at a time: the per-call mode flags live on
+        the handle."""
         self._timing_override = None
         wm, wn = (self.m + 63) // 64, (self.n + 63) // 64
         s = syndrome_words
@@ -247,9 +249,15 @@ class BpOsdDecoder:
                 raise ValueError(f"{name} must be a C-contiguous {np.dtype(dt).name} array of shape {shp}")
         ptr = lambda a: a.ctypes.data if a is not None else None
         fn = self._lib.bposd_decode_batch_packed if wait else self._lib.bposd_decode_batch_packed_async
-        rc = fn(self._h, s.ctypes.data, B, ptr(osdw_words), ptr(osd0_words), ptr(bp_words), ptr(converged), ptr(iters)) if B else 0
+        if B == 0:
+            return osdw_words if wait else None  # nothing was enqueued: no lane to wait for
+        rc = fn(self._h, s.ctypes.data, B, ptr(osdw_words), ptr(osd0_words), ptr(bp_words), ptr(converged), ptr(iters))
         _lib.check(self._lib, self._h, rc)
-        return osdw_words if wait else self.last_lane
+        if wait:
+            return osdw_words
+        lane = self.last_lane
+        self._hold(lane, s, osdw_words, osd0_words, bp_words, converged, iters)
+        return lane
 
     def decode_batch(self, syndromes, want_osd0=True, want_bp=True, want_llr=False, prior_select=None,
                      alt_channel_probs=None, packed=False):
@@ -496,8 +504,17 @@ class BpOsdDecoder:
         """Wait for everything queued on this decoder, or (``lane``) for the calls queued on one lane only."""
         if lane is None:
             _lib.check(self._lib, self._h, self._lib.bposd_synchronize(self._h))
+            self._inflight = {}
         else:
             _lib.check(self._lib, self._h, self._lib.bposd_synchronize_lane(self._h, int(lane)))
+            getattr(self, "_inflight", {}).pop(int(lane), None)
+
+    def _hold(self, lane, *arrays):
+        """An asynchronous host call hands raw pointers to enqueued copies: the arrays (page-locked ones are freed by a
+        finalizer when dropped) stay referenced here until the lane has been synchronised."""
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight.setdefault(int(lane), []).extend(a for a in arrays if a is not None)
 
     @property
     def num_lanes(self):
@@ -553,9 +570,15 @@ class BpOsdDecoder:
                 raise ValueError(f"{name} must be a C-contiguous {np.dtype(dt).name} array of shape {shp}")
         ptr = lambda a: a.ctypes.data if a is not None else None
         fn = self._lib.bposd_decode_batch if wait else self._lib.bposd_decode_batch_async
-        rc = fn(self._h, s.ctypes.data, B, ptr(osdw), ptr(osd0), ptr(bp), ptr(converged), ptr(iters), ptr(llr)) if B else 0
+        if B == 0:
+            return osdw if wait else None  # nothing was enqueued: no lane to wait for
+        rc = fn(self._h, s.ctypes.data, B, ptr(osdw), ptr(osd0), ptr(bp), ptr(converged), ptr(iters), ptr(llr))
         _lib.check(self._lib, self._h, rc)
-        return osdw if wait else self.last_lane
+        if wait:
+            return osdw
+        lane = self.last_lane
+        self._hold(lane, s, osdw, osd0, bp, converged, iters, llr)
+        return lane
 
     def last_timing(self):
         """dict(bp_ms, osd_ms, bp_iterations, osd_invocations) of the last decode call (HIP events).  Small host-pointer
