@@ -1624,10 +1624,15 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 }
                 // ------------ E3: pivot rows of the new group at its start state, for every later word.
                 // One wave per word, wave-private tables (a wave's LDS operations complete in order).
-                // (Round 5, measured and not kept: in Gaussian mode the new pivot rows are final, so the older open groups can be applied
+                // (Round 5, measured and not kept: (i) in Gaussian mode the new pivot rows are final, so the older open groups can be applied
                 // to THEM in M by a sparse pass over just these <= 64 rows, which leaves a plain copy of E3 -- exact, and slower:
                 // E3 30 M -> 45 M cycles per elimination, l29k_ms_e15 10.4 k -> 9.6 k syndromes/s.  A sparse pass costs ~4.5 k cycles
                 // per 8-word chunk whatever it carries -- barrier, staging three chunks ahead -- times 29 chunks, per group.)
+                // (ii) E3 on the set bits of the new pivot rows' masks -- one entry list per group, per word the older groups' pivot
+                // words staged in wave-private LDS and XORed into per-slot accumulators by ds_xor_b64, four words in flight: a
+                // fifth of the instructions of the table form, exact, and no faster (E3 30 -> 32-36 M cycles): the phase is
+                // bound by its gather of 64 scattered row words per word (one cache line each in the word-major matrix, ~4-5
+                // cycles per lane through the vector-memory path), which both forms share.
                 if (w + 1 < W) osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, w, ng, npiv);
                 ++ng;
                 __syncthreads();  // PRO of the new group is visible
