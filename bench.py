@@ -914,6 +914,8 @@ def main():
             e = copy.copy(args)
             e.label, e.config, e.batch, e.gen = label, cfg, batch, gen
             e.steps, e.warmup, e.host_steps, e.cpu_procs = args.extra_steps, 1, 0, 0
+            if cfg.startswith("l29k"):  # (100 ms steps whose first two still warm the workspaces up: a few more, for a number close to the one of record)
+                e.steps, e.warmup = 2 * args.extra_steps, 2
             e.cpu_sample = CPU_SAMPLE_EXTRA.get(cfg, 0) if gen == "numpy" else 0
             e.nbatch = 1
             runs.append(e)

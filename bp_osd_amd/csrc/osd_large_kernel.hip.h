@@ -587,7 +587,9 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
 #ifndef OSDL_SPARSE_LIST
 #define OSDL_SPARSE_LIST 6144  // passes with at most this many mask bits take the sparse form (eight entries per walking thread)
 #endif
-__device__ __attribute__((noinline)) void osdl_apply_sparse(unsigned long long* U_, const int* alist_, const unsigned long long* TmO_,
+// Returns 1 when the pass was done, 0 -- nothing touched -- when the rows' mask bits do not fit the list after all (the caller's
+// count is an upper bound; this is the belt to its braces).
+__device__ __attribute__((noinline)) int osdl_apply_sparse(unsigned long long* U_, const int* alist_, const unsigned long long* TmO_,
                                                             const unsigned long long* PRO_, unsigned long long* M_, const int* gnp_, const int* gbo_,
                                                             int MRL, int W, int xlo, int ng, int nact) {
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
@@ -658,7 +660,9 @@ __device__ __attribute__((noinline)) void osdl_apply_sparse(unsigned long long* 
         }
     }
     __syncthreads();
-    const int nent = *ecount < OSDL_SPARSE_LIST ? *ecount : OSDL_SPARSE_LIST;  // (the caller takes this form only when the bits fit)
+    const int nent = __builtin_amdgcn_readfirstlane(*ecount);
+    if (nent > OSDL_SPARSE_LIST) return 0;  // (uniform) the caller takes the table form
+    if (nent == 0) return 1;
     // ---- The pass is a chain of short steps (a few hundred cycles of LDS work per chunk), and anything a step WAITS for from
     // HBM costs it a round trip (~6 k cycles with 250 eliminations in flight).  Two things keep waits off the steps' path:
     // (i) a row's words are not loaded at all -- the change goes out as a returnless 64-bit atomic XOR per changed word
@@ -762,6 +766,7 @@ __device__ __attribute__((noinline)) void osdl_apply_sparse(unsigned long long* 
     // The atomics were performed in the L2; this CU's vector L1 may still hold lines of M from before.  Agent-scope acquire =
     // invalidate the L1.
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return 1;
 }
 
 // (The apply pass as a non-inlined function of its own was measured too: 90 -> 104-113 M cycles per elimination -- its list build and
@@ -933,15 +938,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             OSDL_TICK(20);
             // sparse masks (the rule in Gaussian mode): walk the set bits, no tables -- osdl_apply_sparse
             const bool sparse_pass = OSDL_SPARSE_LIST > 0 && nact > 0 && xlo < W && passbits <= OSDL_SPARSE_LIST;
+            bool sparse_done = false;
             if (sparse_pass) {
-                OSDL_COUNT(12);
                 OSDL_TICK(5);
-                osdl_apply_sparse(U, alist, TmO, PRO, M, gnp, gbo, (int)MRL, W, xlo, ng, nact);
+                sparse_done = osdl_apply_sparse(U, alist, TmO, PRO, M, gnp, gbo, (int)MRL, W, xlo, ng, nact) != 0;
                 OSDL_TICK(24);
-                OSDL_ADD(25, nact);
-                OSDL_ADD(26, passbits);
+                if (sparse_done) { OSDL_COUNT(12); OSDL_ADD(25, nact); OSDL_ADD(26, passbits); }
             }
-            for (int x0 = xlo; x0 < W && nact > 0 && !sparse_pass; x0 += OSDL_CW) {
+            for (int x0 = xlo; x0 < W && nact > 0 && !sparse_done; x0 += OSDL_CW) {
                 OSDL_FRESH_TID();
                 const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
                 OSDL_TICK(5);

@@ -213,3 +213,19 @@ def test_local_edge_layout_model_regression(lib):
     assert out[1] == 128 and out[15] == 384 and out[4] == 1024
     assert out[0] <= 240 and out[14] <= 430 and out[3] <= 2
     assert out[5:14].sum() == H.shape[0]
+
+
+def test_bench_batches_are_prefix_stable():
+    """bench.py reuses the headline's seeded batch for the 65536-syndrome configurations: numpy's generator is consumed row by
+    row, so the first B rows of a longer batch of the same seed ARE the batch of B rows (errors and syndromes)."""
+    import bench
+    from bp_osd_amd.codes import surface13
+
+    H = surface13().hz
+    bench._BATCH_CACHE.clear()
+    e_small, s_small = bench.make_batch(H, 0.1, 40, seed=5, chunk=16)
+    e_big, s_big = bench.make_batch(H, 0.1, 100, seed=5, chunk=16, cache_key="s13")
+    assert (e_big[:40] == e_small).all() and (s_big[:40] == s_small).all()
+    e_hit, s_hit = bench.make_batch(H, 0.1, 40, seed=5, chunk=16, cache_key="s13")  # served from the cached longer batch
+    assert e_hit.base is not None and (e_hit == e_small).all() and (s_hit == s_small).all()
+    assert ((H @ e_small.T.astype(int)) % 2 == s_small.T).all()
