@@ -570,6 +570,117 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                         }
 }
 
+// E1c as a function of its own (round 5): every thread brings the panel word of its RPT rows up to date with the open groups and
+// appends the non-zero ones to the LDS list.  In the kernel body this ran in batches of four rows, each batch waiting for its own
+// loads (four dependent round trips per panel, ~6 k cycles each with 250 eliminations in flight), and looked every row's four
+// masks up in the nibble tables -- although fewer than one row in fifty has a non-zero mask in an open group (`anymask`).  Here
+// the words of ALL my rows and the masks of my first TWO rows that have any (a thread seldom owns more) are requested together
+// and waited for once; only those rows go through the tables; further such rows take a loop of their own.  Lanes without a
+// masked row read their own panel word again in the masks' place (the line has just been requested: no traffic of its own),
+// so the number of requests is a constant and nothing waits early.  Returns the bit set of my rows whose stored word is
+// non-zero but whose up-to-date word is zero (they are cleared in M by the caller).
+template <int RPT>
+__device__ __attribute__((noinline)) unsigned int osdl_e1c_list(const unsigned long long* Mw_, const unsigned long long* TmO_, const unsigned long long* U_,
+                                                                unsigned long long* Lpw_, unsigned int* Lid_, int* cnt_, const int* gnp_, int MRL, int ng,
+                                                                unsigned int skipmask, unsigned int anymask, unsigned int usedmask) {
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    typedef volatile __attribute__((address_space(3))) unsigned long long l_u64;
+    typedef volatile __attribute__((address_space(3))) unsigned int l_u32;
+    typedef __attribute__((address_space(3))) int l_i32;
+    auto uni = [](const void* p_) {
+        const unsigned long long a = (unsigned long long)p_;
+        return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(a >> 32)) << 32) |
+               (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+    };
+    auto lds = [](const void* p_) { return (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(const __attribute__((address_space(3))) char*)p_); };
+    const g_u64* Mw = (const g_u64*)uni(Mw_);
+    const g_u64* TmO = (const g_u64*)uni(TmO_);
+    l_u64* U = (l_u64*)(size_t)lds(U_);
+    l_u64* Lpw = (l_u64*)(size_t)lds(Lpw_);
+    l_u32* Lid = (l_u32*)(size_t)lds(Lid_);
+    l_i32* cnt = (l_i32*)(size_t)lds(cnt_);
+    const l_i32* gnp = (const l_i32*)(size_t)lds(gnp_);
+    MRL = __builtin_amdgcn_readfirstlane(MRL);
+    ng = __builtin_amdgcn_readfirstlane(ng);
+    constexpr int NT = OSDL_NT;
+    constexpr int CAP = OSDL_E2C_CAP;
+    const int tid = threadIdx.x, lane = threadIdx.x & 63;
+    const unsigned int need = anymask & ~skipmask;  // my rows with a non-zero mask in some open group
+    const int s0 = need ? (int)__builtin_ctz(need) : -1;
+    const unsigned int need1 = need & (need - 1u);
+    const int s1 = need1 ? (int)__builtin_ctz(need1) : -1;
+    unsigned int rest = need1 & (need1 - 1u);
+    unsigned long long old[RPT], m0[OSDL_K], m1[OSDL_K];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) old[k] = Mw[tid + k * NT];
+#pragma unroll
+    for (int g = 0; g < OSDL_K; ++g) {
+        // (the address goes through an opaque register: otherwise the compiler sees that the stand-in IS old[0], waits for it and puts
+        // the real load under a branch -- two round trips again)
+        unsigned long long a0 = (unsigned long long)((g < ng && s0 >= 0) ? TmO + (size_t)g * MRL + tid + s0 * NT : Mw + tid);
+        unsigned long long a1 = (unsigned long long)((g < ng && s1 >= 0) ? TmO + (size_t)g * MRL + tid + s1 * NT : Mw + tid);
+        asm volatile("" : "+v"(a0), "+v"(a1));
+        m0[g] = *(const g_u64*)a0;
+        m1[g] = *(const g_u64*)a1;
+    }
+    // the nibble tables: U[(g * 16 + grp) * 16 + nibble]
+    auto delta = [&](const unsigned long long (&mm)[OSDL_K]) {
+        unsigned long long d = 0ull;
+#pragma unroll
+        for (int g = 0; g < OSDL_K; ++g) {
+            if (g < ng) {
+                const int ngrp = (gnp[g] + 3) >> 2;
+                for (int grp = 0; grp < ngrp; ++grp) d ^= U[(g * 16 + grp) * 16 + (int)((mm[g] >> (4 * grp)) & 15ull)];
+            }
+        }
+        return d;
+    };
+    unsigned long long d0 = 0ull, d1 = 0ull;
+    if (s0 >= 0) d0 = delta(m0);
+    if (s1 >= 0) d1 = delta(m1);
+    unsigned long long v[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        old[k] = ((skipmask >> k) & 1u) ? 0ull : old[k];
+        v[k] = old[k] ^ (k == s0 ? d0 : 0ull) ^ (k == s1 ? d1 : 0ull);
+    }
+    // a thread with more than two masked rows (rare): one row at a time
+    while (__ballot(rest != 0u) != 0ull) {
+        if (rest != 0u) {
+            const int sk = (int)__builtin_ctz(rest);
+            rest &= rest - 1u;
+            unsigned long long mm[OSDL_K];
+#pragma unroll
+            for (int g = 0; g < OSDL_K; ++g) mm[g] = g < ng ? TmO[(size_t)g * MRL + tid + sk * NT] : 0ull;
+            const unsigned long long d = delta(mm);
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) v[k] ^= (k == sk) ? d : 0ull;
+        }
+    }
+    unsigned int zmask = 0u;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        // list positions: ONE LDS atomic per wave and row slot (the wave's entries are consecutive)
+        const bool nz = v[k] != 0ull;
+        const unsigned long long bal = __ballot(nz);
+        int base = 0;
+        if (bal) {  // uniform
+            if (lane == (int)__builtin_ctzll(bal)) base = __hip_atomic_fetch_add((int*)cnt, __popcll(bal), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(bal));
+        }
+        if (nz) {
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < CAP) {
+                Lpw[pos] = v[k];
+                Lid[pos] = (unsigned int)(tid + k * NT) | (((usedmask >> k) & 1u) << 31);
+            }
+        } else if (old[k] != 0ull) {
+            zmask |= 1u << k;
+        }
+    }
+    return zmask;
+}
+
 // AP, sparse form (round 5).  The table walk of the apply pass costs the same whatever the rows' combination masks hold: per
 // listed row and word one look-up per 5-bit field of every open group (46 of 52 on L29k, measured), although with plain
 // Gaussian elimination a pass lists ~300 rows with 4-5 mask bits each (tools/fillin_sim.c) -- 96 % of the look-ups return entry
@@ -1159,66 +1270,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 Lnew[threadIdx.x] = 0;
                 Lany[threadIdx.x] = 0;
                 __syncthreads();  // tables, counter
-                unsigned int zmask = 0u;  // rows whose stored word is non-zero but whose up-to-date word is zero
                 const unsigned int skipmask = frozenmask | (jordan ? usedmask : 0u);  // rows that are not listed
                 const unsigned int usedbefore = usedmask;
-                {
-                    const unsigned int ro = osdl_opaque((unsigned int)tid * 8u);
-                    // rows per batch: a batch's panel words AND its masks in all open groups are requested together (one round trip per
-                    // batch; with the masks fetched group by group behind the words it was 1 + ng round trips per batch, ten per
-                    // panel word at four open groups)
-                    constexpr int HB = RPT < 4 ? RPT : 4;
-#pragma unroll
-                    for (int k0 = 0; k0 < RPT; k0 += HB) {
-                        unsigned long long old[HB], v[HB], mk[OSDL_K][HB];
-#pragma unroll
-                        for (int i = 0; i < HB; ++i)
-                            old[i] = ((skipmask >> (k0 + i)) & 1u) ? 0ull : OSDL_AT(unsigned long long, M + (size_t)w * MRL, ro + (k0 + i) * NT * 8);
-#pragma unroll
-                        for (int g = 0; g < OSDL_K; ++g)
-#pragma unroll
-                            for (int i = 0; i < HB; ++i)
-                                mk[g][i] = (g < ng && (((anymask & ~skipmask) >> (k0 + i)) & 1u) != 0u) ? OSDL_AT(unsigned long long, TmO + (size_t)g * MRL, ro + (k0 + i) * NT * 8) : 0ull;
-                        if (HB == 4)
-                            asm volatile("" : "+v"(old[0]), "+v"(old[1]), "+v"(old[HB > 2 ? 2 : 0]), "+v"(old[HB > 3 ? 3 : 0]), "+v"(mk[0][0]), "+v"(mk[0][1]),
-                                         "+v"(mk[0][HB > 2 ? 2 : 0]), "+v"(mk[0][HB > 3 ? 3 : 0]), "+v"(mk[1][0]), "+v"(mk[1][1]), "+v"(mk[1][HB > 2 ? 2 : 0]),
-                                         "+v"(mk[1][HB > 3 ? 3 : 0]), "+v"(mk[2][0]), "+v"(mk[2][1]), "+v"(mk[2][HB > 2 ? 2 : 0]), "+v"(mk[2][HB > 3 ? 3 : 0]),
-                                         "+v"(mk[3][0]), "+v"(mk[3][1]), "+v"(mk[3][HB > 2 ? 2 : 0]), "+v"(mk[3][HB > 3 ? 3 : 0]));
-                        static_assert(OSDL_K == 4, "the statement above names the masks of four groups");
-#pragma unroll
-                        for (int i = 0; i < HB; ++i) v[i] = old[i];
-#pragma unroll
-                        for (int g = 0; g < OSDL_K; ++g) {
-                            if (g < ng) {
-                                const int ngrp = (gnp[g] + 3) >> 2;
-#pragma unroll
-                                for (int i = 0; i < HB; ++i)
-                                    for (int grp = 0; grp < ngrp; ++grp) v[i] ^= U[(g * 16 + grp) * 16 + (int)((mk[g][i] >> (4 * grp)) & 15ull)];
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < HB; ++i) {
-                            // list positions: ONE LDS atomic per wave and row slot (the wave's entries are consecutive) -- one per
-                            // entry serialised up to 16 k atomics on a single LDS word per panel
-                            const bool nz = v[i] != 0ull;
-                            const unsigned long long bal = __ballot(nz);
-                            int base = 0;
-                            if (bal) {  // uniform
-                                if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(&misc[7], __popcll(bal));
-                                base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(bal));
-                            }
-                            if (nz) {
-                                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                                if (pos < CAP) {
-                                    Lpw[pos] = v[i];
-                                    Lid[pos] = (unsigned int)((int)threadIdx.x + (k0 + i) * NT) | (((usedmask >> (k0 + i)) & 1u) << 31);
-                                }
-                            } else if (old[i] != 0ull) {
-                                zmask |= 1u << (k0 + i);
-                            }
-                        }
-                    }
-                }
+                // rows whose stored word is non-zero but whose up-to-date word is zero
+                const unsigned int zmask = osdl_e1c_list<RPT>(M + (size_t)w * MRL, TmO, U, Lpw, Lid, &misc[7], gnp, (int)MRL, ng, skipmask, anymask, usedmask);
                 __syncthreads();
                 OSDL_TICK(22);  // (E1c: panel words brought up to date and listed)
                 const int nnz = misc[7];
