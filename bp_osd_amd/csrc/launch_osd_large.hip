@@ -36,10 +36,10 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     const bool wide_fp = wide_cs && fpw;  // fp64 weights over a pair span beyond 16: 64-bit column words per row / per bit in HBM
     const bool gauss = Q.osd_method != BPOSD_OSD_CS;  // Gaussian elimination + back-substitution: every pivot group keeps its rows
     Q.pro_stride = gauss ? osd_large_pro_rows(Q.W) * 64 : (size_t)OSDL_K * Q.W * 64;
-    size_t sizes[18];
+    size_t sizes[20];
     // every sub-array is [grid][count], laid out back to back in one allocation
     auto layout = [&](size_t g) {
-        const size_t sz[18] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
+        const size_t sz[20] = {g * sizeof(unsigned long long) * (size_t)Q.W * Q.mrl,  // mat
                                g * sizeof(unsigned long long) * (size_t)Q.nsort,     // keys
                                g * sizeof(int) * (size_t)Q.nsort,                    // kidx
                                g * sizeof(int) * (size_t)h->n,                       // inv
@@ -56,9 +56,11 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
                                wide_cs ? g * sizeof(unsigned long long) * (size_t)OSDL_MAXSPAN_CS * RPT * OSDL_NW : 0,  // colvec_ws
                                wide_fp ? g * sizeof(unsigned long long) * (size_t)Q.mrl : 0,                   // am64_ws
                                wide_fp ? g * sizeof(unsigned long long) * (size_t)h->n : 0,                    // cm64_ws
-                               gauss ? g * sizeof(unsigned long long) * (size_t)64 * Q.W : 0};                 // pmask
+                               gauss ? g * sizeof(unsigned long long) * (size_t)64 * Q.W : 0,                  // pmask
+                               g * sizeof(unsigned long long) * (size_t)Q.mrl,                                 // cnz
+                               g * sizeof(unsigned long long) * (size_t)OSDL_K * 64};                          // gcnz
         size_t t = 0;
-        for (int i = 0; i < 18; ++i) { sizes[i] = sz[i]; t += a256(sz[i]); }
+        for (int i = 0; i < 20; ++i) { sizes[i] = sz[i]; t += a256(sz[i]); }
         return t;
     };
     size_t total = layout((size_t)grid);
@@ -80,10 +82,10 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     }
     int rc = ensure_lanes(h, &Lane::osdl_ws, total);
     if (rc) return rc;
-    unsigned char* ptrs[18];
+    unsigned char* ptrs[20];
     {
         unsigned char* base = (unsigned char*)h->cur->osdl_ws.p;
-        for (int i = 0; i < 18; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
+        for (int i = 0; i < 20; ++i) { ptrs[i] = base; base += a256(sizes[i]); }
     }
     Q.alist = (int*)ptrs[13];
     Q.colvec_ws = wide_cs ? (unsigned long long*)ptrs[14] : nullptr;
@@ -103,6 +105,8 @@ int launch_osd_large(bposd_handle* h, const OsdParams& P, long long B, int* d_ra
     Q.tmo = (unsigned long long*)ptrs[8];
     Q.pro = (unsigned long long*)ptrs[9];
     Q.pmask = gauss ? (unsigned long long*)ptrs[17] : nullptr;
+    Q.cnz = (unsigned long long*)ptrs[18];
+    Q.gcnz = (unsigned long long*)ptrs[19];
     const size_t lds = osd_large_lds_bytes(Q.W, RPT, fpw ? h->n : 0);
     if (lds > h->lds_per_cu) return fail(h, BPOSD_ERR_UNSUPPORTED, "large OSD kernel needs %zu bytes of LDS", lds);
 #define OSDL_LAUNCH(R)                                                                                      \

@@ -106,6 +106,8 @@ struct OsdLargeParams {
                                             // combination mask within its own group, own bit included
     int* __restrict__ alist;                // [grid][mrl]     rows the apply pass still updates (compacted, ascending)
     uint8_t* __restrict__ xout;             // [grid][n]
+    unsigned long long* __restrict__ cnz;   // [grid][mrl]  per row: bit c set when the STORED words 8c .. 8c+7 may be non-zero (a superset; E3 skips the rest)
+    unsigned long long* __restrict__ gcnz;  // [grid][OSDL_K * 64]  the same for the start-state pivot rows of the open groups
     long long* __restrict__ dbg;            // nullable: phase clocks of list slot 0 (s_memtime ticks)
     int* __restrict__ rank_out;             // nullable: [0] = pivots found for list slot 0 (ctor-time rank probe)
     // fp64 candidate weights (non-uniform channel); all null / unused when the channel is uniform
@@ -432,7 +434,7 @@ __device__ __attribute__((noinline)) void osdl_sort(unsigned long long* keys_, i
 // read-modify-write of the word), 33 per row, 528 per thread.  A function of its own (see osdl_sort).
 template <int RPT>
 __device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_, const int* rp_, const int* ci_, const int* inv_, const uint8_t* synd_,
-                                                          long long s, int m, int W, int MRL, int packed) {
+                                                          long long s, int m, int W, int MRL, int packed, unsigned long long* cnz_) {
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     typedef __attribute__((address_space(1))) int g_i32;
     typedef __attribute__((address_space(1))) uint8_t g_u8;
@@ -449,6 +451,7 @@ __device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_
         if (r < m) {
             constexpr int CH = 12;  // edges per batch (the degree of a check of the codes this path serves; more: further batches)
             const int e0 = rp[r], e1 = rp[r + 1];
+            unsigned long long cz = 0ull;  // the row's chunk map: bit (word >> 3)
             const bool sb = packed ? ((((const __attribute__((address_space(1))) unsigned long long*)synd)[(size_t)s * (size_t)((m + 63) >> 6) + (r >> 6)] >> (r & 63)) & 1ull) != 0ull
                                    : (synd[(size_t)s * m + r] & 1) != 0;
             for (int eb = e0; eb < e1 || eb == e0; eb += CH) {
@@ -458,6 +461,9 @@ __device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_
 #pragma unroll
                 for (int i = 0; i < CH; ++i) jj[i] = (jj[i] >= 0) ? inv[jj[i]] : -1;
                 jj[CH] = (eb == e0 && sb) ? (W - 1) * 64 + 63 : -1;  // the syndrome column, with the first batch
+#pragma unroll
+                for (int i = 0; i <= CH; ++i)
+                    if (jj[i] >= 0) cz |= 1ull << (jj[i] >> 9);
 #pragma unroll
                 for (int i = 0; i <= CH; ++i) {
                     if (jj[i] < 0) continue;
@@ -477,6 +483,9 @@ __device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_
                 }
                 if (e1 == e0) break;
             }
+            ((__attribute__((address_space(1))) unsigned long long*)cnz_)[r] = cz;
+        } else if (r < MRL) {
+            ((__attribute__((address_space(1))) unsigned long long*)cnz_)[r] = 0ull;
         }
     }
 }
@@ -486,7 +495,7 @@ __device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_
 // (the kernel sits at its 128-VGPR cap: inside it, more than one word in flight per wave went to scratch and ran slower).
 __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long* U, const int* grow_, const int* gnp_, const unsigned long long* TmO_,
                                                               unsigned long long* PRO_, const int* gbo_, const unsigned long long* M_, int MRL, int W, int w,
-                                                              int ng, int npiv) {
+                                                              int ng, int npiv, const unsigned long long* cnz_, unsigned long long* pcz_) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // The pointers arrive generic.  Left so, every access below is a FLAT instruction, which counts on the vector-memory AND the
@@ -505,6 +514,12 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                         typedef volatile __attribute__((address_space(3))) unsigned long long* lds_rw;
                         lds_rw tw = (lds_rw)(U + (size_t)wave * (OSDL_K - 1) * 256);
                         const int row = (lane < npiv) ? grow[ng * 64 + lane] : 0;
+                        // Round 5: the row's chunk map (bit c: its STORED words 8c .. 8c+7 may be non-zero; kept conservatively by the
+                        // build and the apply passes).  The lightest-row choice makes pivot rows of rows that absorbed little, so most of
+                        // their stored words are zero -- and this phase is bound by its gather of 64 scattered row words per word.  A
+                        // lane whose map clears the chunk reads the start of the matrix instead (one line for all such lanes).
+                        const unsigned long long mycz = (lane < npiv) ? ((const g_u64*)cnz_)[row] : 0ull;
+                        unsigned long long pmap = 0ull;  // chunks in which my pivot row's START state is non-zero
                         unsigned long long mrow[OSDL_K - 1];
     #pragma unroll
                         for (int g = 0; g < OSDL_K - 1; ++g) mrow[g] = (g < ng && lane < npiv) ? TmO[(size_t)g * MRL + row] : 0ull;
@@ -523,14 +538,16 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                                 const g_u64* src = PRO + ((long long)gbo[builder ? tg : 0] + xx) * 64 + q0;
     #pragma unroll
                                 for (int kk = 0; kk < 4; ++kk) prq[d][kk] = src[kk];
-                                mvq[d] = M[(size_t)xx * MRL + row];
+                                unsigned long long ma = (unsigned long long)(((mycz >> (xx >> 3)) & 1ull) ? M + (size_t)xx * MRL + row : M);
+                                asm volatile("" : "+v"(ma));  // (an opaque address: the request count stays a constant, nothing waits early)
+                                mvq[d] = *(const g_u64*)ma;
                             }
                         };
                         auto process = [&](int d, int x) {
                             unsigned long long pr[4];
     #pragma unroll
                             for (int kk = 0; kk < 4; ++kk) pr[kk] = (builder && kk < tnp) ? prq[d][kk] : 0ull;
-                            unsigned long long v = (lane < npiv) ? mvq[d] : 0ull;
+                            unsigned long long v = (lane < npiv && ((mycz >> (x >> 3)) & 1ull)) ? mvq[d] : 0ull;
                             issue(d, x + OSDL_NW * OSDL_E3D);  // this stage's registers are free again
                             if (builder) {
                                 unsigned int idx = osdl_opaque(((unsigned int)lane >> 1) & 15u);  // conflict-free start entries
@@ -558,6 +575,7 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                                 }
                             }
                             PRO[((long long)gbo[ng] + x) * 64 + lane] = v;
+                            pmap |= (v != 0ull) ? (1ull << (x >> 3)) : 0ull;
                             __builtin_amdgcn_wave_barrier();
                         };
                         const int xs = w + 1 + wave;
@@ -568,6 +586,8 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                             for (int d = 0; d < OSDL_E3D; ++d)
                                 if (x + d * OSDL_NW < W) process(d, x + d * OSDL_NW);
                         }
+                        // the sixteen waves' shares of the new pivot rows' maps meet in LDS (zeroed by the caller before its barrier)
+                        if (pmap) __hip_atomic_fetch_or((unsigned long long*)(pcz_ + lane), pmap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // E1c as a function of its own (round 5): every thread brings the panel word of its RPT rows up to date with the open groups and
@@ -702,7 +722,7 @@ __device__ __attribute__((noinline)) unsigned int osdl_e1c_list(const unsigned l
 // count is an upper bound; this is the belt to its braces).
 __device__ __attribute__((noinline)) int osdl_apply_sparse(unsigned long long* U_, const int* alist_, const unsigned long long* TmO_,
                                                             const unsigned long long* PRO_, unsigned long long* M_, const int* gnp_, const int* gbo_,
-                                                            int MRL, int W, int xlo, int ng, int nact) {
+                                                            int MRL, int W, int xlo, int ng, int nact, unsigned long long* cnz_, const unsigned long long* gcnz_) {
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     typedef __attribute__((address_space(1))) int g_i32;
     typedef __attribute__((address_space(1))) char g_char;
@@ -723,6 +743,8 @@ __device__ __attribute__((noinline)) int osdl_apply_sparse(unsigned long long* U
     const g_u64* TmO = (const g_u64*)uni(TmO_);
     const g_u64* PRO = (const g_u64*)uni(PRO_);
     g_u64* M = (g_u64*)uni(M_);
+    g_u64* cnz = (g_u64*)uni(cnz_);
+    const g_u64* gcnz = (const g_u64*)uni(gcnz_);
     const l_i32* gnp = (const l_i32*)(size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(const l_i32*)gnp_);
     const l_i32* gbo = (const l_i32*)(size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(const l_i32*)gbo_);
     l_u64* PRW = (l_u64*)(size_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(l_u64*)U_);  // [2][OSDL_K][OSDL_CW][64]
@@ -758,6 +780,7 @@ __device__ __attribute__((noinline)) int osdl_apply_sparse(unsigned long long* U
         }
         if (nb) {
             int pos = atomicAdd((int*)ecount, nb);
+            unsigned long long cz = 0ull;  // chunks the absorbed pivot rows may fill in this row (E3's map of stored non-zero chunks)
 #pragma unroll
             for (int g = 0; g < OSDL_K; ++g) {
                 unsigned long long m = mk[g];
@@ -765,9 +788,11 @@ __device__ __attribute__((noinline)) int osdl_apply_sparse(unsigned long long* U
                     const int q = (int)__builtin_ctzll(m);
                     m &= m - 1ull;
                     if (pos < OSDL_SPARSE_LIST) ELIST[pos] = ((unsigned int)row << 3) | ((unsigned int)(g * (64 * OSDL_CW) + q) << 17);
+                    cz |= gcnz[g * 64 + q];
                     ++pos;
                 }
             }
+            cnz[row] |= cz;  // (the row is this thread's for the pass; if the list overflows the caller's table walk sets the whole map)
         }
     }
     __syncthreads();
@@ -924,6 +949,9 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
     unsigned long long* PRO = P.pro + (size_t)blockIdx.x * P.pro_stride;
     unsigned long long* pmask = P.pmask ? P.pmask + (size_t)blockIdx.x * 64 * W : nullptr;
     int* alist = P.alist + (size_t)blockIdx.x * MRL;
+    unsigned long long* cnz = P.cnz + (size_t)blockIdx.x * MRL;
+    unsigned long long* gcnz = P.gcnz + (size_t)blockIdx.x * OSDL_K * 64;
+    unsigned long long* pcz = U + 98304 / 8;  // [64] (behind E3's tables: 16 waves x 6 KB)
 
     for (;;) {
         OSDL_FRESH_TID();
@@ -987,7 +1015,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             for (int k = 0; k < RPT; ++k) OSDL_AT(unsigned long long, M + (size_t)x * MRL, ro + k * NT * 8) = 0ull;
         }
         __syncthreads();
-        osdl_build_rows<RPT>(M, P.rp, P.ci, inv, P.synd, s, m, W, (int)MRL, P.packed_io);
+        osdl_build_rows<RPT>(M, P.rp, P.ci, inv, P.synd, s, m, W, (int)MRL, P.packed_io, cnz);
         if (tid < 2 * OSDL_NW) pcol[tid] = 64u;
         if (tid == 0) misc[8] = 0;  // mask bits of the open groups
         __syncthreads();
@@ -1052,10 +1080,12 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             bool sparse_done = false;
             if (sparse_pass) {
                 OSDL_TICK(5);
-                sparse_done = osdl_apply_sparse(U, alist, TmO, PRO, M, gnp, gbo, (int)MRL, W, xlo, ng, nact) != 0;
+                sparse_done = osdl_apply_sparse(U, alist, TmO, PRO, M, gnp, gbo, (int)MRL, W, xlo, ng, nact, cnz, gcnz) != 0;
                 OSDL_TICK(24);
                 if (sparse_done) { OSDL_COUNT(12); OSDL_ADD(25, nact); OSDL_ADD(26, passbits); }
             }
+            if (!sparse_done)  // the table walk keeps no account of what it fills in: every chunk of a listed row may be non-zero now
+                for (int i = threadIdx.x; i < nact; i += NT) cnz[alist[i]] = ~0ull;
             for (int x0 = xlo; x0 < W && nact > 0 && !sparse_done; x0 += OSDL_CW) {
                 OSDL_FRESH_TID();
                 const int cw = (W - x0) < OSDL_CW ? (W - x0) : OSDL_CW;
@@ -1674,6 +1704,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                     gnp[ng] = npiv;
                     gbo[ng] = gauss ? (int)osd_large_pro_base(W, w) : ng * W;
                 }
+                if (threadIdx.x < 64) pcz[threadIdx.x] = 0ull;
                 __syncthreads();  // grow / gnp / TmO of the new group are visible
                 if (pmask && (int)threadIdx.x < npiv) {
                     // what the back-substitution needs of this group besides its rows: pivot row q ends as the XOR of the START
@@ -1692,9 +1723,10 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 // fifth of the instructions of the table form, exact, and no faster (E3 30 -> 32-36 M cycles): the phase is
                 // bound by its gather of 64 scattered row words per word (one cache line each in the word-major matrix, ~4-5
                 // cycles per lane through the vector-memory path), which both forms share.
-                if (w + 1 < W) osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, w, ng, npiv);
+                if (w + 1 < W) osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, w, ng, npiv, cnz, pcz);
                 ++ng;
                 __syncthreads();  // PRO of the new group is visible
+                if (threadIdx.x < 64) gcnz[(ng - 1) * 64 + threadIdx.x] = pcz[threadIdx.x];  // the new pivot rows' chunk maps, for the apply pass
                 OSDL_TICK(4);
                 if (ng == OSDL_K) {
                     apply_open(w + 1);
