@@ -1165,7 +1165,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
                 long long st[28];
                 HIP_TRY(h, hipStreamSynchronize(h->osd_now));
                 HIP_TRY(h, hipMemcpy(st, h->cur->d_osd_dbg, sizeof(st), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[bposd large osd, sparse apply passes %lld: %lld ticks, %lld listed rows, %lld mask bits]\n", st[12], st[24], st[25], st[26]);
+                fprintf(stderr, "[bposd large osd, sparse apply passes %lld: %lld ticks, %lld listed rows, %lld mask bits; word of the last search column %lld]\n", st[12], st[24], st[25], st[26], st[27]);
                 fprintf(stderr, "[bposd large osd, s_memtime ticks, list slot 0] sort %lld  build %lld  E1 %lld  E2 %lld  E3 %lld  apply %lld  "
                         "sweep %lld (back-substitution %lld, column vectors %lld, candidates %lld, write-out %lld) | words %lld groups %lld applies %lld | apply look-ups/thread %lld row-words/thread %lld | apply pass: row walks %lld, wait for the slowest walker %lld, own table build %lld, wait for the builders %lld, list builds %lld\n", st[0], st[1], st[2], st[3], st[4], st[5] + st[17] + st[18] + st[19] + st[20], st[6], st[13], st[14], st[15], st[16], st[7], st[8], st[9], st[10], st[11], st[5], st[19], st[17], st[18], st[20]);
                 {   // every elimination of the launch (osd_large_kernel writes 16 numbers per list slot behind the first 32)

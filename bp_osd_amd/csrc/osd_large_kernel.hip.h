@@ -65,6 +65,11 @@ constexpr int OSDL_G5 = 13;            // 5-bit fields of a 64-bit pivot mask in
                      // cycles per elimination) -- with FLAT loads, whose waits also waited for every prefetch (see osdl_e3_materialise);
                      // with global loads: 1 / 2 / 4 words give 8.09 / 8.16 / 8.07 k syndromes/s on l29k_ms_e15 (same box)
 #endif
+constexpr size_t OSDL_E3_LDS_OFF = 57344;   // bytes from the start of the phase union: behind the E1 tables and the panel lists (54920 B)
+constexpr size_t OSDL_PCZ_LDS_OFF = OSDL_E3_LDS_OFF + (size_t)OSDL_NW * (OSDL_K - 1) * 256 * 8;   // [64] chunk maps of the new pivot rows
+#ifndef OSDL_OVERLAP_E3
+#define OSDL_OVERLAP_E3 1   // E3 of a group on waves 1-15 beside the NEXT panel's one-wave pivot search (round 5)
+#endif
 constexpr int OSDL_MAXSPAN = 16;       // max osd_e order, and max osd_cs order with fp64 (non-uniform channel) weights
 constexpr int OSDL_MAXSPAN_CS = 64;    // max osd_cs order with integer weights (uniform channel): as on the small path; the
                                        // reduced columns of the first w non-pivots then live in a global workspace
@@ -135,7 +140,8 @@ __host__ __device__ inline size_t osd_large_pro_rows(int W) { return (size_t)W *
 
 // n_fp: block length when fp64 candidate weights are needed (adds the per-bit info words of that path), else 0
 __host__ __device__ inline size_t osd_large_union_bytes(int W, int RPT, int n_fp = 0) {
-    size_t e3 = (size_t)OSDL_NW * (OSDL_K - 1) * 256 * 8;   // wave-private tables of E3
+    size_t e3 = OSDL_PCZ_LDS_OFF + 64 * 8;                  // wave-private tables of E3 behind the panel lists (so that E3 of one group can run
+                                                            // beside the next panel's one-wave pivot search), the new pivot rows' chunk maps behind them
     size_t ap = (size_t)OSDL_K * OSDL_G5 * OSDL_CW * 32 * 8;  // apply-pass tables (5-bit; covers E1's OSDL_K * 256 entries)
     size_t sw = (size_t)OSDL_MAXSPAN * RPT * OSDL_NW * 8 + (size_t)RPT * OSDL_NW * 8 + (size_t)W * 8 + 64 * 4;
     // region R behind them: the wspan + 1 solution vectors of the back-substitution, later the per-bit info words of the
@@ -495,9 +501,13 @@ __device__ __attribute__((noinline)) void osdl_build_rows(unsigned long long* M_
 // (the kernel sits at its 128-VGPR cap: inside it, more than one word in flight per wave went to scratch and ran slower).
 __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long* U, const int* grow_, const int* gnp_, const unsigned long long* TmO_,
                                                               unsigned long long* PRO_, const int* gbo_, const unsigned long long* M_, int MRL, int W, int w,
-                                                              int ng, int npiv, const unsigned long long* cnz_, unsigned long long* pcz_) {
+                                                              int ng, int npiv, const unsigned long long* cnz_, unsigned long long* pcz_,
+                                                              int x_first, int x_end, int wave0, int nwv) {
+    // words x_first .. x_end - 1, shared by the nwv waves wave0 .. wave0 + nwv - 1 (the others return at once): all sixteen for the
+    // whole range, or wave 0 for the one word the next panel needs and waves 1-15 for the rest while wave 0 searches that panel's pivots
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = (int)(threadIdx.x >> 6) - wave0;
+    if (wave < 0 || wave >= nwv) return;
     // The pointers arrive generic.  Left so, every access below is a FLAT instruction, which counts on the vector-memory AND the
     // LDS counter: the wait before a stage's first table write then waits for every row word requested for the LATER stages too,
     // and the OSDL_E3D-deep prefetch is no prefetch (E3 34 -> 31 M cycles per elimination with the spaces named).  Named address spaces
@@ -512,7 +522,7 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
     const l_i32* gbo = (const l_i32*)gbo_;
 
                         typedef volatile __attribute__((address_space(3))) unsigned long long* lds_rw;
-                        lds_rw tw = (lds_rw)(U + (size_t)wave * (OSDL_K - 1) * 256);
+                        lds_rw tw = (lds_rw)(U + OSDL_E3_LDS_OFF / 8 + (size_t)wave * (OSDL_K - 1) * 256);
                         const int row = (lane < npiv) ? grow[ng * 64 + lane] : 0;
                         // Round 5: the row's chunk map (bit c: its STORED words 8c .. 8c+7 may be non-zero; kept conservatively by the
                         // build and the apply passes).  The lightest-row choice makes pivot rows of rows that absorbed little, so most of
@@ -534,7 +544,7 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                         // per lane from M, four pivot-row words from PRO), ~10 k cycles each under full load
                         unsigned long long prq[OSDL_E3D][4], mvq[OSDL_E3D];
                         auto issue = [&](int d, int xx) {
-                            if (xx < W) {
+                            if (xx < x_end) {
                                 const g_u64* src = PRO + ((long long)gbo[builder ? tg : 0] + xx) * 64 + q0;
     #pragma unroll
                                 for (int kk = 0; kk < 4; ++kk) prq[d][kk] = src[kk];
@@ -548,7 +558,7 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
     #pragma unroll
                             for (int kk = 0; kk < 4; ++kk) pr[kk] = (builder && kk < tnp) ? prq[d][kk] : 0ull;
                             unsigned long long v = (lane < npiv && ((mycz >> (x >> 3)) & 1ull)) ? mvq[d] : 0ull;
-                            issue(d, x + OSDL_NW * OSDL_E3D);  // this stage's registers are free again
+                            issue(d, x + nwv * OSDL_E3D);  // this stage's registers are free again
                             if (builder) {
                                 unsigned int idx = osdl_opaque(((unsigned int)lane >> 1) & 15u);  // conflict-free start entries
                                 unsigned long long tv = 0ull;
@@ -578,13 +588,13 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                             pmap |= (v != 0ull) ? (1ull << (x >> 3)) : 0ull;
                             __builtin_amdgcn_wave_barrier();
                         };
-                        const int xs = w + 1 + wave;
+                        const int xs = x_first + wave;
     #pragma unroll
-                        for (int d = 0; d < OSDL_E3D; ++d) issue(d, xs + d * OSDL_NW);
-                        for (int x = xs; x < W; x += OSDL_NW * OSDL_E3D) {
+                        for (int d = 0; d < OSDL_E3D; ++d) issue(d, xs + d * nwv);
+                        for (int x = xs; x < x_end; x += nwv * OSDL_E3D) {
     #pragma unroll
                             for (int d = 0; d < OSDL_E3D; ++d)
-                                if (x + d * OSDL_NW < W) process(d, x + d * OSDL_NW);
+                                if (x + d * nwv < x_end) process(d, x + d * nwv);
                         }
                         // the sixteen waves' shares of the new pivot rows' maps meet in LDS (zeroed by the caller before its barrier)
                         if (pmap) __hip_atomic_fetch_or((unsigned long long*)(pcz_ + lane), pmap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -951,7 +961,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
     int* alist = P.alist + (size_t)blockIdx.x * MRL;
     unsigned long long* cnz = P.cnz + (size_t)blockIdx.x * MRL;
     unsigned long long* gcnz = P.gcnz + (size_t)blockIdx.x * OSDL_K * 64;
-    unsigned long long* pcz = U + 98304 / 8;  // [64] (behind E3's tables: 16 waves x 6 KB)
+    unsigned long long* pcz = U + OSDL_PCZ_LDS_OFF / 8;  // [64] (behind E3's tables)
 
     for (;;) {
         OSDL_FRESH_TID();
@@ -1037,6 +1047,16 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
         int ng = 0;                  // open groups
         int wlast = W - 1;           // last word whose panel phase ran
         bool done = false;
+        // E3 of the newest group, deferred: only its first word (which the next panel's E1 needs) has been materialised; the rest runs on
+        // waves 1-15 while wave 0 searches the next panel's pivots (or at once, where that search takes all waves / an apply pass is due)
+        bool e3p = false;
+        int e3p_g = 0, e3p_w = 0, e3p_npiv = 0;
+        auto e3_rest_all_waves = [&]() {  // (uniform) the deferred part now, on all sixteen waves
+            osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, e3p_w, e3p_g, e3p_npiv, cnz, pcz, e3p_w + 2, W, 0, OSDL_NW);
+            __syncthreads();
+            if (threadIdx.x < 64) gcnz[e3p_g * 64 + threadIdx.x] = pcz[threadIdx.x];
+            e3p = false;
+        };
 
         // AP: apply the ng open groups to words [xlo, W) of every row
         auto apply_open = [&](int xlo) {
@@ -1307,6 +1327,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 __syncthreads();
                 OSDL_TICK(22);  // (E1c: panel words brought up to date and listed)
                 const int nnz = misc[7];
+                if (e3p && nnz > OSDL_MW_MIN) e3_rest_all_waves();  // the pivot search will take every wave (or the all-rows form runs)
                 if (nnz <= CAP) {  // uniform
                     compact = true;
                     if (nnz > OSDL_MW_MIN) {
@@ -1448,8 +1469,15 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             else if (nnz <= 512 || OSDL_MW_MIN < 1024) osdl_e2_compact_wave<8, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                             else osdl_e2_compact_wave<16, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                         }
+                    } else if (e3p) {
+                        // waves 1-15: the rest of the previous group's E3 beside wave 0's pivot search (its tables sit behind the lists)
+                        osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, e3p_w, e3p_g, e3p_npiv, cnz, pcz, e3p_w + 2, W, 1, OSDL_NW - 1);
                     }
                     __syncthreads();
+                    if (e3p) {  // (uniform) that group is complete now
+                        if (threadIdx.x < 64) gcnz[e3p_g * 64 + threadIdx.x] = pcz[threadIdx.x];
+                        e3p = false;
+                    }
                     OSDL_TICK(23);  // (E2c: the pivot search on the list, one wave)
                     npiv = misc[4];
                     nrank = misc[5];
@@ -1723,10 +1751,20 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 // fifth of the instructions of the table form, exact, and no faster (E3 30 -> 32-36 M cycles): the phase is
                 // bound by its gather of 64 scattered row words per word (one cache line each in the word-major matrix, ~4-5
                 // cycles per lane through the vector-memory path), which both forms share.
-                if (w + 1 < W) osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, w, ng, npiv, cnz, pcz);
+                if (w + 1 < W) {
+                    // Round 5: where no apply pass follows at once, only word w + 1 -- which the next panel's E1 tables need -- is
+                    // materialised here (wave 0); the rest of the group runs on waves 1-15 beside that panel's one-wave pivot search.
+                    const bool defer = OSDL_OVERLAP_E3 && ng + 1 < OSDL_K && w + 2 < W;
+                    if (defer) {
+                        osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, w, ng, npiv, cnz, pcz, w + 1, w + 2, 0, 1);
+                        e3p = true; e3p_g = ng; e3p_w = w; e3p_npiv = npiv;
+                    } else {
+                        osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, w, ng, npiv, cnz, pcz, w + 1, W, 0, OSDL_NW);
+                    }
+                }
                 ++ng;
                 __syncthreads();  // PRO of the new group is visible
-                if (threadIdx.x < 64) gcnz[(ng - 1) * 64 + threadIdx.x] = pcz[threadIdx.x];  // the new pivot rows' chunk maps, for the apply pass
+                if (!e3p && threadIdx.x < 64) gcnz[(ng - 1) * 64 + threadIdx.x] = pcz[threadIdx.x];  // the new pivot rows' chunk maps, for the apply pass
                 OSDL_TICK(4);
                 if (ng == OSDL_K) {
                     apply_open(w + 1);
@@ -1736,6 +1774,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             }
             __syncthreads();
         }
+        if (e3p) e3_rest_all_waves();
         // pending groups (rank reached before the last word): the sweep reads the syndrome column and the
         // non-pivot columns to the right of the last panel in their final state
         if (ng > 0 && wlast + 1 < W) apply_open(wlast + 1);
@@ -1791,6 +1830,13 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             unsigned long long* resb = resw + NR;  // [NR] the own-word part, by column lane (behind resw: R has room for NR + 1 vectors' tails)
             if (tid < NR) resb[tid] = 0ull;
             __syncthreads();
+            // Round 5: a unit right-hand side e_t is zero to the right of t, and so is its solution (a pivot row has no entry to the
+            // left of its pivot column): beyond the word of the LAST search column only the syndrome's vector is non-zero, and a word there
+            // takes one look-up and two bit operations instead of seventeen and thirty-four.  The search columns are the first non-pivot
+            // columns in sorted order, a few words into the matrix; the loop below was bound by those look-ups (each a 512-byte LDS
+            // broadcast: ~16 k of a step's ~25-30 k cycles, 14 M cycles per L29k elimination).  xt = -1 without search columns (OSD-0).
+            const int xt = ntc_g > 0 ? (tpos[ntc_g - 1] >> 6) : -1;
+            OSDL_ADD(27, xt);
 #pragma clang loop unroll(disable)
             for (int w = wlast; w >= 0; --w) {
                 const int prow = pivrow[w * 64 + lane];  // lane q: the pivot at sorted position 64 w + q, if any
@@ -1816,7 +1862,12 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
 #pragma unroll
                     for (int i = 0; i < XB; ++i) {
                         const int x = x0 + i * OSDL_NW;
-                        if (x < W) {  // uniform
+                        if (x > xt && x < W) {  // uniform: the syndrome's vector alone
+                            const unsigned long long zs = zv[(size_t)OSDL_MAXSPAN * W + x];
+                            const unsigned int lo = __builtin_amdgcn_bitop3_b32((unsigned int)acc[OSDL_MAXSPAN], (unsigned int)vx[i], (unsigned int)zs, 0x78);
+                            const unsigned int hi = __builtin_amdgcn_bitop3_b32((unsigned int)(acc[OSDL_MAXSPAN] >> 32), (unsigned int)(vx[i] >> 32), (unsigned int)(zs >> 32), 0x78);
+                            acc[OSDL_MAXSPAN] = ((unsigned long long)hi << 32) | lo;
+                        } else if (x < W) {  // uniform
                             unsigned long long zz[NR];
 #pragma unroll
                             for (int c = 0; c < NR; ++c) zz[c] = zv[(size_t)c * W + x];
