@@ -67,6 +67,12 @@ constexpr int OSDL_G5 = 13;            // 5-bit fields of a 64-bit pivot mask in
 #endif
 constexpr size_t OSDL_E3_LDS_OFF = 57344;   // bytes from the start of the phase union: behind the E1 tables and the panel lists (54920 B)
 constexpr size_t OSDL_PCZ_LDS_OFF = OSDL_E3_LDS_OFF + (size_t)OSDL_NW * (OSDL_K - 1) * 256 * 8;   // [64] chunk maps of the new pivot rows
+#ifndef OSDL_BACKSUB_V2
+#define OSDL_BACKSUB_V2 1   // back-substitution with everything requested a step ahead and the pivots of a word solved for all right-hand sides at once (round 5)
+#endif
+#ifndef OSDL_BS_XL
+#define OSDL_BS_XL 28
+#endif
 #ifndef OSDL_OVERLAP_E3
 #define OSDL_OVERLAP_E3 1   // E3 of a group on waves 1-15 beside the NEXT panel's one-wave pivot search (round 5)
 #endif
@@ -598,6 +604,215 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                         }
                         // the sixteen waves' shares of the new pivot rows' maps meet in LDS (zeroed by the caller before its barrier)
                         if (pmap) __hip_atomic_fetch_or((unsigned long long*)(pcz_ + lane), pmap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The back-substitution of the Gaussian mode as a function of its own (registers allocated on their own: inside the kernel, at
+// its 128-VGPR cap, the values kept across a step went to scratch, and a scratch reload waits for every row word requested
+// ahead).  zv: [17][W] the right-hand sides / solutions by sorted column position (LDS), resw: [2][17] (LDS).  Returns xt.
+// Round 5 (second form of this loop).  Three things bound the first form (25-30 k cycles per pivot word, 14 M per L29k
+// elimination under load):
+//  - every right-hand side was carried through every word, although a unit right-hand side e_t is zero to the right of t
+//    and so is its solution (a pivot row has no entry to the left of its pivot column): beyond the word of the LAST
+//    search column (xt; the search columns are the first non-pivot columns in sorted order, words 23-30 of 462 on L29k)
+//    only the syndrome's vector is non-zero -- one look-up and two bit operations per word instead of 17 and 34;
+//  - a step was a chain of dependent round trips to memory (the pivot positions, two batches of row words, the own
+//    word and mask of each pivot row), none of which depends on the solution: now each is requested a step ahead;
+//  - the <= 64 pivots of a word were solved by a 12-instruction dependent step each, one right-hand side per lane.
+//    Now lane l holds pivot row l's own word and, bit c, its bit of right-hand side c: solving pivot column j is one
+//    v_readlane (column j's solution bits, all right-hand sides at once) and one v_bitop3 on every lane.
+// One barrier per step: the sums meet in resw[step parity], and the only wave that reads the word just solved in the
+// next step is wave 0, which solved it.
+__device__ __attribute__((noinline)) int osdl_backsub(unsigned long long* zv_, unsigned long long* resw_, const int* tpos_, const int* pivrow_,
+                                                       const unsigned long long* M_, const unsigned long long* pmask_, const unsigned long long* PRO_,
+                                                       int W, int MRL, int wlast, int ntc_g) {
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    typedef __attribute__((address_space(1))) int g_i32;
+    typedef volatile __attribute__((address_space(3))) unsigned long long l_u64;
+    typedef __attribute__((address_space(3))) int l_i32;
+    auto uni = [](const void* p_) {
+        const unsigned long long a = (unsigned long long)p_;
+        return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(a >> 32)) << 32) |
+               (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+    };
+    auto lds = [](const void* p_) { return (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(size_t)(const __attribute__((address_space(3))) char*)p_); };
+    l_u64* zv = (l_u64*)(size_t)lds(zv_);
+    l_u64* resw = (l_u64*)(size_t)lds(resw_);
+    const l_i32* tpos = (const l_i32*)(size_t)lds(tpos_);
+    const g_i32* pivrow = (const g_i32*)uni(pivrow_);
+    const g_u64* M = (const g_u64*)uni(M_);
+    const g_u64* pmask = (const g_u64*)uni(pmask_);
+    const g_u64* PRO = (const g_u64*)uni(PRO_);
+    W = __builtin_amdgcn_readfirstlane(W);
+    MRL = __builtin_amdgcn_readfirstlane(MRL);
+    wlast = __builtin_amdgcn_readfirstlane(wlast);
+    ntc_g = __builtin_amdgcn_readfirstlane(ntc_g);
+    constexpr int NR = OSDL_MAXSPAN + 1;
+    constexpr int SYN = OSDL_MAXSPAN;
+    constexpr int XL = OSDL_BS_XL;  // row words a wave requests ahead of a step (L29k: <= 28 per wave beyond xt)
+    const int tid = threadIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xt = ntc_g > 0 ? (tpos[ntc_g - 1] >> 6) : -1;
+    if (tid < NR) resw[NR + tid] = 0ull;  // resw: [2][NR] by step parity
+    __syncthreads();
+    l_u64* zsyn = zv + (size_t)SYN * W;
+    unsigned long long vx[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) vx[i] = 0ull;
+    // my first word of step w_ in which the syndrome's vector alone is non-zero
+    auto first_alone = [&](int w_) { return (w_ > xt ? w_ : xt) + 1 + wave; };
+    auto request = [&](int w_) {
+        const g_u64* gq = PRO + osd_large_pro_base(W, w_) * 64 + lane;
+        const int xb = first_alone(w_);
+#pragma unroll
+        for (int i4 = 0; i4 < XL / 4; ++i4) {
+            if (xb + 64 * i4 < W) {  // uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int x = xb + OSDL_NW * (4 * i4 + i);
+                    vx[4 * i4 + i] = gq[(size_t)(x < W ? x : W - 1) * 64];
+                }
+            }
+        }
+    };
+    int prow0 = pivrow[wlast * 64 + lane];                        // lane q: the pivot at sorted position 64 w + q, if any
+    int prow1 = wlast > 0 ? pivrow[(wlast - 1) * 64 + lane] : -1;  // ... of the step after
+    unsigned long long vb0 = 0ull, S0 = 0ull;                     // (wave 0) pivot row's own word (final in M) and its mask
+    if (wave == 0 && prow0 >= 0) {
+        vb0 = M[(size_t)wlast * MRL + prow0];
+        S0 = pmask[wlast * 64 + lane];
+    }
+    request(wlast);
+    // One step (pivot word w).  FULL: the step may have words up to xt to the right of it, where every right-hand side is carried
+    // (17 accumulators and 17 solution words in registers: that code spills, and a spill reload anywhere in a loop makes every wait
+    // behind it a wait for the row words requested ahead -- so the steps w >= xt, all but ~25 of 462, run in a loop without it).
+    auto step = [&](const int w, auto FULL) {
+        constexpr bool full = decltype(FULL)::value;
+        const int prow = prow0;
+        const unsigned long long pv = __ballot(prow >= 0);  // (the same in every wave)
+        const int np = __popcll(pv);  // = the group's pivots: slots 0 .. np - 1 of its rows in PRO
+        l_u64* rw = resw + (w & 1) * NR;
+        unsigned long long asyn = 0ull;  // the syndrome's sum of this step, my words
+        if (pv != 0ull) {  // uniform
+            const g_u64* gp = PRO + osd_large_pro_base(W, w) * 64 + lane;
+            const int xb = first_alone(w);
+            unsigned int alo = 0u, ahi = 0u;
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const int x = xb + OSDL_NW * i;
+                if (x < W) {  // uniform
+                    const unsigned long long zs = zsyn[x];
+                    alo = __builtin_amdgcn_bitop3_b32(alo, (unsigned int)vx[i], (unsigned int)zs, 0x78);  // a ^ (b & c)
+                    ahi = __builtin_amdgcn_bitop3_b32(ahi, (unsigned int)(vx[i] >> 32), (unsigned int)(zs >> 32), 0x78);
+                }
+            }
+            for (int x = xb + OSDL_NW * XL; x < W; x += OSDL_NW) {  // (wider matrices than the requests cover)
+                const unsigned long long v = gp[(size_t)x * 64], zs = zsyn[x];
+                alo ^= (unsigned int)v & (unsigned int)zs;
+                ahi ^= (unsigned int)(v >> 32) & (unsigned int)(zs >> 32);
+            }
+            asyn = ((unsigned long long)ahi << 32) | alo;
+        }
+        // Everything requested a step ago has been waited for by now -- and the compiler is told so here: its wait counters run in
+        // order and it cannot count requests behind uniform branches, so a wait for any of these AFTER the requests below would
+        // be a wait for all of those too (as first written: wave 0 waited for its row words before solving the word, every step).
+#pragma unroll
+        for (int i = 0; i < XL; ++i) asm volatile("" : "+v"(vx[i]));
+        asm volatile("" : "+v"(vb0), "+v"(S0), "+v"(prow0), "+v"(prow1));
+        const int prow2 = w >= 2 ? pivrow[(w - 2) * 64 + lane] : -1;
+        if (w > 0) request(w - 1);  // (vx is free again) the next step's words arrive while this one is solved
+        if (full && pv != 0ull && w < xt) {  // uniform
+            // the words up to the last search column's: every right-hand side, in two halves (seventeen sums and seventeen solution
+            // words at once took this function to 128 VGPRs -- and a callee that clobbers the registers the KERNEL keeps its spilled
+            // SGPRs in doubled the kernel's own scratch reloads, 536 -> 1164 in the ISA, l29k_ms_e15 11.0 k -> 10.6 k syndromes/s)
+            const g_u64* gp = PRO + osd_large_pro_base(W, w) * 64 + lane;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                constexpr int HN = 9;
+                unsigned long long a9[HN];
+#pragma unroll
+                for (int i = 0; i < HN; ++i) a9[i] = 0ull;
+                for (int x = w + 1 + wave; x <= xt; x += OSDL_NW) {
+                    const unsigned long long v = gp[(size_t)x * 64];
+                    unsigned long long zz[HN];
+#pragma unroll
+                    for (int i = 0; i < HN; ++i) zz[i] = (h * HN + i < NR) ? zv[(size_t)(h * HN + i) * W + x] : 0ull;
+                    const unsigned int vlo = (unsigned int)v, vhi = (unsigned int)(v >> 32);
+#pragma unroll
+                    for (int i = 0; i < HN; ++i) {
+                        const unsigned int lo = __builtin_amdgcn_bitop3_b32((unsigned int)a9[i], vlo, (unsigned int)zz[i], 0x78);
+                        const unsigned int hi = __builtin_amdgcn_bitop3_b32((unsigned int)(a9[i] >> 32), vhi, (unsigned int)(zz[i] >> 32), 0x78);
+                        a9[i] = ((unsigned long long)hi << 32) | lo;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < HN; ++i) {
+                    const int c = h * HN + i;
+                    if (c == SYN) asyn ^= a9[i];
+                    else if (c < ntc_g) {  // uniform
+                        const unsigned long long bits = __ballot(lane < np && (__popcll(a9[i]) & 1));
+                        if (lane == 0 && bits) __hip_atomic_fetch_xor((unsigned long long*)(rw + c), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        if (pv != 0ull) {
+            const unsigned long long bits = __ballot(lane < np && (__popcll(asyn) & 1));
+            if (lane == 0 && bits) __hip_atomic_fetch_xor((unsigned long long*)(rw + SYN), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        unsigned long long vb1 = 0ull, S1 = 0ull;
+        if (wave == 0 && prow1 >= 0) {
+            vb1 = M[(size_t)(w - 1) * MRL + prow1];
+            S1 = pmask[(w - 1) * 64 + lane];
+        }
+        __syncthreads();
+        if (wave == 0 && pv != 0ull) {
+            // bit c of `part`: right-hand side c's sum for my pivot row over everything but this word's pivot columns --
+            // parity(S & A_c) from the words to the right and the row's own word against the right-hand side's own bits
+            unsigned int part = 0u;
+            if (w <= xt) {  // uniform
+#pragma unroll
+                for (int c = 0; c < OSDL_MAXSPAN; ++c) {
+                    if (c < ntc_g) {
+                        const unsigned long long r = rw[c], z0 = zv[(size_t)c * W + w];
+                        part |= (unsigned int)((__popcll(S0 & r) + __popcll(vb0 & z0)) & 1) << c;
+                    }
+                }
+            }
+            {
+                const unsigned long long r = rw[SYN], z0 = zsyn[w];
+                part |= (unsigned int)((__popcll(S0 & r) + __popcll(vb0 & z0)) & 1) << SYN;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < NR) rw[lane] = 0ull;
+            // pivot columns from the last to the first: column j's row is complete when its turn comes, and its bits are
+            // added to the rows that have an entry there (rows l < j; the own bit and the non-pivot columns are masked out)
+            const unsigned long long vbm = vb0 & pv & ~(1ull << lane);
+            const int mlo = (int)(unsigned int)vbm, mhi = (int)(unsigned int)(vbm >> 32);
+#pragma unroll
+            for (int j = 63; j >= 0; --j) {
+                const unsigned int m = (unsigned int)__builtin_amdgcn_readlane((int)part, j);
+                const unsigned int t = (unsigned int)__builtin_amdgcn_sbfe(j < 32 ? mlo : mhi, (unsigned int)(j & 31), 1u);
+                part = __builtin_amdgcn_bitop3_b32(part, t, m, 0x78);
+            }
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                if (c == SYN || (c < ntc_g && w <= xt)) {  // uniform
+                    const unsigned long long bits = __ballot(prow >= 0 && ((part >> c) & 1u));
+                    if (lane == 0 && bits) zv[(size_t)c * W + w] |= bits;  // (no right-hand side has a bit of its own at a pivot column)
+                }
+            }
+        }
+        prow0 = prow1;
+        prow1 = prow2;
+        vb0 = vb1;
+        S0 = S1;
+    };
+    int w = wlast;
+#pragma clang loop unroll(disable)
+    for (; w >= 0 && w >= xt; --w) step(w, std::false_type{});
+#pragma clang loop unroll(disable)
+    for (; w >= 0; --w) step(w, std::true_type{});
+    return xt;
 }
 
 // E1c as a function of its own (round 5): every thread brings the panel word of its RPT rows up to date with the open groups and
@@ -1827,6 +2042,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
             // path).  Pivot row p ended as XOR of start_l over l in S_p (pmask: the pivots of its own group it absorbed, and
             // itself), so <row_p, z> over the words right of the panel = parity(popcount(S_p & A)) with A_l = <start_l, z>;
             // the panel's own word is final in M and is read from there (one gather per step).
+#if !OSDL_BACKSUB_V2
             unsigned long long* resb = resw + NR;  // [NR] the own-word part, by column lane (behind resw: R has room for NR + 1 vectors' tails)
             if (tid < NR) resb[tid] = 0ull;
             __syncthreads();
@@ -1932,6 +2148,14 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                 }
                 __syncthreads();
             }
+#else
+            {
+                const int xt_ = osdl_backsub(zv, resw, tpos, pivrow, M, pmask, PRO, W, (int)MRL, wlast, ntc_g);
+                OSDL_ADD(27, xt_);
+                (void)xt_;
+            }
+            __syncthreads();
+#endif
             OSDL_TICK(13);
             // reduced columns and reduced syndrome as bit vectors over the pivot ROWS (the layout the sweep below uses)
 #pragma unroll
