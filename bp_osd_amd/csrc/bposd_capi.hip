@@ -1180,11 +1180,11 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
                         }
                     if (v.size() > 1) {
                         std::sort(v.begin(), v.end());
-                        fprintf(stderr, "[bposd large osd, all %zu eliminations of the launch, sorted by ticks] M ticks: total | sort build E2 E3 row-walks sweep | words groups applies | own-table-build E1c E2c-one-wave sparse-apply-passes (E2 column = the rest of the panel phase)\n", v.size());
+                        fprintf(stderr, "[bposd large osd, all %zu eliminations of the launch, sorted by ticks] M ticks: total | sort build E2 E3 row-walks sweep | words groups applies | own-table-build E1c E2c-one-wave sparse-apply-passes | wave 0's pivot search alone (E2 column = the rest of the panel phase; E2c-one-wave = the wait for the other waves' share of E3 after it)\n", v.size());
                         for (size_t i = 0; i < v.size(); i += (i + 8 < v.size() ? v.size() / 8 : 1)) {
                             const auto& a = v[i];
-                            fprintf(stderr, "  [%3zu] %.0f | %.1f %.1f %.1f %.1f %.1f %.1f | %lld %lld %lld | %.1f %.1f %.1f %.1f\n", i, a[0] * 1e-6, a[1] * 1e-6, a[2] * 1e-6, a[4] * 1e-6, a[5] * 1e-6,
-                                    a[6] * 1e-6, a[7] * 1e-6, a[8], a[9], a[10], a[12] * 1e-6, a[13] * 1e-6, a[14] * 1e-6, a[15] * 1e-6);
+                            fprintf(stderr, "  [%3zu] %.0f | %.1f %.1f %.1f %.1f %.1f %.1f | %lld %lld %lld | %.1f %.1f %.1f %.1f | %.1f\n", i, a[0] * 1e-6, a[1] * 1e-6, a[2] * 1e-6, a[4] * 1e-6, a[5] * 1e-6,
+                                    a[6] * 1e-6, a[7] * 1e-6, a[8], a[9], a[10], a[12] * 1e-6, a[13] * 1e-6, a[14] * 1e-6, a[15] * 1e-6, a[3] * 1e-6);
                         }
                     }
                 }

@@ -58,8 +58,14 @@ namespace bposd {
 constexpr int OSDL_NT = 1024;
 constexpr int OSDL_NW = OSDL_NT / 64;  // waves
 constexpr int OSDL_CW = 8;             // chunk width (words) of the apply pass
-constexpr int OSDL_K = 4;              // open (lazily applied) pivot groups
+#ifndef OSDL_K_OPEN
+#define OSDL_K_OPEN 4
+#endif
+constexpr int OSDL_K = OSDL_K_OPEN;    // open (lazily applied) pivot groups
 constexpr int OSDL_G5 = 13;            // 5-bit fields of a 64-bit pivot mask in the apply pass (12 x 5 + 4)
+#ifndef OSDL_E3_X
+#define OSDL_E3_X 0   // timing experiments (wrong results): 1 no store of the materialised rows, 2 no reads of the older groups' rows
+#endif
 #ifndef OSDL_E3D
 #define OSDL_E3D 2   // words in flight per wave in E3 beyond the one being processed.  Round 3 measured 3 and 4 SLOWER (42 -> 57 / 60 M
                      // cycles per elimination) -- with FLAT loads, whose waits also waited for every prefetch (see osdl_e3_materialise);
@@ -224,6 +230,9 @@ constexpr int OSDL_E2C_CAP = 2048;   // longest panel list (rows); beyond it the
 #ifndef OSDL_PIVOT_LIGHT
 #define OSDL_PIVOT_LIGHT 1
 #endif
+#ifndef OSDL_E2C_SKIP
+#define OSDL_E2C_SKIP OSDL_PIVOT_LIGHT  // one-wave pivot search: register slots without a one in the column are skipped (round 5)
+#endif
 constexpr unsigned int OSDL_CNT_MAX = 16383u - 64u;  // stored counts saturate here: count + popcount(mask) stays below 2^14
 
 // GAUSS (OSD-0 / OSD-E, round 5): plain Gaussian elimination -- a pivot row takes no further row additions once it is chosen
@@ -285,6 +294,52 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
         // every lane picks "its" entry with a one in the column (only the winning lane's pick is read)
         int kb = 0;
         unsigned long long a = 0ull, c = 0ull;
+#if OSDL_E2C_SKIP
+        // Round 5: a column of the panel has a handful of ones among the list's rows, so most of the CR register slots hold no
+        // row with a one there in ANY lane: a slot is tested by one wave-uniform branch (4 instructions) and only the slots that
+        // pass run the key comparison (12) and, below, the row addition (7) -- as first written every slot ran both (~20) per pivot.
+        const bool colhi = col >= 32;                       // uniform
+        const unsigned int cbit = 1u << (col & 31);
+        unsigned int slots = 0u;                            // uniform: bit s2 -- some lane's entry s2 has a one in the column
+        unsigned int bk = ~0u;  // the lane's lightest candidate: fewest absorbed pivot rows, then lowest row
+#pragma unroll
+        for (int s2 = CR - 1; s2 >= 0; --s2) {
+            const unsigned int half = colhi ? (unsigned int)(cp[s2] >> 32) : (unsigned int)cp[s2];
+            const bool one = (half & cbit) != 0u;
+            if (__ballot(one) != 0ull) {  // uniform
+                slots |= 1u << s2;
+                const bool hit = one && (GAUSS || ((cu >> s2) & 1u) == 0u);
+                const unsigned int key = key0[s2] + ((unsigned int)__popcll(ct[s2]) << 14);
+                const bool better = hit && key < bk;
+                bk = better ? key : bk;
+                kb = better ? s2 : kb;
+                a = better ? cp[s2] : a;
+                c = better ? ct[s2] : c;
+            }
+        }
+        const unsigned int wmin = osd_wave_min_u32(bk);  // (some lane has a hit: the column was proposed)
+        const int first = (int)__builtin_ctzll(__ballot(bk == wmin));
+        const unsigned long long pw_p =
+            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(a >> 32), first) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)a, first);
+        const unsigned long long t_p =
+            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(c >> 32), first) << 32) |
+            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)c, first);
+        const unsigned long long tq = t_p ^ (1ull << cnp);
+#pragma unroll
+        for (int s2 = 0; s2 < CR; ++s2) {
+            if ((slots >> s2) & 1u) {  // uniform
+                const unsigned int half = colhi ? (unsigned int)(cp[s2] >> 32) : (unsigned int)cp[s2];
+                const unsigned int mm = (half & cbit) != 0u ? ~0u : 0u;
+                const unsigned int plo = __builtin_amdgcn_bitop3_b32((unsigned int)cp[s2], (unsigned int)pw_p, mm, 0x78);  // a ^ (b & c)
+                const unsigned int phi = __builtin_amdgcn_bitop3_b32((unsigned int)(cp[s2] >> 32), (unsigned int)(pw_p >> 32), mm, 0x78);
+                const unsigned int tlo = __builtin_amdgcn_bitop3_b32((unsigned int)ct[s2], (unsigned int)tq, mm, 0x78);
+                const unsigned int thi = __builtin_amdgcn_bitop3_b32((unsigned int)(ct[s2] >> 32), (unsigned int)(tq >> 32), mm, 0x78);
+                cp[s2] = ((unsigned long long)phi << 32) | plo;
+                ct[s2] = ((unsigned long long)thi << 32) | tlo;
+            }
+        }
+#else
 #if OSDL_PIVOT_LIGHT
         unsigned int bk = ~0u;  // the lane's lightest candidate: fewest absorbed pivot rows, then lowest row
 #pragma unroll
@@ -322,6 +377,7 @@ __device__ __attribute__((noinline)) void osdl_e2_compact_wave(unsigned int lpw_
             cp[s2] ^= pw_p & mm;
             ct[s2] ^= tq & mm;
         }
+#endif
         if (lane == first) {
             if (GAUSS) {  // the pivot row is final: to the list, out of the registers
                 Lpw[kb * 64 + lane] = pw_p;
@@ -553,10 +609,18 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                             if (xx < x_end) {
                                 const g_u64* src = PRO + ((long long)gbo[builder ? tg : 0] + xx) * 64 + q0;
     #pragma unroll
+#if OSDL_E3_X != 2 && OSDL_E3_X != 3
                                 for (int kk = 0; kk < 4; ++kk) prq[d][kk] = src[kk];
+#else
+                                for (int kk = 0; kk < 4; ++kk) prq[d][kk] = (unsigned long long)(size_t)src + kk;
+#endif
                                 unsigned long long ma = (unsigned long long)(((mycz >> (xx >> 3)) & 1ull) ? M + (size_t)xx * MRL + row : M);
                                 asm volatile("" : "+v"(ma));  // (an opaque address: the request count stays a constant, nothing waits early)
+#if OSDL_E3_X != 3
                                 mvq[d] = *(const g_u64*)ma;
+#else
+                                mvq[d] = ma;
+#endif
                             }
                         };
                         auto process = [&](int d, int x) {
@@ -590,7 +654,11 @@ __device__ __attribute__((noinline)) void osdl_e3_materialise(unsigned long long
                                         v ^= tw[(g * 16 + grp) * 16 + (int)((mrow[g] >> (4 * grp)) & 15ull)];
                                 }
                             }
+#if OSDL_E3_X != 1 && OSDL_E3_X != 3
                             PRO[((long long)gbo[ng] + x) * 64 + lane] = v;
+#else
+                            if (v == 0x123456789abcdefull) PRO[((long long)gbo[ng] + x) * 64 + lane] = v;
+#endif
                             pmap |= (v != 0ull) ? (1ull << (x >> 3)) : 0ull;
                             __builtin_amdgcn_wave_barrier();
                         };
@@ -1684,6 +1752,7 @@ __global__ __launch_bounds__(OSDL_NT) void osd_large_kernel(const OsdLargeParams
                             else if (nnz <= 512 || OSDL_MW_MIN < 1024) osdl_e2_compact_wave<8, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                             else osdl_e2_compact_wave<16, false>(la, ma, nnz, vmask, P.rank, nrank, done ? 1 : 0, rowpos);
                         }
+                        OSDL_TICK(2);  // (wave 0's pivot search alone; the rest of tick 23 is the wait for the other waves' share of E3)
                     } else if (e3p) {
                         // waves 1-15: the rest of the previous group's E3 beside wave 0's pivot search (its tables sit behind the lists)
                         osdl_e3_materialise(U, grow, gnp, TmO, PRO, gbo, M, (int)MRL, W, e3p_w, e3p_g, e3p_npiv, cnz, pcz, e3p_w + 2, W, 1, OSDL_NW - 1);
