@@ -683,6 +683,70 @@ def test_l29k_golden(gpu_ready, name):
         assert (out == np.unpackbits(g["osdw"], axis=1)[:, :n]).all(), rep
 
 
+@pytest.mark.gpu
+def test_l29k_osd0_alone_equals_the_osd0_of_the_higher_order_fixtures(gpu_ready):
+    """osd_method = "osd_0" on configs[4]'s code: no search columns, so the back-substitution carries the syndrome's vector
+    alone through ALL 462 words (its requests-ahead cover 448 of them per step; the rest takes the in-step loop).  Expected
+    output = the `osd0` field of the osd_e 15 fixtures: the same BP output orders the columns, and OSD-0 does not depend on
+    what a higher-order search would do after it."""
+    import ast
+    import os
+
+    from bp_osd_amd import BpOsdDecoder
+    from bp_osd_amd.codes import l29k
+
+    H = l29k().hz
+    m, n = H.shape
+    for name in ("e15", "e15b"):
+        path = os.path.join(os.path.dirname(__file__), "golden", f"l29k_golden_{name}.npz")
+        if not os.path.exists(path):
+            pytest.skip("l29k_golden fixture not generated")
+        g = np.load(path, allow_pickle=False)
+        cfg = ast.literal_eval(str(g["cfg"]))
+        assert cfg["osd_method"] == "osd_e" and cfg["osd_order"] == 15
+        cfg.update(osd_method="osd_0", osd_order=0)
+        dec = BpOsdDecoder(H, **cfg)
+        syn = np.unpackbits(g["syn"], axis=1)[:, :m]
+        out = dec.decode_batch(syn, want_osd0=True, want_bp=True)
+        want = np.unpackbits(g["osd0"], axis=1)[:, :n]
+        assert (dec.batch_converge == g["converged"].astype(bool)).all()
+        assert (dec.batch_bp == np.unpackbits(g["bp"], axis=1)[:, :n]).all()
+        assert (out == want).all() and (dec.batch_osd0 == want).all()
+        assert ((H @ out.T) % 2 == syn.T).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [1, 16])
+def test_large_osd_e_search_columns_beyond_the_last_panel(gpu_ready, order):
+    """m << n on a random matrix of full row rank: the rank is complete a few columns after column m, so most of the
+    osd_e search columns (the first `order` non-pivot columns) lie to the RIGHT of the last panel word -- the
+    back-substitution then carries every right-hand side through every step (its loop without the unit vectors is empty)."""
+    import scipy.sparse as sp
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    rng = np.random.default_rng(4242)
+    m, n = 1100, 4000
+    rows, cols = [], []
+    for c in range(m):
+        pick = rng.choice(n, size=int(rng.integers(3, 7)), replace=False)
+        rows += [c] * len(pick)
+        cols += list(pick)
+    H = sp.csr_matrix((np.ones(len(rows), dtype=np.uint8), (rows, cols)), shape=(m, n))
+    H.data[:] = 1
+    H.sort_indices()
+    q = 0.04
+    err = (rng.random((12, n)) < q).astype(np.uint8)
+    syn = np.asarray((H @ err.T) % 2).T.astype(np.uint8)
+    kw = dict(error_rate=q, max_iter=4, bp_method="ms", ms_scaling_factor=0.625, osd_method="osd_e", osd_order=order)
+    g = BpOsdDecoder(H, **kw)
+    c = OracleDecoder(H, **kw)
+    assert g.rank == c.rank
+    r = _gpu_decode(g, syn)
+    assert (~r["converged"]).sum() >= 8
+    _compare_exact(r, c.decode_batch(syn))
+
+
 def test_large_code_limits_and_nonuniform_channel(gpu_ready, hgp4050):
     """The HBM-resident path with a non-uniform channel: candidate weights are fp64 sums of log(1/p_i) in ascending bit
     index, as on the small path (a11) -- OSD-E and OSD-CS, a channel_probs vector, update_channel_probs, and the per-shot
