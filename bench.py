@@ -239,7 +239,8 @@ def measure(P, rank, local_rank, world):
     dec = BpOsdDecoder(H, device=local_rank, **kw)
     if a.variant:
         dec.set_bp_variant(a.variant)
-    nslots = 1 if a.no_pipeline else 2  # steps in flight (the handle has dec.num_lanes >= 2 lanes)
+    # steps in flight: two; as many as the handle has lanes on the HBM-resident path (three: see bposd_create)
+    nslots = 1 if a.no_pipeline else (max(2, min(3, dec.num_lanes)) if large else 2)
     if a.slots and not a.no_pipeline:
         nslots = max(1, min(a.slots, dec.num_lanes))
 
@@ -380,6 +381,23 @@ def measure(P, rank, local_rank, world):
                             d_iters.data_ptr(), None)
     dec.synchronize()
     t_last = dec.last_timing()
+    # ---- the rows the gather moves, against the byte rows just written: batch 0 once more through the packed device-pointer call
+    # (the timed loop's own form where the kernels write packed rows), all three outputs and both per-shot vectors
+    packed_same = None
+    if do_gather and native_gather:
+        c2, i2 = mk(B), mk(B, dtype=torch.int32)
+        dec.decode_batch_device_packed(d_psyn[0].data_ptr(), B, d_packed[0].data_ptr(), pouts[0]["osd0"].data_ptr(), pouts[0]["bp"].data_ptr(),
+                                       c2.data_ptr(), i2.data_ptr())
+        dec.synchronize()
+        tmp = torch.empty((B, wpr), dtype=torch.int64, device=dev)
+        packed_same = bool(torch.equal(c2, d_conv) and torch.equal(i2, d_iters))
+        for byte_rows, words in ((d_osdw, d_packed[0]), (d_osd0, pouts[0]["osd0"]), (d_bp, pouts[0]["bp"])):
+            dec.pack_rows_device(byte_rows.data_ptr(), B, n, tmp.data_ptr())
+            dec.synchronize()
+            packed_same = packed_same and bool(torch.equal(tmp, words))
+        del tmp, c2, i2
+        if not packed_same:
+            print(f"[bench] PACKED ROWS DIFFER FROM THE BYTE ROWS ({P['name']})", file=sys.stderr, flush=True)
 
     # ---- cross-kernel check (rank 0, outside the timed region): the whole batch once more on the OTHER kernel path, each
     # pinned to the CPU oracle by tests/ -- min-sum: the generic LDS BP kernel and the workgroup OSD kernel (large codes: the
@@ -766,7 +784,7 @@ def measure(P, rank, local_rank, world):
     if gather_ms is not None:
         out["gather_ms"] = gather_ms
         out["gather"] = {"backend": ("gloo" if a.rehearse_on_one_gpu else "nccl (RCCL)"), "world_size": world,
-                         "native_packed_rows": native_gather, "packed_buffers": nbuf,
+                         "native_packed_rows": native_gather, "packed_rows_equal_byte_rows": packed_same, "packed_buffers": nbuf,
                          "launches_that_waited_for_a_gather": pipe.launch_waited_for_gather}
     if a.rehearse_on_one_gpu:
         out["rehearsal"] = True
@@ -840,6 +858,8 @@ def measure(P, rank, local_rank, world):
                 out["cpu_baseline_all_cores"]["shots_that_differ_from_the_libm_oracle"] = int((~rows_all).sum())
     if cross is not None and cross.get("identical") is not True:
         out["value"] = None  # a number whose outputs two implementations do not agree on (or were not compared on) is not a measurement
+    if packed_same is False:
+        out["value"] = None  # ... nor one whose gathered rows are not the rows the decode wrote
     return out
 
 

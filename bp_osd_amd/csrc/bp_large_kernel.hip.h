@@ -184,7 +184,10 @@ __global__ __launch_bounds__(bp_large_threads(METHOD)) void bp_large_kernel(cons
 #pragma clang loop unroll(disable)
                 for (int c = tid; c < m; c += NT) {
                     const int deg = P.chk_deg[c];
-                    const bool sbit = (syn[c] & 1) != 0;
+                    // (packed_io: the row is ceil(m / 64) words -- the byte address does not exist there.  Round 5's first build of the packed
+                    // path read it all the same: wrong parities for every row but the first few, and reads up to B * m bytes past a buffer of
+                    // B * m / 8; no test ran THIS kernel on packed rows until the three-lane default moved the allocations and the read faulted.)
+                    const bool sbit = P.packed_io ? ((synw[c >> 6] >> (c & 63)) & 1ull) != 0ull : (syn[c] & 1) != 0;
                     double* mc = msg + c;
                     // absent edges (k >= deg) enter as +DBL_MAX (neutral for the minima and the sign parity; tanh = 1): every
                     // array element is defined on every path (partially defined arrays turn into loop-carried registers)

@@ -839,7 +839,11 @@ int bposd_create(const bposd_config* cfg, const int32_t* indptr, const int32_t* 
     h->large = (m > 1024) || (osd_words(n) == 0) || h->bp_hbm;
     if (const char* e = getenv("BPOSD_FORCE_LARGE_OSD")) h->large = h->large || e[0] == '1';  // (probe: the HBM-resident OSD kernel on a small code)
     if (h->large) {
-        h->nlanes = 2;
+        // Two lanes, three where BP is HBM-resident too: its workgroups take a whole CU like the eliminations', a call is a
+        // 35-50 ms BP launch followed by an OSD launch that lasts as long as its slowest elimination (87 ms on L29k, twice the
+        // median), and with two calls in flight the CUs the fast eliminations free stay idle until the next call's BP kernel is
+        // launched (l29k_ms_e15: 88 ms per step with two lanes, 82-83 with three or four -- the sum of the kernels' CU time).
+        h->nlanes = h->bp_hbm ? 3 : 2;
         if (const char* e = getenv("BPOSD_LARGE_LANES")) h->nlanes = std::max(1, std::min(BPOSD_LANES, atoi(e)));
         if (n > 32767 || m > 16384 || (h->bp_hbm && bp_large_lds_need(m, n) > h->lds_per_cu)) {
             fail(nullptr, BPOSD_ERR_UNSUPPORTED, "code too large even for the HBM-resident kernels (m=%d n=%d; limits 16384 / 32767)", m, n);
@@ -1100,7 +1104,11 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
     // workgroup, which fits, and the eliminations of call k starve until the pipeline runs dry (traced with three and four
     // asynchronous host calls in flight: completions came in bursts of three).  With this rule OSD(k) gets its CUs at the
     // start of BP(k + 1)'s tail and BP(k + 2) follows ~1 ms later, whatever the number of calls queued.
-    if (!lean && !h->tail_gate && h->nlanes >= 3) {  // (the chunks of a synchronous host call are released one by one by the host: tail_gate)
+    // (Not where BP is HBM-resident: there both kernels need a whole CU, the OSD stream has the higher priority, and three calls in
+    // flight are what fills the CUs -- see the lane count in bposd_create.  BPOSD_TWO_BACK=0/1 overrides, for probes.)
+    static const char* two_back_env = getenv("BPOSD_TWO_BACK");
+    const bool two_back_rule = two_back_env ? two_back_env[0] == '1' : !h->bp_hbm;
+    if (!lean && !h->tail_gate && h->nlanes >= 3 && two_back_rule) {  // (the chunks of a synchronous host call are released one by one by the host: tail_gate)
         Lane& two_back = h->lanes[(lane + h->nlanes - 2) % h->nlanes];
         if (two_back.done_recorded) HIP_TRY(h, hipStreamWaitEvent(h->cur->stream, two_back.ev_done, 0));
     }

@@ -24,7 +24,8 @@ static int launch_bp_large_tm(bposd_handle* h, BpLargeParams& P) {
     // arrays (465 KB each on 14520 x 29524) stay in the memory-side cache between uses: 72-74 -> 61-62 ms per 1024 syndromes.
     wg_per_cu = METHOD >= 1 ? 1 : occ;
     if (const char* e = getenv("BPOSD_LARGE_WG_CAP")) wg_per_cu = std::max(1, std::min(occ, atoi(e)));
-    const long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
+    long long grid = std::max<long long>(1, std::min<long long>(P.B, (long long)h->num_cu * wg_per_cu));
+    if (const char* e = getenv("BPOSD_LARGE_BP_GRID")) grid = std::max<long long>(1, std::min<long long>(grid, atoll(e)));  // (probe: a bandwidth-bound kernel on fewer CUs)
     constexpr int SLOTS = METHOD == 1 ? DC + 4 : (METHOD == 2 ? DC + 1 : DC);  // message planes (+ the check records of the min-sum form)
     int rc;
     if ((rc = ensure_lanes(h, &Lane::bpl_msg, sizeof(double) * (size_t)grid * SLOTS * P.mp))) return rc;

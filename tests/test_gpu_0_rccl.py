@@ -41,6 +41,7 @@ def test_rccl_backend_and_device_gather_at_world_size_1(extra, native):
     assert d["gather_ms"] is not None and d["gather_ms"] >= 0.0
     assert d["gather"]["backend"].startswith("nccl") and d["gather"]["world_size"] == 1
     assert d["gather"]["native_packed_rows"] is native          # the kernels write packed rows themselves
+    assert d["gather"]["packed_rows_equal_byte_rows"] is True    # ... and they are the byte rows, bit for bit
     assert d["gather"]["packed_buffers"] == d["config"]["pipelined_steps"] + 2
     assert d["cross_kernel_check"]["identical"] is True
     assert d["corrections_reproduce_syndromes"] is True

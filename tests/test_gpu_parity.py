@@ -2020,24 +2020,29 @@ def test_device_pointer_packed_api_with_torch(gpu_ready, h1922, hgp400, hgp4050)
     import torch
 
     from bp_osd_amd import BpOsdDecoder
-    from bp_osd_amd.codes import hgp, rep_code
+    from bp_osd_amd.codes import circulant, hgp, rep_code
 
     dev = torch.device("cuda", 0)
     cases = [(h1922.hz, 20000, 0.06, dict(max_iter=30, osd_method="osd_cs", osd_order=7), 0),
              (hgp400.hz, 9000, 0.07, dict(max_iter=10, osd_method="osd_cs", osd_order=42), 0),
              (hgp400.hx, 5000, 0.07, dict(max_iter=10, osd_method="osd_e", osd_order=6), 1),     # generic LDS BP kernel, workgroup OSD kernel
              (hgp(rep_code(21), compute_logicals=False).hz, 6000, 0.06, dict(max_iter=8, osd_method="osd_cs", osd_order=9), 0),  # osd_mw_kernel
-             (hgp4050.hz, 700, 0.06, dict(max_iter=8, osd_method="osd_cs", osd_order=7), 0),    # bp_large_kernel + osd_large_kernel (Gauss-Jordan)
-             (hgp4050.hz, 300, 0.06, dict(max_iter=6, osd_method="osd_e", osd_order=5), 0)]     # ... Gaussian mode
+             (hgp4050.hz, 700, 0.06, dict(max_iter=8, osd_method="osd_cs", osd_order=7), 0),    # LDS BP (mid-size shape) + osd_large_kernel (Gauss-Jordan)
+             (hgp4050.hz, 300, 0.06, dict(max_iter=6, osd_method="osd_e", osd_order=5), 0),     # ... Gaussian mode
+             # bp_large_kernel (m = 3844 > 2048: messages in HBM) + osd_large_kernel; more rows than 256 workgroups, so that
+             # most rows' byte address s * m + c lies far outside the packed buffer (the read round 5's first build made)
+             (hgp(circulant(62, (0, 2, 5)), compute_logicals=False).hz, 600, 0.05, dict(max_iter=7, osd_method="osd_e", osd_order=4), -1)]
     for H, B, q, kw, variant in cases:
         m, n = H.shape
         _, syn = _syndromes(H, q, B, 321)
         d = BpOsdDecoder(H, error_rate=q, bp_method="ms", ms_scaling_factor=0.625, **kw)
-        if variant:
+        if variant > 0:
             d.set_bp_variant(variant)
             d.set_osd_variant(1)
         want = dict(osdw=d.decode_batch(syn, want_osd0=True, want_bp=True).copy(), osd0=d.batch_osd0.copy(), bp=d.batch_bp.copy(),
                     conv=d.batch_converge.copy(), iters=d.batch_iter.copy())
+        if variant < 0:
+            assert d.bp_kernel_info()["kernel"] == "bp_large_kernel"
         assert (~want["conv"]).sum() > 10
         wn = (n + 63) // 64
         d_syn = torch.from_numpy(d.pack_rows(syn).view(np.int64)).to(dev)
