@@ -19,12 +19,16 @@
 //   1. a8  reliability sort: bitonic network in LDS on (order-preserving u64 image of the
 //          LLR, bit index) -- a strict total order, so the result equals a stable sort.
 //   2. a9  blocked Gauss-Jordan, panels of 64 columns (one register word):
-//          (i) panel phase, one barrier per PIVOT: every wave proposes its lowest column
-//          that still has a candidate row (wave-min of a (column, row) key on the DPP path) together
-//          with that row's panel word and combination mask; after the barrier the lowest
-//          key wins (skipped columns are non-pivot); every row with a 1 in the column XORs the
-//          pivot's panel word and records the pivot in its own 64-bit combination mask t
-//          (row = row_at_panel_start ^ XOR_{q in t} pivot_q_at_panel_start);
+//          (i) panel phase, two barriers per SIX columns (round 5; one per pivot before): which pivot rows a row
+//          absorbs over six columns depends only on the row's six bits there, so every unused row with a non-zero
+//          value v claims v (LDS atomic; the first claimant publishes its panel word and combination mask), two waves
+//          -- alone on their SIMDs while the others wait -- solve the 64 values after the first barrier (lane v =
+//          value v: <= 6 steps of ballot, ffs, readlane, masked XOR; the claimed value whose reduced form has the
+//          lowest column set supplies the pivot row -- any unused row with a 1 in the column is a valid pivot, the
+//          row choice never reaches the outputs) and write one (panel word, mask) XOR per value into a table; after
+//          the second barrier every row XORs the table entry of its value into its panel word and its own 64-bit
+//          combination mask t (row = row_at_panel_start ^ XOR_{q in t} pivot_q_at_panel_start);
+//          tools/panel_subblock_model.py replays the scheme lane by lane against column-by-column elimination;
 //          (ii) trailing phase, once per panel: the <= 64 pivot rows publish their
 //          trailing words, 4-bit "four Russians" tables of their XOR combinations are
 //          built in LDS, and every row applies its mask with one table lookup per 4
@@ -56,7 +60,6 @@ constexpr int OSD_MAXW = 8;     // max waves per workgroup (512 threads)
 #define OSD_CHUNK 8
 #endif
 constexpr int OSD_MAXCV = 16;   // max ballot words per column vector (RPT * waves)
-static_assert(OSD_RPT <= 2 && OSD_MAXW <= 8, "panel keys carry one bit of row slot and nine bits of thread id");
 
 struct OsdParams {
     int m, n;
@@ -184,8 +187,8 @@ __device__ __forceinline__ void osd_bs_add(unsigned int (&c)[6]) {
 // LDS carve-up, all offsets 8-byte aligned
 struct OsdLds {
     unsigned long long* keys;     // [nsort]; after the sort: first 128 B reused as T-index -> position
-    unsigned long long* pbuf;     // [2][OSD_MAXW][2]  (panel word, mask) of each wave's proposed pivot row
-    unsigned int* pcol;           // [2][OSD_MAXW]     key (column << 10 | row slot << 9 | thread) of each wave's proposal
+    unsigned long long* pbuf;     // [3][64][2]  per 6-bit value v: (panel word, mask) of the row that claimed it; table D; table D'
+    unsigned int* pcol;           // [3][64]     per value: number of the last sub-block in which it was claimed; pivot info; (idle atomics' targets)
     unsigned long long* prow;     // [64][W rounded up to even]   trailing words of this panel's pivots
     unsigned long long* tab;      // [16][16][W | 1] XOR combinations of 4 pivots: [group][combination][word]
     unsigned long long* colvec;   // [64][OSD_MAXCV]
@@ -230,8 +233,8 @@ __host__ __device__ constexpr size_t osd_lds_bytes(int W, int mr) {
     const int nsort = osd_nsort(W);
     size_t b = 0;
     b += (size_t)nsort * 8;                     // keys
-    b += (size_t)2 * OSD_MAXW * 2 * 8;          // pbuf
-    b += osd_align8((size_t)2 * OSD_MAXW * 4);  // pcol
+    b += (size_t)3 * 64 * 2 * 8;                // pbuf
+    b += (size_t)3 * 64 * 4;                    // pcol
     b += (size_t)OSD_MAXCV * 8;                 // yvec
     b += (size_t)W * 8;                         // npmask
     b += 2 * 8;                                 // best64
@@ -315,8 +318,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
     {
         unsigned char* p = smem;
         L.keys = (unsigned long long*)p; p += (size_t)NS * 8;
-        L.pbuf = (unsigned long long*)p; p += (size_t)2 * OSD_MAXW * 2 * 8;
-        L.pcol = (unsigned int*)p; p += osd_align8((size_t)2 * OSD_MAXW * 4);
+        L.pbuf = (unsigned long long*)p; p += (size_t)3 * 64 * 2 * 8;
+        L.pcol = (unsigned int*)p; p += (size_t)3 * 64 * 4;
         L.yvec = (unsigned long long*)p; p += (size_t)OSD_MAXCV * 8;
         L.npmask = (unsigned long long*)p; p += (size_t)W * 8;
         L.best64 = (unsigned long long*)p; p += 2 * 8;
@@ -332,7 +335,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         L.tab = L.prow + (size_t)64 * PS;
         L.colvec = L.tab + (size_t)16 * 16 * WS;
     }
-    if (tid < 2 * OSD_MAXW) L.pcol[tid] = ~0u;  // slots of waves that do not exist never propose
+    for (int i = tid; i < 3 * 64; i += NT) L.pcol[i] = 0u;  // no value claimed yet (sub-blocks count from 1, over all eliminations)
+    unsigned int sbc = 1u;  // number of the current six-column sub-block (uniform)
     for (;;) {
         if (tid == 0) L.misc[0] = atomicAdd(&P.counters[2], 1);
         __syncthreads();
@@ -406,16 +410,15 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         // ------------------------------------------------------- a9: blocked Gauss-Jordan
         const int MR = NT * RPT;  // padded row count of the spill layout
         unsigned long long* ws = P.rows_ws + (size_t)blockIdx.x * W * MR;  // [W][MR], word-major: coalesced
-        // per-row pivot state during the elimination, one register each: ukey = 0 while the row is unused and the
-        // "no candidate" key once it is a pivot row; pinfo = -1, or (sorted position << 6) | pivot index in its panel
-        unsigned int ukey[RPT], kbase[RPT];
+        // per-row pivot state during the elimination: pinfo = -1 while the row is unused, else (sorted position << 6) |
+        // pivot index in its panel
         int pinfo[RPT];
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) { ukey[k] = 0u; pinfo[k] = -1; kbase[k] = ((unsigned int)k << 9) | (unsigned int)tid; }
+        for (int k = 0; k < RPT; ++k) pinfo[k] = -1;
         int nrank = 0;
         bool done = false;
 #ifdef BPOSD_OSD_DIAG
-        long long diag_panel = 0, diag_trail = 0, diag_t0 = 0, diag_pub = 0, diag_build = 0;
+        long long diag_panel = 0, diag_trail = 0, diag_t0 = 0, diag_pub = 0, diag_build = 0, diag_claim = 0, diag_solve = 0, diag_absorb = 0, diag_t1 = 0;
 #define OSD_TICK() ((long long)__builtin_amdgcn_s_memtime())
 #endif
 #pragma clang loop unroll(disable)
@@ -427,85 +430,159 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
 #ifdef BPOSD_OSD_DIAG
             diag_t0 = OSD_TICK();
 #endif
-            // ---------------- (i) panel phase on the current word row[k][0]: one barrier per PIVOT.
-            // Every thread forms a key (lowest candidate column, row slot) for each of its rows -- a candidate is an
-            // unused row with a 1 -- and the wave takes the minimum key with four DPP steps; the lane that owns it
-            // publishes the key and the row's (panel word, mask).  After the barrier the lowest of the <= 8 wave keys
-            // is the next pivot: the columns skipped in between have no candidate anywhere, i.e. they are non-pivot.
-            // Unused rows are zero in every column already passed, so no "columns >= b" masking is needed, only
-            // "columns < n".  The loop control is scalar (keys travel through SGPRs).
+            // ---------------- (i) panel phase on the current word row[k][0]: two barriers per SIX columns.
+            // What a row has to absorb while six columns are eliminated depends only on its six bits there (its
+            // "value" v): all rows with the same v receive the same combination of the sub-block's <= 6 pivot rows
+            // as they stood at its start.  (A) every unused row with v != 0 claims v in LDS; the first claimant
+            // publishes its (panel word, mask).  (C) behind the first barrier waves 0 and 1 -- alone on their SIMDs
+            // while the others wait, so at the full issue rate -- solve the 64 values, lane v = value v: for column j
+            // the lowest claimed value whose reduced form has bit j set supplies the pivot row (none: the column is
+            // non-pivot -- unused rows are zero in every column already passed, and every unused row's value is a
+            // claimed one), every value with bit j set absorbs it; a second register follows the pivot rows
+            // themselves.  Wave 0 then writes, per value, the XOR of the published (word, mask) pairs its tag names
+            // (table D), wave 1 the same for the pivot row taken from each value (table D').  (E) behind the second
+            // barrier a row XORs ONE table entry, picked by its value (the claimant of a taken value: from D').
             unsigned long long t[RPT];
 #pragma unroll
             for (int k = 0; k < RPT; ++k) t[k] = 0ull;
             int npiv = 0;  // pivots found in this panel (uniform)
             const int nb = n - w * 64;            // valid columns in this panel; the syndrome bit (bit 63 of the last
-            const int nbc = nb < 64 ? nb : 64;    // word) lies beyond them, so "lowest candidate >= nbc" ends the panel
-            if (nb <= 0) done = true;
-            // One pivot step; PAR (the proposal double buffer) is a literal so that every LDS address is an immediate.
-#define OSD_PIVOT_STEP(PAR)                                                                                             \
-    {                                                                                                                   \
-        if (nrank >= P.rank) { done = true; goto panel_done; }                                                          \
-        unsigned int key[RPT];                                                                                          \
-        _Pragma("unroll") for (int k = 0; k < RPT; ++k) {                                                               \
-            const unsigned int l = osd_ffs64_or_64(row[k][0]);                                                          \
-            const unsigned int lk = (l << 10) | kbase[k];                                                               \
-            key[k] = lk > ukey[k] ? lk : ukey[k]; /* a pivot row never proposes */                                      \
-        }                                                                                                               \
-        unsigned int mk = key[0];                                                                                       \
-        _Pragma("unroll") for (int k = 1; k < RPT; ++k) mk = key[k] < mk ? key[k] : mk;                                 \
-        const unsigned int wk = osd_wave_min_u32(mk); /* wave-uniform */                                                \
-        if (mk == wk) { /* exactly one lane: keys are distinct */                                                       \
-            unsigned long long pw = 0ull, pt = 0ull;                                                                    \
-            _Pragma("unroll") for (int k = 0; k < RPT; ++k) if (key[k] == wk) { pw = row[k][0]; pt = t[k]; }            \
-            pkw[(PAR) * OSD_MAXW] = wk;                                                                                 \
-            pbw[(PAR) * OSD_MAXW] = make_ulonglong2(pw, pt);                                                            \
-        }                                                                                                               \
-        __syncthreads();                                                                                                \
-        unsigned int g; /* lowest of the <= 8 wave keys (slots of absent waves hold ~0) */                              \
-        {                                                                                                               \
-            const uint4 ka = *reinterpret_cast<const uint4*>(&L.pcol[(PAR) * OSD_MAXW]);                                \
-            const uint4 kb = *reinterpret_cast<const uint4*>(&L.pcol[(PAR) * OSD_MAXW + 4]);                            \
-            const unsigned int g0 = min(min(ka.x, ka.y), min(ka.z, ka.w));                                              \
-            const unsigned int g1 = min(min(kb.x, kb.y), min(kb.z, kb.w));                                              \
-            g = (unsigned int)__builtin_amdgcn_readfirstlane((int)min(g0, g1));                                         \
-        }                                                                                                               \
-        const int mincol = (int)(g >> 10);                                                                              \
-        if (mincol >= nbc) goto panel_done; /* panel exhausted (uniform) */                                             \
-        const ulonglong2 pp = reinterpret_cast<const ulonglong2*>(L.pbuf)[(PAR) * OSD_MAXW + (int)((g >> 6) & 7u)];     \
-        const unsigned int pw_lo = (unsigned int)pp.x, pw_hi = (unsigned int)(pp.x >> 32);                              \
-        const unsigned long long tq = pp.y ^ (1ull << npiv);                                                            \
-        const unsigned int tq_lo = (unsigned int)tq, tq_hi = (unsigned int)(tq >> 32);                                  \
-        const int pj = ((w * 64 + mincol) << 6) | npiv;                                                                 \
-        _Pragma("unroll") for (int k = 0; k < RPT; ++k) {                                                               \
-            const bool is_pivot = key[k] == g;                                                                          \
-            const bool hit = ((row[k][0] >> mincol) & 1ull) != 0ull;                                                    \
-            unsigned int msk = (hit && !is_pivot) ? ~0u : 0u;                                                           \
-            asm volatile("" : "+v"(msk)); /* keep it a register mask: row ^= pivot & msk is one v_bitop3 per half */    \
-            unsigned int rlo = (unsigned int)row[k][0], rhi = (unsigned int)(row[k][0] >> 32);                          \
-            unsigned int tlo = (unsigned int)t[k], thi = (unsigned int)(t[k] >> 32);                                    \
-            rlo ^= pw_lo & msk; rhi ^= pw_hi & msk;                                                                     \
-            tlo ^= tq_lo & msk; thi ^= tq_hi & msk;                                                                     \
-            row[k][0] = ((unsigned long long)rhi << 32) | rlo;                                                          \
-            t[k] = ((unsigned long long)thi << 32) | tlo;                                                               \
-            ukey[k] = is_pivot ? ((64u << 10) | kbase[k]) : ukey[k];                                                    \
-            pinfo[k] = is_pivot ? pj : pinfo[k];                                                                        \
-        }                                                                                                               \
-        ++npiv;                                                                                                         \
-        ++nrank;                                                                                                        \
-    }
+            const int nbc = nb < 64 ? nb : 64;    // word) lies beyond them and never takes part in a value
+            if (nb <= 0 || nrank >= P.rank) done = true;
             {
-                unsigned int* const pkw = L.pcol + wave;
-                ulonglong2* const pbw = reinterpret_cast<ulonglong2*>(L.pbuf) + wave;
+                typedef __attribute__((address_space(3))) unsigned int* lds_u32p;
+                ulonglong2* const pub = reinterpret_cast<ulonglong2*>(L.pbuf);  // [64] published rows, [64] D, [64] D'
+                unsigned int* const claim = L.pcol;                              // [64] claims, [64] per-value info, [64] idle targets
+                const int nsolve = nwaves < 2 ? nwaves : 2;
+                const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // (the compiler cannot see that tid >> 6 is wave-uniform)
 #pragma clang loop unroll(disable)
-                for (;;) {
-                    OSD_PIVOT_STEP(0)
-                    OSD_PIVOT_STEP(1)
+                for (int c0 = 0; c0 < nbc && !done; c0 += 6, ++sbc) {
+                    const int wsb = nbc - c0 < 6 ? nbc - c0 : 6;
+                    const unsigned int vmask = (1u << wsb) - 1u;
+#ifdef BPOSD_OSD_DIAG
+                    diag_t1 = OSD_TICK();
+#endif
+                    // (A) claims: both rows' atomics go out together (a row that does not claim aims at a word of its
+                    // own lane that nobody reads), one wait, then the winners publish
+                    unsigned int bv[RPT], prev[RPT];
+                    bool cl[RPT];
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        bv[k] = (unsigned int)(row[k][0] >> c0) & vmask;
+                        cl[k] = pinfo[k] < 0 && bv[k] != 0u;  // rows beyond m are zero: they never claim
+                        prev[k] = __hip_atomic_fetch_max((lds_u32p)(size_t)(claim + (cl[k] ? bv[k] : 128u + (unsigned int)lane)), sbc, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    bool won[RPT];
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        won[k] = cl[k] && prev[k] != sbc;
+                        if (won[k]) pub[bv[k]] = make_ulonglong2(row[k][0], t[k]);
+                    }
+                    __syncthreads();
+#ifdef BPOSD_OSD_DIAG
+                    { const long long t2 = OSD_TICK(); diag_claim += t2 - diag_t1; diag_t1 = t2; }
+#endif
+                    if (wave_u < nsolve) {
+                        // (C) X, lane v: reduced value (bits 0-5) and tag (bits 8-13) of the rows that hold value v; Y, lane
+                        // v: the same for the pivot row taken from value v, with its column (bits 16-18) and bit 20 set, 0 if
+                        // none was.  Tag bit j = "has absorbed the pivot row of the sub-block's column j as it stood at the
+                        // sub-block's start"; lj[j] = the value that row was taken from (scalar).  A value has no bit beyond
+                        // the valid columns, so j >= wsb never finds a candidate.  (The same on the scalar unit -- value sets
+                        // as 64-bit masks, s_bitcmp1 / s_cselect / s_xor -- was built and measured no faster: a lone wave
+                        // issues about one instruction per eight cycles whatever the unit, and this form has fewer.)
+                        unsigned long long avm = __ballot(claim[lane] == sbc) & ~1ull;  // claimed values
+                        unsigned int X = (unsigned int)lane, Y = 0u;
+                        unsigned int pivmask = 0u;  // columns of the sub-block that are pivot columns (uniform)
+                        int lj[6];
+                        int room = P.rank - nrank;  // pivots still to find (> 0 here)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            lj[j] = 0;
+                            unsigned int mh = (unsigned int)((int)(X << (31 - j)) >> 31);  // all ones where bit j of the reduced value is set
+                            asm volatile("" : "+v"(mh));
+                            const unsigned long long cand = __ballot(mh != 0u) & avm;
+                            if (cand) {  // uniform
+                                const int l = __ffsll((long long)cand) - 1;
+                                const unsigned int ppk = (unsigned int)__builtin_amdgcn_readlane((int)X, l) & 0x3f3fu;
+                                const unsigned int pn = ppk ^ (0x100u << j);
+                                X ^= pn & mh;
+                                unsigned int my = (unsigned int)((int)(Y << (31 - j)) >> 31);
+                                asm volatile("" : "+v"(my));
+                                Y ^= pn & my;
+                                unsigned int ml = lane == l ? ~0u : 0u;
+                                asm volatile("" : "+v"(ml));
+                                Y |= (ppk | ((unsigned int)j << 16) | (1u << 20)) & ml;  // (a value is taken at most once: Y was 0 there)
+                                lj[j] = l;
+                                pivmask |= 1u << j;
+                                if (--room == 0) avm = 0ull;  // rank reached: no further pivots
+                            }
+                        }
+                        if (wave_u == 0) {
+                            // per value: the sub-block's number if a pivot row was taken from it, and that row's column
+                            claim[64 + lane] = ((Y >> 20) & 1u) * (sbc << 3) | ((Y >> 16) & 7u);
+                            if (lane == 0) L.misc[1] = (int)pivmask;
+                        }
+                        if (pivmask) {  // uniform
+                            for (int which = wave_u; which < 2; which += nsolve) {  // 0: table D from X's tags, 1: table D' from Y's
+                                const unsigned int tg = ((which ? Y : X) >> 8) & 63u;
+                                unsigned int alo = 0u, ahi = 0u, blo = 0u, bhi = 0u;
+#pragma unroll
+                                for (int h3 = 0; h3 < 6; h3 += 3) {
+                                    ulonglong2 pp[3];
+#pragma unroll
+                                    for (int q = 0; q < 3; ++q) pp[q] = pub[lj[h3 + q]];  // (non-pivot column: value 0's never-written entry, under a tag bit that is never set)
+#pragma unroll
+                                    for (int q = 0; q < 3; ++q) {
+                                        unsigned int msk = (unsigned int)((int)(tg << (31 - (h3 + q))) >> 31);
+                                        asm volatile("" : "+v"(msk));
+                                        alo ^= (unsigned int)pp[q].x & msk; ahi ^= (unsigned int)(pp[q].x >> 32) & msk;
+                                        blo ^= (unsigned int)pp[q].y & msk; bhi ^= (unsigned int)(pp[q].y >> 32) & msk;
+                                    }
+                                }
+                                // the absorbed pivots themselves: tag bit j stands for the panel's pivot number npiv + (pivot columns below j)
+                                unsigned int tgc = tg;
+                                if (pivmask != vmask) {  // uniform, rare (a non-pivot column inside the sub-block): squeeze the tag's bits together
+                                    tgc = 0u;
+                                    int cnt = 0;
+#pragma unroll
+                                    for (int j = 0; j < 6; ++j)
+                                        if ((pivmask >> j) & 1u) { tgc |= ((tg >> j) & 1u) << cnt; ++cnt; }
+                                }
+                                const unsigned long long own = (unsigned long long)tgc << npiv;
+                                pub[64 + 64 * which + lane] = make_ulonglong2(((unsigned long long)ahi << 32) | alo, (((unsigned long long)bhi << 32) | blo) ^ own);
+                            }
+                        }
+                    }
+                    __syncthreads();
+#ifdef BPOSD_OSD_DIAG
+                    { const long long t2 = OSD_TICK(); diag_solve += t2 - diag_t1; diag_t1 = t2; }
+#endif
+                    const unsigned int pivmask_all = (unsigned int)__builtin_amdgcn_readfirstlane(L.misc[1]);
+                    if (pivmask_all) {  // uniform
+                        // (E) one table entry per row
+#pragma unroll
+                        for (int k = 0; k < RPT; ++k) {
+                            const unsigned int inf = claim[64 + bv[k]];
+                            ulonglong2 d = pub[64 + bv[k]];
+                            if (won[k] && (inf >> 3) == sbc) {  // the claimant of a taken value: the pivot row of column c0 + jc
+                                const unsigned int jc = inf & 7u;
+                                d = pub[128 + bv[k]];
+                                pinfo[k] = ((w * 64 + c0 + (int)jc) << 6) | (npiv + __popc(pivmask_all & ((1u << jc) - 1u)));
+                            }
+                            row[k][0] ^= d.x;
+                            t[k] ^= d.y;
+                        }
+                        const int nps = __popc(pivmask_all);
+                        npiv += nps;
+                        nrank += nps;
+                        if (nrank >= P.rank) done = true;
+                    }
+#ifdef BPOSD_OSD_DIAG
+                    diag_absorb += OSD_TICK() - diag_t1;
+#endif
                 }
             }
-        panel_done:
-#undef OSD_PIVOT_STEP
-            // every panel starts on proposal buffer 0: nobody may still be reading this panel's last proposals
-            __syncthreads();
 #ifdef BPOSD_OSD_DIAG
             { const long long t1 = OSD_TICK(); diag_panel += t1 - diag_t0; diag_t0 = t1; }
 #endif
@@ -576,7 +653,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         }
         OSD_STAMP(3);
 #ifdef BPOSD_OSD_DIAG
-        if (P.dbg && tid == 0 && slot_id == 0) { P.dbg[1190] = diag_panel; P.dbg[1191] = diag_trail; P.dbg[1192] = nrank; P.dbg[1193] = diag_pub; P.dbg[1194] = diag_build; }
+        if (P.dbg && tid == 0 && slot_id == 0) { P.dbg[1190] = diag_panel; P.dbg[1191] = diag_trail; P.dbg[1192] = nrank; P.dbg[1193] = diag_pub; P.dbg[1194] = diag_build; P.dbg[1195] = diag_claim; P.dbg[1196] = diag_solve; P.dbg[1197] = diag_absorb; }
 #endif
         bool used[RPT];
         int mypos[RPT];

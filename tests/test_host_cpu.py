@@ -229,3 +229,15 @@ def test_bench_batches_are_prefix_stable():
     e_hit, s_hit = bench.make_batch(H, 0.1, 40, seed=5, chunk=16, cache_key="s13")  # served from the cached longer batch
     assert e_hit.base is not None and (e_hit == e_small).all() and (s_hit == s_small).all()
     assert ((H @ e_small.T.astype(int)) % 2 == s_small.T).all()
+
+
+def test_panel_phase_by_six_column_sub_blocks_model():
+    """osd_kernel's panel phase (claims by 6-bit value, the 64 values solved lane by lane, one table entry per row) replayed on
+    random panels against column-by-column Gauss-Jordan: same pivot columns, reduced form, combination masks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "panel_subblock_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "panel_subblock_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed in range(300):
+        mod.check(seed)
