@@ -937,7 +937,9 @@ def main():
             if cfg.startswith("l29k"):  # (100 ms steps whose first two still warm the workspaces up: a few more, for a number close to the one of record)
                 e.steps, e.warmup = 2 * args.extra_steps, 2
             e.cpu_sample = CPU_SAMPLE_EXTRA.get(cfg, 0) if gen == "numpy" else 0
-            e.nbatch = 1
+            # one seeded batch -- two on the large code, like its line of record: a step there costs the SUM of its ~252 eliminations'
+            # CU time, and that sum differs by 20-30 % between batches (batch 0 alone: 10.0 k syndromes/s, batches 0 / 1 alternating: 11.9 k)
+            e.nbatch = 2 if cfg.startswith("l29k") else 1
             runs.append(e)
     # ---- phase 1: codes, batches and every CPU leg, before the GPU is initialised in this process
     preps = [prepare(r, rank, world) for r in runs]
@@ -981,7 +983,7 @@ def main():
             out["configs"][P["name"]]["wall_s"] = time.time() - t1
             P["batches"] = None
             torch.cuda.empty_cache()
-        out["configs_note"] = ("short runs of the other BASELINE.json configurations in the same process (extra-steps timed steps, one seeded batch, "
+        out["configs_note"] = ("short runs of the other BASELINE.json configurations in the same process (extra-steps timed steps, one seeded batch -- two alternating on l29k_ms_e15 --, "
                                "cross-kernel check on the whole batch, a one-core CPU sample where it costs < 10 s; their numbers of record "
                                "with both CPU legs: python bench.py --config NAME, kept under profiles/); h1922_ms_cs7_b1048576 = the headline "
                                "configuration with configs[3]'s whole batch of 2^20 syndromes on the one GPU")
