@@ -625,6 +625,7 @@ def measure(P, rank, local_rank, world):
                          f", {nbuf} packed buffers for {nslots} steps in flight"),
             "bp_variant": a.variant,
             "pipelined_steps": nslots,
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "timed_outputs": ["osdw", "osd0", "bp", "converged", "iters"],
             "batches": (f"{nbatch} distinct seeded batches alternate over the timed steps; the logical error rates, the CPU "
                         "comparison and the isolated kernel times are on batch 0") +
@@ -882,6 +883,12 @@ def summary(rec):
 
 
 def main():
+    # A handle's lanes are HIP streams that must be able to run side by side.  The runtime multiplexes a process's streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that land on one queue run their kernels one after the other;
+    # which streams share depends on how many were created before (measured on l29k_ms_e15, three calls in flight: 12.2 k
+    # syndromes/s alone in a fresh process, 10.0-10.4 k as the fifth decoder of the default run, 10.9 k with 2 queues, 12.1-12.2 k
+    # with 8 in both places).  Read by the runtime when it initialises, i.e. before anything below touches the GPU.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)

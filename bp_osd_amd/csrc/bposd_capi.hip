@@ -1209,7 +1209,7 @@ static int decode_device_impl(bposd_handle* h, const uint8_t* d_synd, int64_t B,
             }
             fprintf(stderr, "[bposd osd phases, s_memtime ticks] sort %lld  rowbuild %lld  eliminate %lld  osd0 %lld  sweep %lld  write %lld\n",
                     st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5]);
-            fprintf(stderr, "[bposd osd elimination] panel phase %lld (claims + barrier %lld, solve %lld, absorb %lld)  trailing phase %lld (publish %lld, tables %lld)  pivots %lld\n", st[1190], st[1195], st[1196], st[1197], st[1191], st[1193], st[1194], st[1192]);
+            fprintf(stderr, "[bposd osd elimination] panel phase %lld (claims + barrier %lld, solve + tables %lld of which the six steps %lld, absorb %lld)  trailing phase %lld (publish %lld, tables %lld)  pivots %lld\n", st[1190], st[1195], st[1196], st[1189], st[1197], st[1191], st[1193], st[1194], st[1192]);
         }
     }
     if (osd_on && !lean) {  // whatever follows on the lane's stream comes after the OSD kernel

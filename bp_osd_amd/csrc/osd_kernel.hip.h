@@ -21,7 +21,8 @@
 //   2. a9  blocked Gauss-Jordan, panels of 64 columns (one register word):
 //          (i) panel phase, two barriers per SIX columns (round 5; one per pivot before): which pivot rows a row
 //          absorbs over six columns depends only on the row's six bits there, so every unused row with a non-zero
-//          value v claims v (LDS atomic; the first claimant publishes its panel word and combination mask), two waves
+//          value v stores (sub-block number, row) into v's claim word -- a plain LDS store, the last one to land is
+//          the row the solvers see -- and its panel word and combination mask into its own slot of rowbuf; two waves
 //          -- alone on their SIMDs while the others wait -- solve the 64 values after the first barrier (lane v =
 //          value v: <= 6 steps of ballot, ffs, readlane, masked XOR; the claimed value whose reduced form has the
 //          lowest column set supplies the pivot row -- any unused row with a 1 in the column is a valid pivot, the
@@ -51,6 +52,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace bposd {
 
@@ -187,8 +189,8 @@ __device__ __forceinline__ void osd_bs_add(unsigned int (&c)[6]) {
 // LDS carve-up, all offsets 8-byte aligned
 struct OsdLds {
     unsigned long long* keys;     // [nsort]; after the sort: first 128 B reused as T-index -> position
-    unsigned long long* pbuf;     // [3][64][2]  per 6-bit value v: (panel word, mask) of the row that claimed it; table D; table D'
-    unsigned int* pcol;           // [3][64]     per value: number of the last sub-block in which it was claimed; pivot info; (idle atomics' targets)
+    unsigned long long* pbuf;     // [2][64][2]  per 6-bit value v: tables D and D' of the current sub-block
+    unsigned int* pcol;           // [2][64]     per value: (sub-block << 10 | row) of its last claim; pivot info
     unsigned long long* prow;     // [64][W rounded up to even]   trailing words of this panel's pivots
     unsigned long long* tab;      // [16][16][W | 1] XOR combinations of 4 pivots: [group][combination][word]
     unsigned long long* colvec;   // [64][OSD_MAXCV]
@@ -229,12 +231,18 @@ __host__ __device__ constexpr size_t osd_union_bytes(int nsort, int W, int mr) {
     return elim > fpw ? elim : fpw;
 }
 
+// rowbuf[mr] (16 bytes per row: the claimants' panel words and masks during the panel phase) lies over the sort keys, which are
+// dead between the sort and the sweep; a shape with more rows than nsort / 2 (many short rows) gets a region of its own at the end.
+__host__ __device__ constexpr size_t osd_rowbuf_extra(int nsort, int mr) {
+    return (size_t)mr * 16 > (size_t)nsort * 8 ? (size_t)mr * 16 + 16 : 0;
+}
+
 __host__ __device__ constexpr size_t osd_lds_bytes(int W, int mr) {
     const int nsort = osd_nsort(W);
     size_t b = 0;
     b += (size_t)nsort * 8;                     // keys
-    b += (size_t)3 * 64 * 2 * 8;                // pbuf
-    b += (size_t)3 * 64 * 4;                    // pcol
+    b += (size_t)2 * 64 * 2 * 8;                // pbuf
+    b += (size_t)2 * 64 * 4;                    // pcol
     b += (size_t)OSD_MAXCV * 8;                 // yvec
     b += (size_t)W * 8;                         // npmask
     b += 2 * 8;                                 // best64
@@ -246,6 +254,7 @@ __host__ __device__ constexpr size_t osd_lds_bytes(int W, int mr) {
     b += (size_t)nsort;                         // xout
     b = (b + 15) & ~(size_t)15;                 // the union region is 16-byte aligned (16-byte pivot-row writes)
     b += osd_union_bytes(nsort, W, mr);         // prow | tab | colvec  /  fp64-weight tables
+    b += osd_rowbuf_extra(nsort, mr);           // rowbuf, where the (dead) sort keys cannot hold it
     return b + 64;
 }
 
@@ -318,8 +327,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
     {
         unsigned char* p = smem;
         L.keys = (unsigned long long*)p; p += (size_t)NS * 8;
-        L.pbuf = (unsigned long long*)p; p += (size_t)3 * 64 * 2 * 8;
-        L.pcol = (unsigned int*)p; p += (size_t)3 * 64 * 4;
+        L.pbuf = (unsigned long long*)p; p += (size_t)2 * 64 * 2 * 8;
+        L.pcol = (unsigned int*)p; p += (size_t)2 * 64 * 4;
         L.yvec = (unsigned long long*)p; p += (size_t)OSD_MAXCV * 8;
         L.npmask = (unsigned long long*)p; p += (size_t)W * 8;
         L.best64 = (unsigned long long*)p; p += 2 * 8;
@@ -335,8 +344,10 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         L.tab = L.prow + (size_t)64 * PS;
         L.colvec = L.tab + (size_t)16 * 16 * WS;
     }
-    for (int i = tid; i < 3 * 64; i += NT) L.pcol[i] = 0u;  // no value claimed yet (sub-blocks count from 1, over all eliminations)
-    unsigned int sbc = 1u;  // number of the current six-column sub-block (uniform)
+    // the claimants' (panel word, mask) pairs of the current sub-block, one slot per row
+    ulonglong2* const rowbuf = osd_rowbuf_extra(NS, NT * RPT)
+                                   ? reinterpret_cast<ulonglong2*>(smem + ((((size_t)((unsigned char*)L.prow - smem) + osd_union_bytes(NS, W, NT * RPT)) + 15) & ~(size_t)15))
+                                   : reinterpret_cast<ulonglong2*>(L.keys);
     for (;;) {
         if (tid == 0) L.misc[0] = atomicAdd(&P.counters[2], 1);
         __syncthreads();
@@ -359,6 +370,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             L.pivrow[i] = -1;
         }
         for (int i = tid; i < 32 * W; i += NT) L.wt[i] = 0x00010001;  // 16-bit single-candidate weights, two per word: 1 each
+        for (int i = tid; i < 2 * 64; i += NT) L.pcol[i] = 0u;          // no value claimed yet: the panel phase's sub-blocks count from 1
+        unsigned int sbc = 1u;  // number of the current six-column sub-block of this elimination (uniform; <= 11 * W)
         __syncthreads();
         for (int k = 2; k <= NS; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         int nrank = 0;
         bool done = false;
 #ifdef BPOSD_OSD_DIAG
-        long long diag_panel = 0, diag_trail = 0, diag_t0 = 0, diag_pub = 0, diag_build = 0, diag_claim = 0, diag_solve = 0, diag_absorb = 0, diag_t1 = 0;
+        long long diag_panel = 0, diag_trail = 0, diag_t0 = 0, diag_pub = 0, diag_build = 0, diag_claim = 0, diag_solve = 0, diag_absorb = 0, diag_t1 = 0, diag_steps = 0;
 #define OSD_TICK() ((long long)__builtin_amdgcn_s_memtime())
 #endif
 #pragma clang loop unroll(disable)
@@ -433,14 +446,14 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             // ---------------- (i) panel phase on the current word row[k][0]: two barriers per SIX columns.
             // What a row has to absorb while six columns are eliminated depends only on its six bits there (its
             // "value" v): all rows with the same v receive the same combination of the sub-block's <= 6 pivot rows
-            // as they stood at its start.  (A) every unused row with v != 0 claims v in LDS; the first claimant
-            // publishes its (panel word, mask).  (C) behind the first barrier waves 0 and 1 -- alone on their SIMDs
-            // while the others wait, so at the full issue rate -- solve the 64 values, lane v = value v: for column j
-            // the lowest claimed value whose reduced form has bit j set supplies the pivot row (none: the column is
-            // non-pivot -- unused rows are zero in every column already passed, and every unused row's value is a
-            // claimed one), every value with bit j set absorbs it; a second register follows the pivot rows
-            // themselves.  Wave 0 then writes, per value, the XOR of the published (word, mask) pairs its tag names
-            // (table D), wave 1 the same for the pivot row taken from each value (table D').  (E) behind the second
+            // as they stood at its start.  (A) every unused row with v != 0 stores its number into v's claim word and
+            // its (panel word, mask) into its own slot of rowbuf.  (C) behind the first barrier waves 0 and 1 -- alone on
+            // their SIMDs while the others wait -- solve the 64 values, lane v = value v: for column j the lowest claimed
+            // value whose reduced form has bit j set supplies the pivot row, the row whose claim landed last (none: the
+            // column is non-pivot -- unused rows are zero in every column already passed, and every unused row's value
+            // is a claimed one), every value with bit j set absorbs it; a second register follows the pivot rows
+            // themselves.  Wave 0 then writes, per value, the XOR of the (word, mask) pairs its tag names (table D),
+            // wave 1 the same for the pivot row taken from each value (table D').  (E) behind the second
             // barrier a row XORs ONE table entry, picked by its value (the claimant of a taken value: from D').
             unsigned long long t[RPT];
 #pragma unroll
@@ -450,9 +463,8 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
             const int nbc = nb < 64 ? nb : 64;    // word) lies beyond them and never takes part in a value
             if (nb <= 0 || nrank >= P.rank) done = true;
             {
-                typedef __attribute__((address_space(3))) unsigned int* lds_u32p;
-                ulonglong2* const pub = reinterpret_cast<ulonglong2*>(L.pbuf);  // [64] published rows, [64] D, [64] D'
-                unsigned int* const claim = L.pcol;                              // [64] claims, [64] per-value info, [64] idle targets
+                ulonglong2* const pub = reinterpret_cast<ulonglong2*>(L.pbuf);  // [64] table D, [64] table D'
+                unsigned int* const claim = L.pcol;                              // [64] claims, [64] per-value pivot info
                 const int nsolve = nwaves < 2 ? nwaves : 2;
                 const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // (the compiler cannot see that tid >> 6 is wave-uniform)
 #pragma clang loop unroll(disable)
@@ -462,22 +474,17 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
 #ifdef BPOSD_OSD_DIAG
                     diag_t1 = OSD_TICK();
 #endif
-                    // (A) claims: both rows' atomics go out together (a row that does not claim aims at a word of its
-                    // own lane that nobody reads), one wait, then the winners publish
-                    unsigned int bv[RPT], prev[RPT];
-                    bool cl[RPT];
+                    // (A) claims: a plain store of (sub-block number, row) per claimed value -- whichever claimant's store lands
+                    // last is the row the solvers see -- and every claimant's (panel word, mask) into its own slot of rowbuf:
+                    // nothing to wait for before the barrier (an atomic with return, the first form of this, cost a round trip)
+                    unsigned int bv[RPT];
 #pragma unroll
                     for (int k = 0; k < RPT; ++k) {
                         bv[k] = (unsigned int)(row[k][0] >> c0) & vmask;
-                        cl[k] = pinfo[k] < 0 && bv[k] != 0u;  // rows beyond m are zero: they never claim
-                        prev[k] = __hip_atomic_fetch_max((lds_u32p)(size_t)(claim + (cl[k] ? bv[k] : 128u + (unsigned int)lane)), sbc, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    bool won[RPT];
-#pragma unroll
-                    for (int k = 0; k < RPT; ++k) {
-                        won[k] = cl[k] && prev[k] != sbc;
-                        if (won[k]) pub[bv[k]] = make_ulonglong2(row[k][0], t[k]);
+                        if (pinfo[k] < 0 && bv[k] != 0u) {  // rows beyond m are zero: they never claim
+                            claim[bv[k]] = (sbc << 10) | (unsigned int)(tid + k * NT);
+                            rowbuf[tid + k * NT] = make_ulonglong2(row[k][0], t[k]);
+                        }
                     }
                     __syncthreads();
 #ifdef BPOSD_OSD_DIAG
@@ -487,40 +494,56 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                         // (C) X, lane v: reduced value (bits 0-5) and tag (bits 8-13) of the rows that hold value v; Y, lane
                         // v: the same for the pivot row taken from value v, with its column (bits 16-18) and bit 20 set, 0 if
                         // none was.  Tag bit j = "has absorbed the pivot row of the sub-block's column j as it stood at the
-                        // sub-block's start"; lj[j] = the value that row was taken from (scalar).  A value has no bit beyond
+                        // sub-block's start".  A value has no bit beyond
                         // the valid columns, so j >= wsb never finds a candidate.  (The same on the scalar unit -- value sets
                         // as 64-bit masks, s_bitcmp1 / s_cselect / s_xor -- was built and measured no faster: a lone wave
                         // issues about one instruction per eight cycles whatever the unit, and this form has fewer.)
-                        unsigned long long avm = __ballot(claim[lane] == sbc) & ~1ull;  // claimed values
+                        const unsigned int cw = claim[lane];  // last claim of value `lane`: (sub-block number << 10) | row
+                        const unsigned long long avm0 = __ballot((cw >> 10) == sbc) & ~1ull;  // claimed values
                         unsigned int X = (unsigned int)lane, Y = 0u;
                         unsigned int pivmask = 0u;  // columns of the sub-block that are pivot columns (uniform)
-                        int lj[6];
-                        int room = P.rank - nrank;  // pivots still to find (> 0 here)
+                        ulonglong2 pp[6];  // (panel word, mask) of column j's pivot row as it stood at the sub-block's start: requested the
+                                           // moment the row is known, so that the table pass below finds them loaded
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            lj[j] = 0;
-                            unsigned int mh = (unsigned int)((int)(X << (31 - j)) >> 31);  // all ones where bit j of the reduced value is set
-                            asm volatile("" : "+v"(mh));
-                            const unsigned long long cand = __ballot(mh != 0u) & avm;
-                            if (cand) {  // uniform
-                                const int l = __ffsll((long long)cand) - 1;
-                                const unsigned int ppk = (unsigned int)__builtin_amdgcn_readlane((int)X, l) & 0x3f3fu;
-                                const unsigned int pn = ppk ^ (0x100u << j);
-                                X ^= pn & mh;
-                                unsigned int my = (unsigned int)((int)(Y << (31 - j)) >> 31);
-                                asm volatile("" : "+v"(my));
-                                Y ^= pn & my;
-                                unsigned int ml = lane == l ? ~0u : 0u;
-                                asm volatile("" : "+v"(ml));
-                                Y |= (ppk | ((unsigned int)j << 16) | (1u << 20)) & ml;  // (a value is taken at most once: Y was 0 there)
-                                lj[j] = l;
-                                pivmask |= 1u << j;
-                                if (--room == 0) avm = 0ull;  // rank reached: no further pivots
+                        for (int j = 0; j < 6; ++j) pp[j] = make_ulonglong2(0ull, 0ull);
+                        // LIMITED: fewer than six pivots are left to find (the elimination's last sub-block): count them down
+                        auto solve = [&](auto limited) {
+                            unsigned long long avm = avm0;
+                            int room = P.rank - nrank;  // pivots still to find (> 0 here)
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) {
+                                unsigned int mh = (unsigned int)((int)(X << (31 - j)) >> 31);  // all ones where bit j of the reduced value is set
+                                asm volatile("" : "+v"(mh));
+                                const unsigned long long cand = __ballot(mh != 0u) & avm;
+                                if (cand) {  // uniform
+                                    const int l = __ffsll((long long)cand) - 1;
+                                    const unsigned int ppk = (unsigned int)__builtin_amdgcn_readlane((int)X, l) & 0x3f3fu;
+                                    const unsigned int pn = ppk ^ (0x100u << j);
+                                    X = __builtin_amdgcn_bitop3_b32(pn, X, mh, 0x6c);  // X ^= pn & mh
+                                    unsigned int my = (unsigned int)((int)(Y << (31 - j)) >> 31);
+                                    asm volatile("" : "+v"(my));
+                                    Y = __builtin_amdgcn_bitop3_b32(pn, Y, my, 0x6c);
+                                    // (a value is taken at most once: Y was 0 in lane l)
+                                    unsigned int ml = lane == l ? ~0u : 0u;
+                                    asm volatile("" : "+v"(ml));
+                                    Y |= (ppk | ((unsigned int)j << 16) | (1u << 20)) & ml;
+                                    pp[j] = rowbuf[__builtin_amdgcn_readlane((int)cw, l) & 1023];
+                                    pivmask |= 1u << j;
+                                    if (decltype(limited)::value && --room == 0) avm = 0ull;  // rank reached: no further pivots
+                                }
                             }
-                        }
+                        };
+#ifdef BPOSD_OSD_DIAG
+                        const long long ts0 = OSD_TICK();
+#endif
+                        if (P.rank - nrank >= 6) solve(std::false_type{});
+                        else solve(std::true_type{});
+#ifdef BPOSD_OSD_DIAG
+                        diag_steps += OSD_TICK() - ts0;
+#endif
                         if (wave_u == 0) {
-                            // per value: the sub-block's number if a pivot row was taken from it, and that row's column
-                            claim[64 + lane] = ((Y >> 20) & 1u) * (sbc << 3) | ((Y >> 16) & 7u);
+                            // per value: if a pivot row was taken from it, the sub-block's number, that row and its column; else 0
+                            claim[64 + lane] = ((Y >> 20) & 1u) * ((sbc << 13) | (((Y >> 16) & 7u) << 10) | (cw & 1023u));
                             if (lane == 0) L.misc[1] = (int)pivmask;
                         }
                         if (pivmask) {  // uniform
@@ -528,17 +551,13 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                                 const unsigned int tg = ((which ? Y : X) >> 8) & 63u;
                                 unsigned int alo = 0u, ahi = 0u, blo = 0u, bhi = 0u;
 #pragma unroll
-                                for (int h3 = 0; h3 < 6; h3 += 3) {
-                                    ulonglong2 pp[3];
-#pragma unroll
-                                    for (int q = 0; q < 3; ++q) pp[q] = pub[lj[h3 + q]];  // (non-pivot column: value 0's never-written entry, under a tag bit that is never set)
-#pragma unroll
-                                    for (int q = 0; q < 3; ++q) {
-                                        unsigned int msk = (unsigned int)((int)(tg << (31 - (h3 + q))) >> 31);
-                                        asm volatile("" : "+v"(msk));
-                                        alo ^= (unsigned int)pp[q].x & msk; ahi ^= (unsigned int)(pp[q].x >> 32) & msk;
-                                        blo ^= (unsigned int)pp[q].y & msk; bhi ^= (unsigned int)(pp[q].y >> 32) & msk;
-                                    }
+                                for (int j = 0; j < 6; ++j) {
+                                    unsigned int msk = (unsigned int)((int)(tg << (31 - j)) >> 31);
+                                    asm volatile("" : "+v"(msk));
+                                    alo = __builtin_amdgcn_bitop3_b32((unsigned int)pp[j].x, alo, msk, 0x6c);  // alo ^= word & msk
+                                    ahi = __builtin_amdgcn_bitop3_b32((unsigned int)(pp[j].x >> 32), ahi, msk, 0x6c);
+                                    blo = __builtin_amdgcn_bitop3_b32((unsigned int)pp[j].y, blo, msk, 0x6c);
+                                    bhi = __builtin_amdgcn_bitop3_b32((unsigned int)(pp[j].y >> 32), bhi, msk, 0x6c);
                                 }
                                 // the absorbed pivots themselves: tag bit j stands for the panel's pivot number npiv + (pivot columns below j)
                                 unsigned int tgc = tg;
@@ -550,7 +569,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
                                         if ((pivmask >> j) & 1u) { tgc |= ((tg >> j) & 1u) << cnt; ++cnt; }
                                 }
                                 const unsigned long long own = (unsigned long long)tgc << npiv;
-                                pub[64 + 64 * which + lane] = make_ulonglong2(((unsigned long long)ahi << 32) | alo, (((unsigned long long)bhi << 32) | blo) ^ own);
+                                pub[64 * which + lane] = make_ulonglong2(((unsigned long long)ahi << 32) | alo, (((unsigned long long)bhi << 32) | blo) ^ own);
                             }
                         }
                     }
@@ -564,10 +583,10 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
 #pragma unroll
                         for (int k = 0; k < RPT; ++k) {
                             const unsigned int inf = claim[64 + bv[k]];
-                            ulonglong2 d = pub[64 + bv[k]];
-                            if (won[k] && (inf >> 3) == sbc) {  // the claimant of a taken value: the pivot row of column c0 + jc
-                                const unsigned int jc = inf & 7u;
-                                d = pub[128 + bv[k]];
+                            ulonglong2 d = pub[bv[k]];
+                            if (inf == ((sbc << 13) | (inf & 0x1c00u) | (unsigned int)(tid + k * NT))) {  // the row the solvers took for column c0 + jc
+                                const unsigned int jc = (inf >> 10) & 7u;
+                                d = pub[64 + bv[k]];
                                 pinfo[k] = ((w * 64 + c0 + (int)jc) << 6) | (npiv + __popc(pivmask_all & ((1u << jc) - 1u)));
                             }
                             row[k][0] ^= d.x;
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(64 * OSD_MAXW) void osd_kernel(const OsdParams P) {
         }
         OSD_STAMP(3);
 #ifdef BPOSD_OSD_DIAG
-        if (P.dbg && tid == 0 && slot_id == 0) { P.dbg[1190] = diag_panel; P.dbg[1191] = diag_trail; P.dbg[1192] = nrank; P.dbg[1193] = diag_pub; P.dbg[1194] = diag_build; P.dbg[1195] = diag_claim; P.dbg[1196] = diag_solve; P.dbg[1197] = diag_absorb; }
+        if (P.dbg && tid == 0 && slot_id == 0) { P.dbg[1190] = diag_panel; P.dbg[1191] = diag_trail; P.dbg[1192] = nrank; P.dbg[1193] = diag_pub; P.dbg[1194] = diag_build; P.dbg[1195] = diag_claim; P.dbg[1196] = diag_solve; P.dbg[1197] = diag_absorb; P.dbg[1189] = diag_steps; }
 #endif
         bool used[RPT];
         int mypos[RPT];
