@@ -1580,6 +1580,37 @@ def test_osd_kernel_window_and_workgroup_shapes(gpu_ready, m, n, osd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,n,osd", [(700, 120, ("osd_cs", 12)), (520, 250, ("osd_e", 6)), (1000, 60, ("osd_cs", 5))])
+def test_osd_kernel_tall_matrices(gpu_ready, m, n, osd):
+    """More checks than bits (redundant checks): the register-resident OSD kernel then has more rows than half its sort size, and
+    the row buffer of its panel phase (the claimants' panel words, 16 bytes per row) no longer fits over the sort keys -- it gets
+    an LDS region of its own (osd_rowbuf_extra).  Every check holds two or three random bits of the first half of the columns, the other columns are sums of two of those.
+    Bit-exact against the oracle."""
+    import scipy.sparse as sp
+    from bp_osd_amd import BpOsdDecoder
+    from oracle import OracleDecoder
+
+    rng = np.random.default_rng(m * 11 + n)
+    h = n // 2
+    A = np.zeros((m, h), dtype=np.uint8)
+    for c in range(m):
+        A[c, rng.choice(h, size=int(rng.integers(2, 4)), replace=False)] = 1
+    # the second half of the columns: sums of two columns of the first half, so n - rank >= n / 2 and OSD-E / OSD-CS have columns to search
+    B = np.stack([A[:, a] ^ A[:, b] for a, b in (rng.choice(h, size=2, replace=False) for _ in range(n - h))], axis=1)
+    Hd = np.concatenate([A, B], axis=1)
+    Hd = Hd[:, rng.permutation(n)]
+    H = sp.csr_matrix(Hd)
+    q = 0.08
+    _, syn = _syndromes(H, q, 64, 9)
+    kw = dict(error_rate=q, max_iter=2, bp_method="ms", ms_scaling_factor=0.8, osd_method=osd[0], osd_order=osd[1])
+    g = BpOsdDecoder(H, **kw)
+    ref = OracleDecoder(H, **kw).decode_batch(syn)
+    got = _gpu_decode(g, syn)
+    assert (~got["converged"]).mean() > 0.3, "the elimination hardly ran"
+    _compare_exact(got, ref)
+
+
+@pytest.mark.gpu
 def test_decode_attributes_are_lazy_but_exact(gpu_ready, hgp400):
     """``decode()`` converts its result attributes when they are read, and obtains ``log_prob_ratios`` by repeating the
     deterministic call with the LLR output on -- with the channel the decode ran under, also if ``update_channel_probs``
