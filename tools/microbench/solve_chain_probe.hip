@@ -13,7 +13,7 @@
 
 __device__ __forceinline__ long long tick() { return (long long)__builtin_amdgcn_s_memtime(); }
 
-// MODE 0: solve steps; 1: dependent v_xor chain; 2: dependent s_xor chain
+// MODE 0: solve steps; 1: dependent v_xor chain; 2: dependent s_xor chain; 3: six INDEPENDENT v_xor per iteration; 4: six independent s_xor
 template <int MODE>
 __global__ __launch_bounds__(512) void probe(long long* out, unsigned int* sink, int nrep, int others) {
     __shared__ unsigned long long lds[4096];
@@ -55,6 +55,20 @@ __global__ __launch_bounds__(512) void probe(long long* out, unsigned int* sink,
                 for (int j = 0; j < 6; ++j) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v) : "v"(X));
             }
             acc = v;
+        } else if (MODE == 3) {
+            unsigned int v0 = lane, v1 = lane + 1, v2 = lane + 2, v3 = lane + 3, v4 = lane + 4, v5 = lane + 5;
+            for (int r = 0; r < nrep; ++r) {
+                asm volatile("v_xor_b32 %0, %0, %6\n\tv_xor_b32 %1, %1, %6\n\tv_xor_b32 %2, %2, %6\n\tv_xor_b32 %3, %3, %6\n\tv_xor_b32 %4, %4, %6\n\tv_xor_b32 %5, %5, %6"
+                             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5) : "v"(X));
+            }
+            acc = v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5;
+        } else if (MODE == 4) {
+            unsigned int s0 = (unsigned int)__builtin_amdgcn_readfirstlane(nrep), s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3, s4 = s0 + 4, s5 = s0 + 5;
+            for (int r = 0; r < nrep; ++r) {
+                asm volatile("s_xor_b32 %0, %0, 0x55\n\ts_xor_b32 %1, %1, 0x55\n\ts_xor_b32 %2, %2, 0x55\n\ts_xor_b32 %3, %3, 0x55\n\ts_xor_b32 %4, %4, 0x55\n\ts_xor_b32 %5, %5, 0x55"
+                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5) : : "scc");
+            }
+            acc = s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5;
         } else {
             unsigned int sv = (unsigned int)__builtin_amdgcn_readfirstlane(nrep);
             for (int r = 0; r < nrep; ++r) {
@@ -102,6 +116,8 @@ int main() {
             if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(ncu), dim3(512), 0, 0, d_out, d_sink, nrep, others);
             if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(ncu), dim3(512), 0, 0, d_out, d_sink, nrep, others);
             if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(ncu), dim3(512), 0, 0, d_out, d_sink, nrep, others);
+            if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(ncu), dim3(512), 0, 0, d_out, d_sink, nrep, others);
+            if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(ncu), dim3(512), 0, 0, d_out, d_sink, nrep, others);
             hipDeviceSynchronize();
         }
         hipMemcpy(h.data(), d_out, sizeof(long long) * ncu, hipMemcpyDeviceToHost);
@@ -114,5 +130,7 @@ int main() {
     run("(c) solve step, the seven other waves reading LDS", 0, 2);
     run("(d) one dependent v_xor_b32 (x 6 per iteration), alone", 1, 0);
     run("(e) one dependent s_xor_b32 (x 6 per iteration), alone", 2, 0);
+    run("(f) one of six INDEPENDENT v_xor_b32 per iteration, alone", 3, 0);
+    run("(g) one of six independent s_xor_b32 per iteration, alone", 4, 0);
     return 0;
 }
