@@ -90,6 +90,12 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  bp_osd_amd has no CPU fallback."
         )
+    # A handle's lanes are HIP streams that should run side by side; the runtime multiplexes a process's streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one take turns.  Read when the runtime starts, so this
+    # only helps a process that has not touched the GPU yet; never overrides the caller's own setting.  (Measured, DESIGN.md
+    # section 1: one synchronous host-to-host call of 131072 syndromes 30.7 -> 27.5 ms, BASELINE configs[4] as the fifth handle of
+    # a process 10.0-10.4 k -> 12.1 k syndromes/s.)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.bposd_device_count.restype = C.c_int
